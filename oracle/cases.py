@@ -1,0 +1,60 @@
+"""The table of golden cases: shared by tools/make_golden.py (which runs the REFERENCE on
+them) and by the tests (which run the oracle and the HIP path on them).  Data only."""
+
+SINGLE_CRITERIA = (
+    [f"div_{d}_{m}_aug{a}" for d in ("js", "kl") for m in ("f1", "dcg") for a in (1, 0)]
+    + [f"{c}_{m}" for m in ("f1", "dcg") for c in ("choopy", "attncutloss")]
+)
+FEW = ["div_js_f1_aug1", "div_kl_dcg_aug0", "choopy_f1"]
+MT = ["mtcut_f1", "mtcut_dcg"]
+
+
+def _case(tag, model, kwargs, batch, seq_len, n_feat, seed, criteria, grad_crit,
+          gate_scale=None, w_r=0.5, w_c=0.5):
+    return dict(tag=tag, model=model, kwargs=kwargs, batch=batch, seq_len=seq_len, n_feat=n_feat,
+                seed=seed, criteria=list(criteria), grad_crit=grad_crit, gate_scale=gate_scale,
+                w_r=w_r, w_c=w_c)
+
+
+MODEL_CASES = [
+    _case("attncut_b5_s300", "AttnCut", {}, 5, 300, 3, 101, SINGLE_CRITERIA, "div_js_f1_aug1"),
+    _case("attncut_b8_s100", "AttnCut", {}, 8, 100, 3, 102, FEW, "div_js_f1_aug1"),
+    _case("attncut_b8_s200", "AttnCut", {}, 8, 200, 3, 103, FEW, "div_kl_dcg_aug0"),
+    _case("attncut_b63_s300", "AttnCut", {}, 63, 300, 3, 104, ["div_js_f1_aug1"], "div_js_f1_aug1"),
+    _case("choopy_b5_s300", "Choopy", {}, 5, 300, 1, 111, SINGLE_CRITERIA, "choopy_f1"),
+    _case("choopy_b32_s300", "Choopy", {}, 32, 300, 1, 112, ["choopy_f1"], "choopy_f1"),
+    _case("choopy_b6_s40", "Choopy", {"seq_len": 40}, 6, 40, 1, 113, FEW, "choopy_f1"),
+    _case("mtattncut_t3_b5_s300", "MtAttnCut", {"num_tasks": 3}, 5, 300, 3, 122, MT, "mtcut_f1"),
+    _case("mtattncut_t21_b5_s300", "MtAttnCut", {"num_tasks": 2.1}, 5, 300, 3, 120, MT, "mtcut_f1"),
+    _case("mtattncut_t22_b5_s300", "MtAttnCut", {"num_tasks": 2.2}, 5, 300, 3, 121, MT, "mtcut_f1"),
+    _case("mtattncut_t3_b8_s100", "MtAttnCut", {"num_tasks": 3}, 8, 100, 3, 127, MT, "mtcut_dcg"),
+    _case("mtchoopy_t3_b5_s300", "MtChoopy", {"num_tasks": 3}, 5, 300, 1, 131, MT, "mtcut_f1"),
+    _case("mtchoopy_t21_b4_s300", "MtChoopy", {"num_tasks": 2.1}, 4, 300, 1, 132, MT, "mtcut_f1"),
+    _case("mmoecut_e3_t3_b5_s300", "MMOECut", {"num_experts": 3, "num_tasks": 3}, 5, 300, 3, 141, MT,
+          "mtcut_f1", w_r=0.4, w_c=0.6),
+    _case("mmoecut_e4_t21_b5_s300", "MMOECut", {"num_experts": 4, "num_tasks": 2.1}, 5, 300, 3, 142, MT,
+          "mtcut_f1", w_r=0.4, w_c=0.6),
+    _case("mmoecut_e4_t22_b5_s300", "MMOECut", {"num_experts": 4, "num_tasks": 2.2}, 5, 300, 3, 143, MT,
+          "mtcut_f1", w_r=0.4, w_c=0.6),
+    _case("mmoecut_e3_t3_b4_s300_refgate", "MMOECut", {"num_experts": 3, "num_tasks": 3}, 4, 300, 3, 144, MT,
+          "mtcut_f1", gate_scale=1.0, w_r=0.4, w_c=0.6),
+    _case("mmoecut_e3_t3_b6_s40", "MMOECut", {"num_experts": 3, "num_tasks": 3, "seq_len": 40}, 6, 40, 3, 145, MT,
+          "mtcut_f1", w_r=0.4, w_c=0.6),
+]
+CASE_BY_TAG = {c["tag"]: c for c in MODEL_CASES}
+
+
+def make_criterion(losses_mod, name, case=None):
+    """Build criterion `name` from a losses module exposing the reference's class names
+    (the reference's utils.losses, oracle.losses, or the HIP package's utils.losses)."""
+    parts = name.split("_")
+    if parts[0] == "div":
+        return losses_mod.DivLoss(metric=parts[2], div_type=parts[1], augmented=parts[3] == "aug1")
+    if parts[0] == "choopy":
+        return losses_mod.ChoopyLoss(metric=parts[1])
+    if parts[0] == "attncutloss":
+        return losses_mod.AttnCutLoss(metric=parts[1])
+    if parts[0] == "mtcut":
+        return losses_mod.MtCutLoss(metric=parts[1], rerank_weight=case["w_r"], classi_weight=case["w_c"],
+                                    num_tasks=case["kwargs"]["num_tasks"])
+    raise KeyError(name)

@@ -1,0 +1,64 @@
+"""CPU restatement of the evaluation metrics (TEST INFRASTRUCTURE ONLY).
+
+    cut_positions   run.py:137-142          k = argmax_j p[i, j] + 1 (first maximum)
+    Metric.f1       utils/metrics.py:15-24  F1 of the top-k prefix, float64, batch mean
+    Metric.dcg      utils/metrics.py:26-38  penalised DCG of the top-k prefix, float64, batch mean
+
+Known answers carried by the reference (utils/metrics.py:104-109):
+    labels [[1,0,1],[0,0,1],[1,0,0]], k_s [1,2,1] -> f1 0.5555555555555555, dcg 0.1230234154761809
+"""
+import math
+
+import numpy as np
+
+# utils/metrics.py:7 - python-float log with explicit base 2, 300 entries
+DCG_COEF = [math.log(j + 2, 2) for j in range(300)]
+
+
+def dcg_coef(seq_len):
+    if seq_len > len(DCG_COEF):
+        return [math.log(j + 2, 2) for j in range(seq_len)]
+    return DCG_COEF[:seq_len]
+
+
+def cut_positions(p):
+    """p: (B,S) or (B,S,1) array of cut probabilities -> (B,) int k in 1..S."""
+    p = np.asarray(p)
+    if p.ndim == 3:
+        p = p[:, :, 0]
+    return np.argmax(p, axis=1) + 1
+
+
+def f1_per_list(labels, k_s):
+    labels = np.asarray(labels, dtype=np.float64)
+    out = np.zeros(len(labels), dtype=np.float64)
+    for i, k in enumerate(k_s):
+        k = int(k)
+        n_rel = labels[i].sum()
+        hit = labels[i, :k].sum()
+        prec = hit / k
+        rec = hit / n_rel if n_rel != 0 else 0.0
+        out[i] = 2 * prec * rec / (prec + rec) if prec + rec != 0 else 0.0
+    return out
+
+
+def dcg_per_list(labels, k_s, penalty=-1):
+    labels = np.asarray(labels)
+    out = np.zeros(len(labels), dtype=np.float64)
+    for i, k in enumerate(k_s):
+        k = int(k)
+        head = labels[i, :k]
+        coef = np.asarray(dcg_coef(labels.shape[1])[:k], dtype=np.float64)
+        gain = np.where(head == 1, 1.0, float(penalty))
+        out[i] = (gain / coef).sum()
+    return out
+
+
+class Metric:
+    @classmethod
+    def f1(cls, labels, k_s):
+        return float(np.mean(f1_per_list(labels, k_s)))
+
+    @classmethod
+    def dcg(cls, labels, k_s, penalty=-1):
+        return float(np.mean(dcg_per_list(labels, k_s, penalty)))

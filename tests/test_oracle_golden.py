@@ -1,0 +1,145 @@
+"""Pin the CPU oracle to the reference: every golden vector under tests/golden/ was produced by
+the reference itself (tools/make_golden.py); the oracle must reproduce it.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import explicit, losses as olosses, metrics as ometrics, models as omodels
+from oracle.cases import MODEL_CASES, SINGLE_CRITERIA, make_criterion
+
+torch.set_num_threads(8)
+SMALL = [c for c in MODEL_CASES if c["batch"] <= 8]
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=lambda c: c["tag"])
+def test_model_forward_loss_metrics(case):
+    gold = gu.load(case["tag"])
+    model, x, y = gu.build(omodels, case)
+    np.testing.assert_array_equal(x.numpy(), gold["x"])
+    np.testing.assert_array_equal(y.numpy(), gold["y"])
+    model.train()
+    outs = gu.as_list(model(x))
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().squeeze(2).numpy(), gold[f"out{i}"], rtol=0, atol=1e-6)
+    k_s = ometrics.cut_positions(outs[-1].detach().numpy())
+    np.testing.assert_array_equal(k_s, gold["k_s"])
+    # F1: the reference divides float32 label sums; under numpy>=2 (this container) that stays
+    # float32, under the numpy<1.20 it was written for it promoted to float64.  The oracle uses
+    # float64, so agreement is to fp32 rounding only.
+    assert abs(ometrics.Metric.f1(y.numpy(), k_s) - float(gold["f1"])) < 1e-6
+    assert abs(ometrics.Metric.dcg(y.numpy(), k_s) - float(gold["dcg"])) < 1e-12
+    for cname in case["criteria"]:
+        loss = make_criterion(olosses, cname, case)(model(x), y)
+        ref = float(gold["loss/" + cname])
+        assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref)), (cname, loss.item(), ref)
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: c["tag"])
+def test_model_gradients(case):
+    gold = gu.load(case["tag"])
+    model, x, y = gu.build(omodels, case)
+    model.train()
+    loss = make_criterion(olosses, case["grad_crit"], case)(model(x), y)
+    model.zero_grad()
+    loss.backward()
+    gu.check_grads(model, gold, rtol=1e-4, atol_frac=1e-4)
+
+
+def test_losses_edge_rows_and_gradients():
+    gold = gu.load("losses_edge_s300")
+    y = torch.from_numpy(gold["y"])
+    for cname in SINGLE_CRITERIA:
+        lg = torch.from_numpy(gold["logits"]).clone().requires_grad_(True)
+        p = torch.softmax(lg, dim=1).unsqueeze(2)
+        p.retain_grad()
+        loss = make_criterion(olosses, cname)(p, y)
+        loss.backward()
+        ref = float(gold["loss/" + cname])
+        assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref)), cname
+        scale = np.abs(gold["dp/" + cname]).max()
+        assert np.abs(p.grad.squeeze(2).numpy() - gold["dp/" + cname]).max() <= 2e-5 * scale, cname
+        assert np.abs(lg.grad.numpy() - gold["dlogit/" + cname]).max() <= 1e-6, cname
+
+
+def test_reward_matrix_closed_form_matches_loop_and_reference():
+    gold = gu.load("losses_edge_s300")
+    y = torch.from_numpy(gold["y"])
+    for metric, tol in (("f1", 2e-7), ("dcg", 2e-5)):
+        closed = olosses.reward_matrix(y, metric).numpy()
+        assert np.abs(closed - gold["reward/" + metric]).max() <= tol
+    # the loop-faithful builder on a few rows (it is O(S^2) python)
+    rows = y[[0, 1, 2, 3, 5]][:, :120]
+    for metric, tol in (("f1", 2e-7), ("dcg", 2e-5)):
+        assert (olosses.reward_matrix_loop(rows, metric) - olosses.reward_matrix(rows, metric)).abs().max() <= tol
+
+
+@pytest.mark.parametrize("tag,nt", [("t3", 3), ("t21", 2.1), ("t22", 2.2)])
+@pytest.mark.parametrize("metric", ["f1", "dcg"])
+def test_multitask_criterion(tag, nt, metric):
+    gold = gu.load("losses_edge_s300")
+    y = torch.from_numpy(gold["y"])
+    lg = torch.from_numpy(gold["logits"]).clone().requires_grad_(True)
+    cl = torch.from_numpy(gold["cls_logit"]).clone().requires_grad_(True)
+    rr = torch.from_numpy(gold["rerank"]).clone().requires_grad_(True)
+    p, c, r3 = torch.softmax(lg, 1).unsqueeze(2), torch.sigmoid(cl).unsqueeze(2), rr.unsqueeze(2)
+    outs = [c, r3, p] if nt == 3 else ([c, p] if nt == 2.1 else [r3, p])
+    loss = olosses.MtCutLoss(metric=metric, rerank_weight=0.4, classi_weight=0.6, num_tasks=nt)(outs, y)
+    loss.backward()
+    key = f"mtcut_{tag}_{metric}"
+    assert abs(loss.item() - float(gold["loss/" + key])) <= 2e-6
+    assert np.abs(lg.grad.numpy() - gold["dlogit/" + key]).max() <= 1e-6
+    if nt != 2.2:
+        assert np.abs(cl.grad.numpy() - gold["dcls_logit/" + key]).max() <= 1e-7
+    if nt != 2.1:
+        assert np.abs(rr.grad.numpy() - gold["drerank/" + key]).max() <= 1e-7     # hinge is active here
+
+
+def test_rerank_edges():
+    gold = gu.load("losses_edge_s300")
+    # the reference raises on a batch without positives under torch 2.10 (int tensor with
+    # requires_grad, utils/losses.py:138); its evident intent - a zero loss - is what we return.
+    assert math.isnan(float(gold["rerank_nopos"]))
+    s = torch.from_numpy(gold["rerank"][:3]).unsqueeze(2)
+    assert olosses.RerankLoss()(s, torch.zeros(3, 300)).item() == 0.0
+    y = torch.from_numpy(gold["y"][4:7])
+    assert float(olosses.RerankLoss()((y * 5.0).unsqueeze(2), y)) == float(gold["rerank_inactive"]) == 0.0
+
+
+def test_metric_known_answers():
+    gold = gu.load("losses_edge_s300")
+    kat_x = np.array([[1, 0, 1], [0, 0, 1], [1, 0, 0]])
+    kat_k = np.array([1, 2, 1])
+    # values the reference prints for its own __main__ input (utils/metrics.py:104-109)
+    assert ometrics.Metric.f1(kat_x, kat_k) == 0.5555555555555555 == float(gold["kat_f1"])
+    assert ometrics.Metric.dcg(kat_x, kat_k) == 0.1230234154761809 == float(gold["kat_dcg"])
+    assert abs(ometrics.Metric.f1(gold["y"], gold["k_s"]) - float(gold["metric_f1"])) < 1e-6
+    assert abs(ometrics.Metric.dcg(gold["y"], gold["k_s"]) - float(gold["metric_dcg"])) < 1e-12
+
+
+def test_attention_runs_over_the_list_axis():
+    """lists of one mini-batch are coupled through the encoder."""
+    case = gu.CASE_BY_TAG["attncut_b5_s300"]
+    model, x, _ = gu.build(omodels, case)
+    model.eval()
+    with torch.no_grad():
+        base = model(x)
+        x2 = x.clone()
+        x2[0] += 1.0
+        moved = model(x2)
+    assert (base[1:] - moved[1:]).abs().max() > 1e-7
+
+
+@pytest.mark.parametrize("tag", ["attncut_b5_s300", "choopy_b5_s300"])
+def test_explicit_restatement_matches_stock_modules(tag):
+    case = gu.CASE_BY_TAG[tag]
+    gold = gu.load(tag)
+    model, x, _ = gu.build(omodels, case)
+    sd = model.state_dict()
+    fwd = explicit.attncut_forward if case["model"] == "AttnCut" else explicit.choopy_forward
+    p32 = fwd(x, sd).squeeze(2).numpy()
+    p64 = fwd(x.double(), sd).squeeze(2).numpy()
+    assert np.abs(p32 - gold["out0"]).max() < 1e-6
+    assert np.abs(p64 - gold["out0"]).max() < 1e-6
