@@ -1,0 +1,235 @@
+/*
+ * rlt_hip.h - C ABI of librlt_hip.so: the MI355X (gfx950) implementation of the
+ * ranked-list-truncation forward/backward hot path.
+ *
+ * The reference (Woody5962/Ranked-List-Truncation) has no FFI: its hot path sits behind Python
+ * classes (models/__init__.py:1-12, utils/losses.py, utils/metrics.py).  This header is the
+ * boundary those classes are re-implemented on: every entry point below replaces the arithmetic
+ * of the reference lines it cites, and the Python mirror of the reference's classes
+ * (ranked-list-truncation_amd/{models,utils}) binds exactly these symbols through ctypes.
+ *
+ * Conventions
+ *   - all tensors are fp32 device pointers owned by the caller (labels are fp32 0/1 like the
+ *     reference's), contiguous unless a leading dimension is given; nothing is allocated or
+ *     freed here, workspaces are passed in; no host synchronisation, everything is ordered on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 ok; <0 argument error (RLT_E_*); >0 a hipError_t from the launch;
+ *   - "position-major" activations: token row index t = s*B + b (position s outermost, list b
+ *     innermost), i.e. a (S, B, E) tensor.  The reference keeps (B, S, E) and lets
+ *     nn.TransformerEncoderLayer(batch_first=False) attend over axis 0 = the B lists at each
+ *     position (models/AttnCut.py:9,17-18); position-major makes that attention axis contiguous.
+ *     User-facing inputs/outputs stay in the reference's (B, S, F) / (B, S, 1) layout.
+ */
+#ifndef RLT_HIP_H
+#define RLT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLT_E_ARG      (-1)   /* null pointer / non-positive dimension            */
+#define RLT_E_SHAPE    (-2)   /* dimension outside what the kernels support        */
+#define RLT_E_WORKSPACE (-3)  /* workspace too small                               */
+#define RLT_E_ALIGN    (-4)   /* pointer / leading dimension not 16-byte aligned   */
+
+#define RLT_ABI_VERSION 1
+int rlt_abi_version(void);
+/* human-readable name of an RLT_E_* / hipError_t code (static storage) */
+const char* rlt_error_string(int code);
+
+/* ------------------------------------------------------------------ reward losses (L1-L6)
+ * utils/losses.py:48-68 (ChoopyLoss), :71-96 (AttnCutLoss), :194-233 (DivLoss) with the
+ * reward matrix of :57-65/:81-89/:217-225 built from utils/metrics.py:85-101 in closed form
+ * (prefix sums), fused: one pass over p and labels yields the per-list loss terms and
+ * d(loss)/dp.
+ *   p, labels: (B,S).  metric: RLT_METRIC_*.  kind: RLT_LOSS_*.  tau: reward temperature
+ *   (DivLoss: 0.85 augmented / 1.0; AttnCutLoss: 0.95; ignored for EXPECT).
+ *   dcg_coef: S floats log2(j+2) (utils/metrics.py:7), required for RLT_METRIC_DCG.
+ *   loss_per_list: (B) un-normalised per-list terms; *loss_out = sum(loss_per_list)/B
+ *   (KLDivLoss 'batchmean' / the reference's .div(B)).
+ *   dp: (B,S) or NULL; receives d(loss_out)/dp (already divided by B).
+ *   S <= 1024.
+ */
+#define RLT_METRIC_F1  0
+#define RLT_METRIC_DCG 1
+#define RLT_LOSS_EXPECT 0   /* ChoopyLoss:  -E_p[r]                 */
+#define RLT_LOSS_CE     1   /* AttnCutLoss: -sum q log p            */
+#define RLT_LOSS_KL     2   /* DivLoss kl:  KL(q || p)              */
+#define RLT_LOSS_JS     3   /* DivLoss js:  JS(q, p)                */
+int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                    int metric, int kind, float tau,
+                    float* loss_per_list, float* loss_out, float* dp, void* stream);
+/* reward matrix r (B,S) and its distribution q = softmax(r/tau) (either may be NULL):
+ * the B*S python loop of utils/losses.py:217-228 on its own (tests, plots). */
+int rlt_reward_matrix(const float* labels, const float* dcg_coef, int B, int S, int metric, float tau,
+                      float* r_out, float* q_out, void* stream);
+
+/* ------------------------------------------------------------------ multi-task terms (L7-L8)
+ * utils/losses.py:99-141 (RerankLoss) and nn.BCELoss of :177,:187 (MtCutLoss).
+ * rlt_mt_terms: one pass over the rerank scores and/or class probabilities (either may be NULL)
+ * accumulating the batch-wide sums; then finalises on device (no host sync):
+ *   terms[0] = rerank hinge  max(0, mean_{y==0} s - mean_{y==1} s + margin), 0 if a class is empty
+ *   terms[1] = BCE mean over B*S (log clamped at -100 like torch)
+ *   terms[2] = d hinge / d s for y==1 entries (= -1/n_pos if active else 0)
+ *   terms[3] = d hinge / d s for y==0 entries (= +1/n_neg if active else 0)
+ * ws: at least rlt_mt_terms_workspace(B,S) bytes.
+ * rlt_mt_terms_bwd: d_rerank (B,S) = w_r * terms[2|3]; d_class (B,S) = w_c * dBCE/dc / (B*S);
+ * both scaled by *gscale (device scalar, NULL = 1).
+ */
+size_t rlt_mt_terms_workspace(int B, int S);
+int rlt_mt_terms(const float* rerank, const float* cls, const float* labels, int B, int S, float margin,
+                 float* terms, void* ws, size_t ws_bytes, void* stream);
+int rlt_mt_terms_bwd(const float* cls, const float* labels, const float* terms, int B, int S,
+                     float w_rerank, float w_class, const float* gscale,
+                     float* d_rerank, float* d_class, void* stream);
+/* out[0] = sum_i w[i] * x[i] for n <= 8 device scalars (combining cut / rerank / class terms) */
+int rlt_weighted_sum(const float* const* x, const float* w, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------ cut metrics (E1-E3)
+ * run.py:137-142 (k = argmax+1) and utils/metrics.py:15-38 (Metric.f1 / Metric.dcg at k).
+ * p, labels: (B,S).  k_out (B) int32; f1_out, dcg_out (B) float64 per list (the reference
+ * averages them over the batch on the host); any output may be NULL.
+ * If k_in != NULL the metrics are evaluated at those cut positions instead of the argmax.
+ * sums (2 doubles, may be NULL) receives sum_i f1_i, sum_i dcg_i.
+ */
+int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
+                    int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
+
+/* ------------------------------------------------------------------ dense contraction (M2-M7)
+ * C[M,N] (+)= op(A) * op(B) (+ bias[N] + bias2[N]), optional ReLU.  fp32 in, fp32 accumulate on
+ * the f32 MFMA (exact fp32 products, v_mfma_f32_32x32x2_f32).
+ *   ta = 0: A stored [M,K] (lda >= K);  ta = 1: A stored [K,M] (lda >= M)
+ *   tb = 0: B stored [K,N] (ldb >= N);  tb = 1: B stored [N,K] (ldb >= K)   (nn.Linear: tb = 1)
+ *   flags: RLT_GEMM_RELU, RLT_GEMM_ACCUMULATE (C += ...).
+ * Replaces the nn.Linear / in_proj / out_proj / LSTM input-projection matmuls of
+ * models/AttnCut.py:8-14 and their backward.  ws: rlt_gemm_workspace(...) bytes (split-K partials).
+ */
+#define RLT_GEMM_RELU       1
+#define RLT_GEMM_ACCUMULATE 2
+size_t rlt_gemm_workspace(int ta, int tb, int M, int N, int K);
+int rlt_gemm(int ta, int tb, int M, int N, int K,
+             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             const float* bias, const float* bias2, int flags,
+             void* ws, size_t ws_bytes, void* stream);
+/* out[N] (+)= sum over the T rows of X[T,N] (ldx) - bias gradients.  ws: rlt_colsum_workspace bytes. */
+size_t rlt_colsum_workspace(int T, int N);
+int rlt_colsum(const float* X, int ldx, int T, int N, float* out, int accumulate,
+               void* ws, size_t ws_bytes, void* stream);
+/* out[g][n] (+)= sum_{r<R} X[(g*R + r)*ldx + n] for g < G: per-position sums (Choopy dPE) */
+int rlt_segment_colsum(const float* X, int ldx, int G, int R, int N, float* out, int ldo,
+                       int accumulate, void* stream);
+/* y = max(x,0) backward etc. are fused in the kernels; dX *= (Y > 0) in place (FFN backward) */
+int rlt_relu_bwd(float* dX, const float* Y, size_t n, void* stream);
+/* x[i] *= *scale (device scalar) */
+int rlt_scale(float* x, const float* scale, size_t n, void* stream);
+
+/* ------------------------------------------------------------------ residual + LayerNorm (M3)
+ * y = LayerNorm(x + r) * gamma + beta, eps inside the sqrt, biased variance
+ * (nn.TransformerEncoderLayer post-norm, models/AttnCut.py:9).  stats: (T,2) mean, rstd.
+ * bwd: dz (T,E) = gradient w.r.t. (x + r) (identical for x and r); dgamma/dbeta (E) (+)=.
+ * E multiple of 64, E <= 1024.
+ */
+int rlt_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
+                          int T, int E, float eps, float* y, float* stats, void* stream);
+size_t rlt_add_layernorm_bwd_workspace(int T, int E);
+int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, const float* stats,
+                          const float* dy, int T, int E, float* dz, float* dgamma, float* dbeta,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ list-axis attention (M3)
+ * Multi-head self-attention where, at every position s and head h, the B lists of the
+ * mini-batch attend to each other (F.multi_head_attention_forward on a (L=B, N=S, E) input,
+ * models/AttnCut.py:9,18).  Flash-style: the B x B score matrix is never
+ * materialised.
+ *   qkv: (S*B, 3E) position-major, columns [q | k | v], head h = columns h*HD..h*HD+HD of each.
+ *   out: (S*B, E) concatenated heads (input of out_proj).  lse: (S,H,B) log-sum-exp of the
+ *   scaled scores (saved for backward).  scale = 1/sqrt(HD).
+ * bwd: dqkv (S*B,3E) from dout; ws: rlt_list_attention_bwd_workspace bytes.
+ * HD in {16, 32, 64}; E = H*HD.
+ */
+int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD,
+                           float* out, float* lse, void* stream);
+size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD);
+int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                           int S, int B, int H, int HD, float* dqkv,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ BiLSTM recurrence (M2)
+ * One bidirectional LSTM layer with hidden size 128 (nn.LSTM(..., hidden_size=128,
+ * bidirectional=True, batch_first=True), models/AttnCut.py:8): gate order i,f,g,o, h0=c0=0.
+ * The input projections x_t W_ih^T + b_ih + b_hh of both directions are computed beforehand by
+ * rlt_gemm into `gates` (S*B, 2, 512) position-major (dir 0 = forward in s, dir 1 = reverse).
+ * fwd: adds h_{t-1} W_hh^T, applies the nonlinearities, overwrites `gates` in place with the
+ *      ACTIVATED gates (i,f,g,o), writes the cell states c (S*B,2,128) and h_out (S*B,256) =
+ *      [forward | reverse] hidden states.
+ * bwd: from d_hout (S*B,256) and the stashes, writes d(pre-activation gates) in place over
+ *      `gates` (then dW_ih, dW_hh, db, dx are plain rlt_gemm / rlt_colsum calls on it).
+ * w_hh_fwd, w_hh_rev: (512,128) each = weight_hh_l{k}, weight_hh_l{k}_reverse.
+ */
+int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
+                       float* h_out, float* c_out, void* stream);
+int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
+                       const float* d_hout, int S, int B, void* stream);
+
+/* ------------------------------------------------------------------ layout helpers
+ * (B,S,F) user layout <-> (S*B,F) position-major */
+int rlt_to_position_major(const float* x_bsf, int B, int S, int F, float* x_sbf, void* stream);
+int rlt_from_position_major(const float* x_sbf, int B, int S, int F, float* x_bsf, void* stream);
+/* Choopy input: out[(s*B+b), 0] = score[b,s]; out[.., 1+c] = pe[s,c] (models/Choopy.py:19-20).
+ * E = 1 + pe columns (128). */
+int rlt_choopy_embed(const float* score_bs, const float* pe, int B, int S, int E, float* out, void* stream);
+
+/* ------------------------------------------------------------------ decision heads (M4, M6)
+ * Up to 3 heads Linear(E,1) over the same position-major activations x (S*B,E), each followed
+ * by softmax over the S positions of a list (kind 0), a sigmoid (1) or nothing (2):
+ * models/AttnCut.py:11-14,19; models/MtAttnCut.py:11-19,24-26.
+ *   w: (n_heads,E), b: (n_heads).  out: (n_heads,B,S) in the reference's (B,S) layout.
+ * bwd: dout (n_heads,B,S) -> dx (S*B,E) (overwritten, or += with accumulate), dw (n_heads,E), db (n_heads).
+ */
+#define RLT_HEAD_SOFTMAX  0
+#define RLT_HEAD_SIGMOID  1
+#define RLT_HEAD_IDENTITY 2
+int rlt_heads_fwd(const float* x, const float* w, const float* b, const int* kinds, int n_heads,
+                  int S, int B, int E, float* out, void* stream);
+size_t rlt_heads_bwd_workspace(int n_heads, int S, int B, int E);
+int rlt_heads_bwd(const float* x, const float* w, const int* kinds, int n_heads,
+                  const float* out, const float* dout, int S, int B, int E,
+                  float* dx, int accumulate_dx, float* dw, float* db,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ MMOE gates / mixture (M7)
+ * models/MMOECut.py:93-94: gate[t][b][:] = softmax_e( flatten_s(h[b]) @ w_gate[t] ), h the BiLSTM
+ * output (position-major (S*B,C), C = 256), w_gate[t]: (S*C, n_e) row index s*C + c.
+ * models/MMOECut.py:101-102: mixed[t][tok][:] = sum_e gate[t][b][e] * expert[e][tok][:].
+ *   gates out: (n_tasks,B,n_e).  n_e <= 8, n_tasks <= 3.
+ * bwd of the gate: from dgate (n_tasks,B,n_e): dh (S*B,C) = or += (accumulate_dh), dw_gate[t] (S*C,n_e) =.
+ * mix fwd: experts[e] (S*B,E), e < n_e (host array of device pointers) -> mixed (n_tasks,S*B,E).
+ * mix bwd: dmixed (n_tasks,S*B,E) -> dexperts[e] (S*B,E) = ; dgate (n_tasks,B,n_e) = .
+ * w_gate / dw_gate / experts / dexperts are HOST arrays of device pointers.
+ */
+int rlt_mmoe_gate_fwd(const float* h, const float* const* w_gate, int n_tasks, int n_e,
+                      int S, int B, int C, float* gates, void* stream);
+size_t rlt_mmoe_gate_bwd_workspace(int n_tasks, int n_e, int S, int B, int C);
+int rlt_mmoe_gate_bwd(const float* h, const float* const* w_gate, const float* gates, const float* dgates,
+                      int n_tasks, int n_e, int S, int B, int C,
+                      float* dh, int accumulate_dh, float* const* dw_gate,
+                      void* ws, size_t ws_bytes, void* stream);
+int rlt_mmoe_mix_fwd(const float* const* experts, const float* gates, int n_tasks, int n_e,
+                     int S, int B, int E, float* mixed, void* stream);
+int rlt_mmoe_mix_bwd(const float* const* experts, const float* gates, const float* dmixed,
+                     int n_tasks, int n_e, int S, int B, int E,
+                     float* const* dexperts, float* dgates, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (N2, run.py:104,129)
+ * torch.optim.Adam with coupled L2 (grad += wd * p), bias correction, eps outside the sqrt,
+ * on a flat fp32 bucket.  step: 1-based step count. */
+int rlt_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLT_HIP_H */

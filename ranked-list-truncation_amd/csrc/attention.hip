@@ -1,0 +1,503 @@
+// List-axis multi-head self-attention (row M3 of SURVEY.md section 8a), forward and backward.
+//
+// In the reference every nn.TransformerEncoderLayer is batch_first=False but receives (B,S,E)
+// (models/AttnCut.py:9,17-18), so at each position s and head h the B lists of the mini-batch
+// attend to each other: a dense B x B score matrix per (s,h) - 1200 of them at AttnCut's
+// S=300, H=4.  With position-major activations the B rows of one position are contiguous.
+//
+// Flash-style, fp32 throughout on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products):
+// the score matrix is never written to memory.  One wavefront owns 32 queries (or 32 keys in the
+// dK/dV kernel); scores are produced TRANSPOSED (S^T = K Q^T) so that a query is a lane: the online
+// softmax over keys is a per-lane loop over the 16 accumulator registers plus one cross-half
+// shuffle, and the probability registers are directly the B operand of the P.V product - no LDS
+// round trip, no conversion.  K/V (or Q/dO) tiles of 64 rows are double-buffered in LDS with a
+// register prefetch, shared by the 4 wavefronts of a workgroup.
+//
+// Backward recomputes the probabilities from the saved log-sum-exp (no B x B stash):
+//   kernel dKV: workgroup = 128 keys, loops over queries, accumulates dK^T, dV^T in registers
+//   kernel dQ : workgroup = 128 queries, loops over keys, accumulates dQ^T in registers
+// so every gradient element is written exactly once: deterministic, no float atomics.
+//
+// FLOPs per (s,h): forward 4*B^2*HD; backward 14*B^2*HD (7 products; 5 would need atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;      // rows per LDS tile
+constexpr int QT = 128;     // rows owned by a workgroup (4 wavefronts x 32)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnArgs {
+    const float* qkv; const float* out; const float* dout; const float* lse; const float* delta;
+    float* o; float* lse_o; float* dqkv;
+    int S, B, H;
+    float scale;
+};
+
+// flat block id -> (position*head pair, row tile); all row tiles of a pair go to one XCD (they
+// share that pair's K/V in the XCD's L2) when the pair count allows.
+__device__ __forceinline__ void map_block(int bid, int npair, int ntile, int& pair, int& tile) {
+    if ((npair & 7) == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        pair = (j / ntile) * 8 + xcd;
+        tile = j % ntile;
+    } else {
+        pair = bid / ntile;
+        tile = bid % ntile;
+    }
+}
+
+// stage a [KT][HD] tile (row stride ld floats in global, HD+4 in LDS) through registers
+template <int HD>
+struct TileRegs { float4 v[(KT * HD / 4 + 255) / 256]; };
+
+template <int HD>
+__device__ __forceinline__ void tile_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid,
+                                          TileRegs<HD>& r) {
+    constexpr int PER_ROW = HD / 4, N4 = KT * PER_ROW, NI = (N4 + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < N4) {
+            const int row = idx / PER_ROW, c4 = idx % PER_ROW;
+            if (row0 + row < nrows) v = *reinterpret_cast<const float4*>(base + (size_t)(row0 + row) * ld + 4 * c4);
+        }
+        r.v[i] = v;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store(float* __restrict__ lds, int tid, const TileRegs<HD>& r) {
+    constexpr int PER_ROW = HD / 4, N4 = KT * PER_ROW, NI = (N4 + 255) / 256, LD = HD + 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < N4) {
+            const int row = idx / PER_ROW, c4 = idx % PER_ROW;
+            *reinterpret_cast<float4*>(lds + row * LD + 4 * c4) = r.v[i];
+        }
+    }
+}
+
+// this lane's half of a row: regs[ks] = row[hh*HD/2 + ks] * mul, ks < HD/2
+template <int HD>
+__device__ __forceinline__ void row_half_load(const float* __restrict__ rowp, int hh, float mul, float (&regs)[HD / 2]) {
+#pragma unroll
+    for (int j = 0; j < HD / 8; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(rowp + hh * (HD / 2) + 4 * j);
+        regs[4 * j + 0] = v.x * mul; regs[4 * j + 1] = v.y * mul;
+        regs[4 * j + 2] = v.z * mul; regs[4 * j + 3] = v.w * mul;
+    }
+}
+
+// acc += Tile[rows sub*32 + (lane&31)][all d] (A operand, from LDS) x regs (B operand):
+// result D[row = tile row][col = lane&31]
+template <int HD>
+__device__ __forceinline__ f32x16 mma_tile_rows(const float* __restrict__ tile, int sub, int l31, int hh,
+                                                const float (&regs)[HD / 2], f32x16 acc) {
+    constexpr int LD = HD + 4;
+    const float* rp = tile + (sub * 32 + l31) * LD + hh * (HD / 2);
+#pragma unroll
+    for (int j = 0; j < HD / 8; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(rp + 4 * j);
+        acc = mfma32(a.x, regs[4 * j + 0], acc);
+        acc = mfma32(a.y, regs[4 * j + 1], acc);
+        acc = mfma32(a.z, regs[4 * j + 2], acc);
+        acc = mfma32(a.w, regs[4 * j + 3], acc);
+    }
+    return acc;
+}
+// acc[dt] += sum over the 32 rows of sub-tile `sub`:  Tile[row][dt*32 + i]^T-ish product
+//   D[row = d (dt*32 + i)][col = lane&31] += sum_r Tile[sub*32 + acc_row(r,hh)][dt*32 + (lane&31)] * w[r]
+// i.e. A operand = Tile^T read column-wise (ds_read_b32, consecutive lanes -> consecutive d),
+//      B operand = the accumulator registers w of a previous product (rows of that product = k).
+template <int HD>
+__device__ __forceinline__ void mma_tile_cols(const float* __restrict__ tile, int sub, int l31, int hh,
+                                              const f32x16& w, f32x16 (&acc)[(HD + 31) / 32]) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 32 + l31;
+        const bool ok = d < HD;
+        const float* cp = tile + (sub * 32 + 4 * hh) * LD + (ok ? d : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = ok ? cp[((r & 3) + 8 * (r >> 2)) * LD] : 0.f;
+            acc[dt] = mfma32(a, w[r], acc[dt]);
+        }
+    }
+}
+
+// store D^T accumulators (row = d, col = lane's row index) to global rows: dst + row*ld + d
+template <int HD>
+__device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh, const f32x16 (&acc)[(HD + 31) / 32],
+                                            float mul) {
+    constexpr int DT = (HD + 31) / 32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * hh;
+            if (d0 < HD) {
+                float4 v;
+                v.x = acc[dt][4 * g + 0] * mul; v.y = acc[dt][4 * g + 1] * mul;
+                v.z = acc[dt][4 * g + 2] * mul; v.w = acc[dt][4 * g + 3] * mul;
+                *reinterpret_cast<float4*>(dst_row + d0) = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                       // [2][KT*LD]
+    float* Vs = smem + 2 * KT * LD;         // [2][KT*LD]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;     // row b of this position: base + b*ld
+    const int q = qt * QT + wv * 32 + l31;
+    const bool wave_live = qt * QT + wv * 32 < B;
+    const int qc = min(q, B - 1);
+
+    float qreg[HD / 2];
+    row_half_load<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qreg);
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    TileRegs<HD> rk, rv;
+    const int nt = rlt_cdiv_dev(B, KT);
+    tile_load<HD>(base + E, ld, 0, B, tid, rk);
+    tile_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+    tile_store<HD>(Ks, tid, rk);
+    tile_store<HD>(Vs, tid, rv);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+            tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+        }
+        if (wave_live) {
+            const float* kt_ = Ks + buf * KT * LD;
+            const float* vt_ = Vs + buf * KT * LD;
+            f32x16 sc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
+                sc[sub] = mma_tile_rows<HD>(kt_, sub, l31, hh, qreg, sc[sub]);     // S^T[key][q], log2 domain
+            }
+            // mask keys beyond B, tile max
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + sub * 32 + acc_row(r, hh);
+                    if (key >= B) sc[sub][r] = -INFINITY;
+                    tmax = fmaxf(tmax, sc[sub][r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(sc[sub][r] - m_new);
+                    sc[sub][r] = p;
+                    psum += p;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) mma_tile_cols<HD>(vt_, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
+        }
+        if (t + 1 < nt) {
+            tile_store<HD>(Ks + (buf ^ 1) * KT * LD, tid, rk);
+            tile_store<HD>(Vs + (buf ^ 1) * KT * LD, tid, rv);
+        }
+        __syncthreads();
+    }
+    if (!wave_live) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q < B) {
+        store_acc_T<HD>(a.o + ((size_t)s * B + q) * E + h * HD, hh, oacc, 1.f / l_tot);
+        if (hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_tot)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ delta
+// delta[s][h][b] = sum_d dO[t][h*HD+d] * O[t][h*HD+d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                         int S, int B, int H, int HD, float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t T = (size_t)S * B;
+    const int E = H * HD;
+    for (size_t t = (size_t)blockIdx.x * 4 + wv; t < T; t += (size_t)gridDim.x * 4) {
+        const int s = (int)(t / B), b = (int)(t % B);
+        for (int h = 0; h < H; ++h) {
+            float v = 0.f;
+            if (lane < HD) v = o[t * E + h * HD + lane] * dout[t * E + h * HD + lane];
+            v = wave_sum(v);
+            if (lane == 0) delta[((size_t)s * H + h) * B + b] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                         // [2][KT*LD]
+    float* Ds = smem + 2 * KT * LD;           // [2][KT*LD]   dO
+    float* Ls = smem + 4 * KT * LD;           // [2][KT]      lse * log2e
+    float* Es = Ls + 2 * KT;                  // [2][KT]      delta
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, ktile;
+    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
+    const float* dobase = a.dout + (size_t)s * B * E + h * HD;
+    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
+    const float* delbase = a.delta + ((size_t)s * H + h) * B;
+    const int key = ktile * QT + wv * 32 + l31;
+    const bool wave_live = ktile * QT + wv * 32 < B;
+    const int kc = min(key, B - 1);
+
+    float kreg[HD / 2], vreg[HD / 2];
+    row_half_load<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kreg);
+    row_half_load<HD>(base + (size_t)kc * ld + 2 * E, hh, 1.f, vreg);
+
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+    TileRegs<HD> rq, rd;
+    float rl = 0.f, re = 0.f;
+    const int nt = rlt_cdiv_dev(B, KT);
+    auto load_small = [&](int row0) {
+        if (tid < KT) {
+            const int qi = row0 + tid;
+            rl = qi < B ? lsebase[qi] * LOG2E : 0.f;
+            re = qi < B ? delbase[qi] : 0.f;
+        }
+    };
+    tile_load<HD>(base, ld, 0, B, tid, rq);
+    tile_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
+    load_small(0);
+    tile_store<HD>(Qs, tid, rq);
+    tile_store<HD>(Ds, tid, rd);
+    if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            tile_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
+            tile_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
+            load_small((t + 1) * KT);
+        }
+        if (wave_live) {
+            const float* qt_ = Qs + buf * KT * LD;
+            const float* dt_ = Ds + buf * KT * LD;
+            const float* lt_ = Ls + buf * KT;
+            const float* et_ = Es + buf * KT;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+                sc = mma_tile_rows<HD>(qt_, sub, l31, hh, kreg, sc);    // S[q][key] (log2 domain)
+                dp = mma_tile_rows<HD>(dt_, sub, l31, hh, vreg, dp);    // dP[q][key]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + acc_row(r, hh);
+                    const bool ok = t * KT + ql < B;
+                    const float p = ok ? exp2f(sc[r] - lt_[ql]) : 0.f;
+                    sc[r] = p;                                           // P
+                    dp[r] = p * (dp[r] - et_[ql]);                       // dS
+                }
+                mma_tile_cols<HD>(dt_, sub, l31, hh, sc, dv);            // dV^T[d][key] += dO^T P
+                mma_tile_cols<HD>(qt_, sub, l31, hh, dp, dk);            // dK^T[d][key] += Q^T dS
+            }
+        }
+        if (t + 1 < nt) {
+            tile_store<HD>(Qs + (buf ^ 1) * KT * LD, tid, rq);
+            tile_store<HD>(Ds + (buf ^ 1) * KT * LD, tid, rd);
+            if (tid < KT) { Ls[(buf ^ 1) * KT + tid] = rl; Es[(buf ^ 1) * KT + tid] = re; }
+        }
+        __syncthreads();
+    }
+    if (!wave_live || key >= B) return;
+    float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
+    store_acc_T<HD>(drow + E, hh, dk, a.scale);
+    store_acc_T<HD>(drow + 2 * E, hh, dv, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + 2 * KT * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
+    const int q = qt * QT + wv * 32 + l31;
+    const bool wave_live = qt * QT + wv * 32 < B;
+    const int qc = min(q, B - 1);
+
+    float qreg[HD / 2], doreg[HD / 2];
+    row_half_load<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qreg);
+    row_half_load<HD>(a.dout + ((size_t)s * B + qc) * E + h * HD, hh, 1.f, doreg);
+    const float lse2 = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
+    const float del = a.delta[((size_t)s * H + h) * B + qc];
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    TileRegs<HD> rk, rv;
+    const int nt = rlt_cdiv_dev(B, KT);
+    tile_load<HD>(base + E, ld, 0, B, tid, rk);
+    tile_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+    tile_store<HD>(Ks, tid, rk);
+    tile_store<HD>(Vs, tid, rv);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+            tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+        }
+        if (wave_live) {
+            const float* kt_ = Ks + buf * KT * LD;
+            const float* vt_ = Vs + buf * KT * LD;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+                sc = mma_tile_rows<HD>(kt_, sub, l31, hh, qreg, sc);     // S^T[key][q]
+                dp = mma_tile_rows<HD>(vt_, sub, l31, hh, doreg, dp);    // dP^T[key][q]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = t * KT + sub * 32 + acc_row(r, hh);
+                    const float p = kidx < B ? exp2f(sc[r] - lse2) : 0.f;
+                    dp[r] = p * (dp[r] - del);                            // dS^T
+                }
+                mma_tile_cols<HD>(kt_, sub, l31, hh, dp, dq);             // dQ^T[d][q] += K^T dS^T
+            }
+        }
+        if (t + 1 < nt) {
+            tile_store<HD>(Ks + (buf ^ 1) * KT * LD, tid, rk);
+            tile_store<HD>(Vs + (buf ^ 1) * KT * LD, tid, rv);
+        }
+        __syncthreads();
+    }
+    if (!wave_live || q >= B) return;
+    store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
+}
+
+template <int HD> size_t fwd_smem() { return (size_t)4 * KT * (HD + 4) * sizeof(float); }
+template <int HD> size_t dkv_smem() { return (size_t)(4 * KT * (HD + 4) + 4 * KT) * sizeof(float); }
+
+template <int HD>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+    const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
+    int rc = rlt_allow_lds(attn_fwd_kernel<HD>, fwd_smem<HD>());
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    return RLT_LAUNCH_RESULT();
+}
+template <int HD>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+    const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
+    int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD>, dkv_smem<HD>());
+    if (!rc) rc = rlt_allow_lds(attn_bwd_dq_kernel<HD>, fwd_smem<HD>());
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    return RLT_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD,
+                           float* out, float* lse, void* stream) {
+    RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    if (!(rlt_aligned16(qkv) && rlt_aligned16(out))) return RLT_E_ALIGN;
+    AttnArgs a{};
+    a.qkv = qkv; a.o = out; a.lse_o = lse; a.S = S; a.B = B; a.H = H;
+    a.scale = 1.0f / sqrtf((float)HD);
+    hipStream_t st = rlt_stream(stream);
+    if (HD == 64) return launch_fwd<64>(a, st);
+    if (HD == 32) return launch_fwd<32>(a, st);
+    return launch_fwd<16>(a, st);
+}
+
+size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
+    (void)HD;
+    if (S <= 0 || B <= 0 || H <= 0) return 0;
+    return (size_t)S * H * B * sizeof(float);
+}
+
+int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                           int S, int B, int H, int HD, float* dqkv,
+                           void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(qkv && out && dout && lse && dqkv && ws && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    if (ws_bytes < rlt_list_attention_bwd_workspace(S, B, H, HD)) return RLT_E_WORKSPACE;
+    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.dqkv = dqkv;
+    a.S = S; a.B = B; a.H = H;
+    a.scale = 1.0f / sqrtf((float)HD);
+    hipStream_t st = rlt_stream(stream);
+    const size_t T = (size_t)S * B;
+    const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
+    if (HD == 64) return launch_bwd<64>(a, st);
+    if (HD == 32) return launch_bwd<32>(a, st);
+    return launch_bwd<16>(a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Shared device/host helpers for librlt_hip.so (gfx950 only: 64-lane wavefronts, f32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/rlt_hip.h"
+
+#define RLT_WAVE 64
+
+#define RLT_CHECK_ARG(cond)   do { if (!(cond)) return RLT_E_ARG; } while (0)
+#define RLT_CHECK_SHAPE(cond) do { if (!(cond)) return RLT_E_SHAPE; } while (0)
+#define RLT_LAUNCH_RESULT()   ((int)hipGetLastError())
+
+static inline hipStream_t rlt_stream(void* s) { return (hipStream_t)s; }
+static inline bool rlt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int rlt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+__device__ __forceinline__ int rlt_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// kernels that use more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in
+template <typename K>
+static inline int rlt_allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- wavefront (64 lanes) reductions / scans ------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+template <typename T>
+__device__ __forceinline__ T wave_scan_incl(T v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// ---- f32 MFMA (exact fp32 products; 64 FLOP/clk/SIMD on gfx950) -------------------------------
+// 32x32x2: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+//          D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r of 16.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// row of the 32x32 accumulator tile held in register r by a lane of half hh = lane>>5
+__device__ __forceinline__ constexpr int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }

@@ -1,0 +1,344 @@
+// fp32 dense contraction on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products and
+// accumulation, 64 FLOP/clk/SIMD = the chip's 157 TFLOP/s fp32 peak).  Serves every nn.Linear-shaped
+// product of the hot path and its backward: in_proj / out_proj / FFN of the encoder layer
+// (models/AttnCut.py:9), the LSTM input projections (models/AttnCut.py:8) and the weight gradients
+// dW = dY^T X (split-K, deterministic slab reduction - no float atomics).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 wavefronts as 2x2, each 64x64 = 2x2 MFMA
+// tiles, 64 accumulator VGPRs), K step 16, operands staged in LDS k-major ([k][m], row 132 floats)
+// so that the MFMA operand of lane l (row l&31, k = l>>5) is one conflict-free ds_read_b32; register
+// prefetch of the next K tile overlaps the MFMAs of the current one.  blockIdx is remapped so that
+// the tiles an XCD runs are contiguous (they share the A panel in that XCD's L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* bias2;
+    int M, N, K, lda, ldb, ldc;
+    int vecA, vecB;      // 16-byte vector loads allowed
+    int flags;
+    int kchunk;          // K range per z-slice (multiple of BK); gridDim.z slices
+    float* slab;         // split-K partials [z][M*N] or null
+    int tiles_m, tiles_n;
+};
+
+// KC = true : operand stored [MN][K] (K contiguous)   -> transposing LDS store
+// KC = false: operand stored [K][MN] (MN contiguous)  -> direct LDS store
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend,
+                                          bool vec, int tid, float4 (&reg)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            const int row = mn0 + (idx >> 2), kk = k0 + 4 * (idx & 3);
+            if (row < MN) {
+                const float* src = P + (size_t)row * ld + kk;
+                if (vec && kk + 3 < Kend) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (kk + 0 < Kend) v.x = src[0];
+                    if (kk + 1 < Kend) v.y = src[1];
+                    if (kk + 2 < Kend) v.z = src[2];
+                    if (kk + 3 < Kend) v.w = src[3];
+                }
+            }
+        } else {
+            const int kk = k0 + (idx >> 5), col = mn0 + 4 * (idx & 31);
+            if (kk < Kend) {
+                const float* src = P + (size_t)kk * ld + col;
+                if (vec && col + 3 < MN) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (col + 0 < MN) v.x = src[0];
+                    if (col + 1 < MN) v.y = src[1];
+                    if (col + 2 < MN) v.z = src[2];
+                    if (col + 3 < MN) v.w = src[3];
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const float4 (&reg)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        if (KC) {
+            const int mn = idx >> 2, k = 4 * (idx & 3);
+            T[(k + 0) * LDT + mn] = reg[i].x;
+            T[(k + 1) * LDT + mn] = reg[i].y;
+            T[(k + 2) * LDT + mn] = reg[i].z;
+            T[(k + 3) * LDT + mn] = reg[i].w;
+        } else {
+            const int k = idx >> 5, mn = 4 * (idx & 31);
+            *reinterpret_cast<float4*>(&T[k * LDT + mn]) = reg[i];
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    // XCD-aware, bijective remap of the flat block id (8 XCDs, round-robin dispatch)
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    // A operand: TA=0 -> stored [M][K] (K contiguous); B operand: TB=1 -> stored [N][K] (K contiguous)
+    load_tile<!TA>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
+    load_tile<TB>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
+    store_tile<!TA>(As[0], tid, ra);
+    store_tile<TB>(Bs[0], tid, rb);
+    __syncthreads();
+
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {
+            load_tile<!TA>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
+            load_tile<TB>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
+        }
+        const float* a_ = As[buf] + wm * 64 + l31;
+        const float* b_ = Bs[buf] + wn * 64 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = (2 * ks + hh) * LDT;
+            const float a0 = a_[kk], a1 = a_[kk + 32];
+            const float b0 = b_[kk], b1 = b_[kk + 32];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+        if (more) {
+            store_tile<!TA>(As[buf ^ 1], tid, ra);
+            store_tile<TB>(Bs[buf ^ 1], tid, rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        float bv = 0.f;
+        if (!to_slab) {
+            if (g.bias) bv += g.bias[col];
+            if (g.bias2) bv += g.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, hh);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                float* dst = out + (size_t)row * ldo + col;
+                if (!to_slab) {
+                    v += bv;
+                    if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
+                    if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
+// C = sum_z slab[z] (+bias, relu, accumulate); fixed order => deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int nsplit) {
+    const size_t mn = (size_t)g.M * g.N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < nsplit; ++z) v += g.slab[(size_t)z * mn + i];
+        const int row = (int)(i / g.N), col = (int)(i - (size_t)row * g.N);
+        if (g.bias) v += g.bias[col];
+        if (g.bias2) v += g.bias2[col];
+        float* dst = g.C + (size_t)row * g.ldc + col;
+        if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
+        if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
+        *dst = v;
+    }
+}
+
+int choose_split(int M, int N, int K) {
+    const long long tiles = (long long)rlt_cdiv(M, BM) * rlt_cdiv(N, BN);
+    if (tiles >= 256 || K < 4096) return 1;
+    long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
+    const long long maxs = K / 512 > 0 ? K / 512 : 1;        // keep >= 512 of K per slice
+    if (want > maxs) want = maxs;
+    if (want > 256) want = 256;
+    return (int)(want < 1 ? 1 : want);
+}
+
+// ---- column sums (bias gradients) ------------------------------------------------------------------
+constexpr int CS_ROWS_PER_WG = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, int T, int N,
+                                                             float* __restrict__ partial) {
+    // block = (column block of 256, row chunk); thread = one column, 4 row phases via... keep simple:
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rphase = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * CS_ROWS_PER_WG, r1 = min(T, r0 + CS_ROWS_PER_WG);
+    float acc = 0.f;
+    if (col < N)
+        for (int r = r0 + rphase; r < r1; r += 4) acc += X[(size_t)r * ldx + col];
+    __shared__ float sm[4][64];
+    sm[rphase][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < N)
+        partial[(size_t)blockIdx.y * N + col] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nchunk, int N,
+                                                           float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float acc = 0.f;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * N + col];
+    out[col] = accumulate ? out[col] + acc : acc;
+}
+
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const float* __restrict__ X, int ldx, int R, int N,
+                                                             float* __restrict__ out, int ldo, int accumulate) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, rphase = threadIdx.x >> 6;
+    __shared__ float sm[4][64];
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int col = c0 + lane;
+        float acc = 0.f;
+        if (col < N)
+            for (int r = rphase; r < R; r += 4) acc += X[((size_t)g * R + r) * ldx + col];
+        sm[rphase][lane] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64 && col < N) {
+            const float v = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+            float* dst = out + (size_t)g * ldo + col;
+            *dst = accumulate ? *dst + v : v;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dX, const float* __restrict__ Y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        if (!(Y[i] > 0.f)) dX[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, const float* __restrict__ s, size_t n) {
+    const float f = s[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= f;
+}
+
+int ew_grid(size_t n) { size_t g = (n + 1023) / 1024; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+extern "C" {
+
+size_t rlt_gemm_workspace(int ta, int tb, int M, int N, int K) {
+    (void)ta; (void)tb;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int ns = choose_split(M, N, K);
+    return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+}
+
+int rlt_gemm(int ta, int tb, int M, int N, int K,
+             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             const float* bias, const float* bias2, int flags,
+             void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+    RLT_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.vecA = (lda % 4 == 0) && rlt_aligned16(A);
+    g.vecB = (ldb % 4 == 0) && rlt_aligned16(B);
+    g.flags = flags;
+    g.tiles_m = rlt_cdiv(M, BM); g.tiles_n = rlt_cdiv(N, BN);
+    int ns = choose_split(M, N, K);
+    if (ns > 1 && (!ws || ws_bytes < (size_t)ns * M * N * sizeof(float))) {
+        if (ws == nullptr && ws_bytes == 0) ns = 1; else return RLT_E_WORKSPACE;
+    }
+    int kchunk = rlt_cdiv(rlt_cdiv(K, ns), BK) * BK;
+    ns = rlt_cdiv(K, kchunk);
+    g.kchunk = kchunk;
+    g.slab = ns > 1 ? (float*)ws : nullptr;
+    hipStream_t st = rlt_stream(stream);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, ns), block(256);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
+    if (ns > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_grid((size_t)M * N)), dim3(256), 0, st, g, ns);
+    return RLT_LAUNCH_RESULT();
+}
+
+size_t rlt_colsum_workspace(int T, int N) {
+    if (T <= 0 || N <= 0) return 0;
+    return (size_t)rlt_cdiv(T, CS_ROWS_PER_WG) * N * sizeof(float);
+}
+
+int rlt_colsum(const float* X, int ldx, int T, int N, float* out, int accumulate,
+               void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(X && out && ws && T > 0 && N > 0 && ldx >= N);
+    if (ws_bytes < rlt_colsum_workspace(T, N)) return RLT_E_WORKSPACE;
+    const int nchunk = rlt_cdiv(T, CS_ROWS_PER_WG);
+    hipStream_t st = rlt_stream(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rlt_cdiv(N, 64), nchunk), dim3(256), 0, st, X, ldx, T, N, (float*)ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(rlt_cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, nchunk, N, out, accumulate);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_segment_colsum(const float* X, int ldx, int G, int R, int N, float* out, int ldo,
+                       int accumulate, void* stream) {
+    RLT_CHECK_ARG(X && out && G > 0 && R > 0 && N > 0 && ldx >= N && ldo >= N);
+    hipLaunchKernelGGL(segment_colsum_kernel, dim3(G), dim3(256), 0, rlt_stream(stream), X, ldx, R, N, out, ldo, accumulate);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_relu_bwd(float* dX, const float* Y, size_t n, void* stream) {
+    RLT_CHECK_ARG(dX && Y && n > 0);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, rlt_stream(stream), dX, Y, n);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_scale(float* x, const float* scale, size_t n, void* stream) {
+    RLT_CHECK_ARG(x && scale && n > 0);
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, rlt_stream(stream), x, scale, n);
+    return RLT_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// Reward losses, multi-task terms and cut metrics: rows L1-L8, E1-E3 of SURVEY.md section 8(a).
+//
+// HBM-bound scan/reduction kernels.  One ranked list per wavefront: the rows of a workgroup's 4
+// lists are loaded with coalesced (float4) reads and staged in LDS, every lane then owns a
+// contiguous chunk of C = ceil(S/64) positions, so the prefix sums c_k = sum_{j<k} y_j and the
+// DCG prefix are a short serial scan per lane plus one 64-lane shuffle scan; the softmax
+// normaliser and the loss terms are wavefront shuffle reductions.  The reference builds the
+// same reward matrix with B*S python calls of O(S) tensor ops each (utils/losses.py:217-225 ->
+// utils/metrics.py:85-101).
+//
+// Algorithmic bytes per list (fp32): read p 4S + labels 4S, write dL/dp 4S (+ 4 B loss) = 3.6 KB at
+// S = 300.
+#include "common.h"
+
+namespace {
+
+constexpr int LISTS_PER_WG = 4;
+
+struct RewardArgs {
+    const float* p;        // (B,S) or null
+    const float* y;        // (B,S)
+    const float* coef;     // (S) log2(j+2) or null
+    float* loss_per_list;  // (B) or null
+    float* dp;             // (B,S) or null
+    float* r_out;          // (B,S) or null
+    float* q_out;          // (B,S) or null
+    int B, S, metric, kind;
+    float tau, gscale;     // gscale = 1/B
+};
+
+// element j of a list lives at lds[(j / C) * STRIDE + j % C], STRIDE = C|1 (odd => conflict-free)
+template <int C>
+__device__ __forceinline__ int lds_slot(int j) { return (j / C) * (C | 1) + (j % C); }
+
+template <int C>
+__global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
+    constexpr int STRIDE = C | 1;
+    constexpr int ROW = 64 * STRIDE;
+    __shared__ float sp[LISTS_PER_WG * ROW];
+    __shared__ float sy[LISTS_PER_WG * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int S = a.S;
+    const int b0 = blockIdx.x * LISTS_PER_WG;
+    const int nl = min(LISTS_PER_WG, a.B - b0);
+    const size_t base = (size_t)b0 * S;
+    const int total = nl * S;
+
+    // ---- stage the rows in LDS (coalesced global reads) ------------------------------------
+    if ((S & 3) == 0) {
+        for (int e = tid * 4; e < total; e += 256 * 4) {
+            const float4 vy = *reinterpret_cast<const float4*>(a.y + base + e);
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.p) vp = *reinterpret_cast<const float4*>(a.p + base + e);
+            const int l = e / S, j = e - l * S;   // S % 4 == 0: the 4 elements stay in one row
+            const float ys[4] = {vy.x, vy.y, vy.z, vy.w};
+            const float ps[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = l * ROW + lds_slot<C>(j + i);
+                sy[s] = ys[i];
+                sp[s] = ps[i];
+            }
+        }
+    } else {
+        for (int e = tid; e < total; e += 256) {
+            const int l = e / S, j = e - l * S;
+            const int s = l * ROW + lds_slot<C>(j);
+            sy[s] = a.y[base + e];
+            sp[s] = a.p ? a.p[base + e] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    float dpv[C];
+    float rv[C], qv[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { dpv[i] = 0.f; rv[i] = 0.f; qv[i] = 0.f; }
+
+    if (wv < nl) {
+        const float* ly = sy + wv * ROW + lane * STRIDE;
+        const float* lp = sp + wv * ROW + lane * STRIDE;
+        float yv[C], pv[C];
+        bool ok[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int j = lane * C + i;
+            ok[i] = j < S;
+            yv[i] = ok[i] ? ly[i] : 0.f;
+            pv[i] = ok[i] ? lp[i] : 1.f;
+        }
+        // ---- reward r_k, k = j+1 -------------------------------------------------------------
+        if (a.metric == RLT_METRIC_F1) {
+            // utils/metrics.py:85-91 on prefix sums: hits c_k (exact small integers in fp32)
+            float run = 0.f;
+            float pre[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) { run += yv[i]; pre[i] = run; }
+            const float incl = wave_scan_incl(run, lane);
+            const float excl = incl - run;
+            const float n_rel = __shfl(incl, 63, 64);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const float hits = excl + pre[i];
+                const float k = (float)(lane * C + i + 1);
+                const float prec = hits / k;
+                const float rec = (n_rel != 0.f) ? hits / n_rel : 0.f;
+                const float tot = prec + rec;
+                rv[i] = (tot != 0.f) ? (prec * rec * 2.f) / tot : 0.f;
+            }
+        } else {
+            // utils/metrics.py:93-101: prefix sum of (+1 | -1) / log2(j+2)
+            float run = 0.f;
+            float pre[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int j = lane * C + i;
+                float g = 0.f;
+                if (ok[i]) {
+                    const float cf = a.coef[j];
+                    g = (yv[i] == 1.f) ? 1.f / cf : (1.f / cf) * -1.f;
+                }
+                run += g;
+                pre[i] = run;
+            }
+            const float incl = wave_scan_incl(run, lane);
+            const float excl = incl - run;
+#pragma unroll
+            for (int i = 0; i < C; ++i) rv[i] = excl + pre[i];
+        }
+        // ---- q = exp(r/tau) / sum (utils/losses.py:226-228; no max subtraction, like the reference)
+        float part = 0.f;
+        if (a.kind != RLT_LOSS_EXPECT || a.q_out) {
+            float zs = 0.f;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                qv[i] = ok[i] ? expf(rv[i] / a.tau) : 0.f;
+                zs += qv[i];
+            }
+            const float z = wave_sum(zs);
+#pragma unroll
+            for (int i = 0; i < C; ++i) qv[i] = qv[i] / z;
+        }
+        // ---- loss terms and d/dp ---------------------------------------------------------------
+        if (a.p) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                if (!ok[i]) continue;
+                const float p = pv[i], q = qv[i], r = rv[i];
+                float term, g;
+                if (a.kind == RLT_LOSS_EXPECT) {            // utils/losses.py:67-68
+                    term = -(p * r);
+                    g = -r;
+                } else if (a.kind == RLT_LOSS_CE) {          // utils/losses.py:94-96
+                    term = -(logf(p) * q);
+                    g = -q / p;
+                } else if (a.kind == RLT_LOSS_KL) {          // utils/losses.py:230, kl_div(log p, q)
+                    const float qlq = (q > 0.f) ? q * logf(q) : 0.f;
+                    term = qlq - q * logf(p);
+                    g = -q / p;
+                } else {                                     // utils/losses.py:232-233, JS
+                    const float lm = logf((p + q) * 0.5f);
+                    const float lp_ = logf(p);
+                    const float qlq = (q > 0.f) ? q * logf(q) : 0.f;
+                    const float plp = (p > 0.f) ? p * lp_ : 0.f;
+                    term = 0.5f * ((qlq - q * lm) + (plp - p * lm));
+                    g = 0.5f * (lp_ - lm);                   // gradient flows through log m AND the target p
+                }
+                part += term;
+                dpv[i] = g * a.gscale;
+            }
+            const float tot = wave_sum(part);
+            if (lane == 0 && a.loss_per_list) a.loss_per_list[b0 + wv] = tot;
+        }
+    }
+    // ---- coalesced write-back through LDS ---------------------------------------------------------
+    auto write_back = [&](float* dst, const float (&vals)[C]) {
+        __syncthreads();
+        if (wv < nl) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) sp[wv * ROW + lane * STRIDE + i] = vals[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < total; e += 256) {
+            const int l = e / S, j = e - l * S;
+            dst[base + e] = sp[l * ROW + lds_slot<C>(j)];
+        }
+    };
+    if (a.dp) write_back(a.dp, dpv);
+    if (a.r_out) write_back(a.r_out, rv);
+    if (a.q_out) write_back(a.q_out, qv);
+}
+
+// out[0] = scale * sum_i x[i], single workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* x, int n, float scale, float* out) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)x[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(sm[0] * (double)scale);
+}
+
+template <int C>
+int launch_reward(const RewardArgs& a, hipStream_t st) {
+    const int grid = rlt_cdiv(a.B, LISTS_PER_WG);
+    hipLaunchKernelGGL(reward_loss_kernel<C>, dim3(grid), dim3(256), 0, st, a);
+    return RLT_LAUNCH_RESULT();
+}
+
+int dispatch_reward(const RewardArgs& a, hipStream_t st) {
+    const int c = rlt_cdiv(a.S, 64);
+    if (c <= 1) return launch_reward<1>(a, st);
+    if (c <= 2) return launch_reward<2>(a, st);
+    if (c <= 3) return launch_reward<3>(a, st);
+    if (c <= 4) return launch_reward<4>(a, st);
+    if (c <= 5) return launch_reward<5>(a, st);
+    if (c <= 6) return launch_reward<6>(a, st);
+    if (c <= 8) return launch_reward<8>(a, st);
+    if (c <= 12) return launch_reward<12>(a, st);
+    if (c <= 16) return launch_reward<16>(a, st);
+    return RLT_E_SHAPE;
+}
+
+// ------------------------------------------------------------------------------ multi-task terms
+constexpr int MT_PART = 8;   // floats per partial record
+
+__global__ __launch_bounds__(256) void mt_partial_kernel(const float* rerank, const float* cls, const float* y,
+                                                         size_t n, float* partial) {
+    float s_pos = 0.f, n_pos = 0.f, s_neg = 0.f, n_neg = 0.f, bce = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float t = y[i];
+        if (rerank) {
+            const float s = rerank[i];
+            if (t == 1.f) { s_pos += s; n_pos += 1.f; }
+            if (t == 0.f) { s_neg += s; n_neg += 1.f; }
+        }
+        if (cls) {   // torch binary_cross_entropy: logs clamped at -100
+            const float c = cls[i];
+            const float l1 = fmaxf(logf(c), -100.f);
+            const float l0 = fmaxf(log1pf(-c), -100.f);
+            bce += (t - 1.f) * l0 - t * l1;
+        }
+    }
+    float v[5] = {s_pos, n_pos, s_neg, n_neg, bce};
+    __shared__ float sm[4][5];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float t = wave_sum(v[k]);
+        if (lane == 0) sm[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        partial[blockIdx.x * MT_PART + threadIdx.x] =
+            sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void mt_final_kernel(const float* partial, int nparts, double n_elem, float margin,
+                                                      int has_rerank, int has_cls, float* terms) {
+    const int lane = threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = lane; i < nparts; i += 64)
+        for (int k = 0; k < 5; ++k) v[k] += (double)partial[i * MT_PART + k];
+    for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+        float hinge = 0.f, gpos = 0.f, gneg = 0.f;
+        if (has_rerank && v[1] > 0 && v[3] > 0) {            // utils/losses.py:136-141
+            const float gap = (float)(v[2] / v[3]) - (float)(v[0] / v[1]) + margin;
+            if (gap > 0.f) { hinge = gap; gpos = (float)(-1.0 / v[1]); gneg = (float)(1.0 / v[3]); }
+        }
+        terms[0] = hinge;
+        terms[1] = has_cls ? (float)(v[4] / n_elem) : 0.f;
+        terms[2] = gpos;
+        terms[3] = gneg;
+    }
+}
+
+__global__ __launch_bounds__(256) void mt_bwd_kernel(const float* cls, const float* y, const float* terms, size_t n,
+                                                     float w_r, float w_c, const float* gscale,
+                                                     float* d_rerank, float* d_class) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float gpos = terms[2] * w_r * gs, gneg = terms[3] * w_r * gs;
+    const float cscale = w_c * gs / (float)n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float t = y[i];
+        if (d_rerank) d_rerank[i] = (t == 1.f) ? gpos : ((t == 0.f) ? gneg : 0.f);
+        if (d_class) {   // torch binary_cross_entropy_backward: (x - t) / max((1-x)x, 1e-12)
+            const float c = cls[i];
+            d_class[i] = (c - t) / fmaxf((1.f - c) * c, 1e-12f) * cscale;
+        }
+    }
+}
+
+struct WSumArgs { const float* x[8]; float w[8]; int n; };
+__global__ void weighted_sum_kernel(WSumArgs a, float* out) {
+    float acc = 0.f;
+    for (int i = 0; i < a.n; ++i) acc += a.w[i] * a.x[i][0];
+    out[0] = acc;
+}
+
+// ------------------------------------------------------------------------------ cut metrics
+__global__ __launch_bounds__(256) void cut_metrics_kernel(const float* p, const float* y, const int32_t* k_in,
+                                                          int B, int S, int32_t* k_out, double* f1_out, double* dcg_out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    const float* yr = y + (size_t)b * S;
+    int k;
+    if (k_in) {
+        k = k_in[b];
+    } else {
+        // first maximum, like np.argmax (run.py:141-142)
+        const float* pr = p + (size_t)b * S;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < S; j += 64) {
+            const float v = pr[j];
+            if (v > best) { best = v; bi = j; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        k = (bi == 0x7fffffff ? 0 : bi) + 1;
+    }
+    // utils/metrics.py:15-38 in float64
+    double hits = 0.0, n_rel = 0.0, dcg = 0.0;
+    for (int j = lane; j < S; j += 64) {
+        const double t = (double)yr[j];
+        n_rel += t;
+        if (j < k) {
+            hits += t;
+            dcg += ((yr[j] == 1.f) ? 1.0 : -1.0) / log2((double)(j + 2));
+        }
+    }
+    hits = wave_sum(hits);
+    n_rel = wave_sum(n_rel);
+    dcg = wave_sum(dcg);
+    if (lane == 0) {
+        const double prec = hits / (double)k;
+        const double rec = (n_rel != 0.0) ? hits / n_rel : 0.0;
+        const double f1 = (prec + rec != 0.0) ? 2.0 * prec * rec / (prec + rec) : 0.0;
+        if (k_out) k_out[b] = k;
+        if (f1_out) f1_out[b] = f1;
+        if (dcg_out) dcg_out[b] = dcg;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum2_f64_kernel(const double* a, const double* b, int n, double* out) {
+    __shared__ double sa[256], sb[256];
+    double x = 0.0, z = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { x += a[i]; z += b[i]; }
+    sa[threadIdx.x] = x;
+    sb[threadIdx.x] = z;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                    int metric, int kind, float tau,
+                    float* loss_per_list, float* loss_out, float* dp, void* stream) {
+    RLT_CHECK_ARG(p && labels && loss_per_list && B > 0 && S > 0);
+    RLT_CHECK_ARG(metric == RLT_METRIC_F1 || (metric == RLT_METRIC_DCG && dcg_coef));
+    RLT_CHECK_ARG(kind >= RLT_LOSS_EXPECT && kind <= RLT_LOSS_JS);
+    RLT_CHECK_SHAPE(S <= 1024);
+    if ((S & 3) == 0 && !(rlt_aligned16(p) && rlt_aligned16(labels))) return RLT_E_ALIGN;
+    RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B};
+    hipStream_t st = rlt_stream(stream);
+    int rc = dispatch_reward(a, st);
+    if (rc) return rc;
+    if (loss_out) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_per_list, B, 1.0f / (float)B, loss_out);
+        rc = RLT_LAUNCH_RESULT();
+    }
+    return rc;
+}
+
+int rlt_reward_matrix(const float* labels, const float* dcg_coef, int B, int S, int metric, float tau,
+                      float* r_out, float* q_out, void* stream) {
+    RLT_CHECK_ARG(labels && B > 0 && S > 0 && (r_out || q_out));
+    RLT_CHECK_ARG(metric == RLT_METRIC_F1 || (metric == RLT_METRIC_DCG && dcg_coef));
+    RLT_CHECK_SHAPE(S <= 1024);
+    if ((S & 3) == 0 && !rlt_aligned16(labels)) return RLT_E_ALIGN;
+    RewardArgs a{nullptr, labels, dcg_coef, nullptr, nullptr, r_out, q_out, B, S, metric, RLT_LOSS_KL, tau, 1.0f};
+    return dispatch_reward(a, rlt_stream(stream));
+}
+
+static int mt_grid(size_t n) { return (int)((n + 256 * 8 - 1) / (256 * 8) < 1024 ? (n + 256 * 8 - 1) / (256 * 8) : 1024); }
+
+size_t rlt_mt_terms_workspace(int B, int S) {
+    return (size_t)mt_grid((size_t)B * S) * MT_PART * sizeof(float);
+}
+
+int rlt_mt_terms(const float* rerank, const float* cls, const float* labels, int B, int S, float margin,
+                 float* terms, void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(labels && terms && ws && B > 0 && S > 0 && (rerank || cls));
+    if (ws_bytes < rlt_mt_terms_workspace(B, S)) return RLT_E_WORKSPACE;
+    const size_t n = (size_t)B * S;
+    const int grid = mt_grid(n);
+    hipStream_t st = rlt_stream(stream);
+    hipLaunchKernelGGL(mt_partial_kernel, dim3(grid), dim3(256), 0, st, rerank, cls, labels, n, (float*)ws);
+    hipLaunchKernelGGL(mt_final_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, grid, (double)n, margin,
+                       rerank ? 1 : 0, cls ? 1 : 0, terms);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_mt_terms_bwd(const float* cls, const float* labels, const float* terms, int B, int S,
+                     float w_rerank, float w_class, const float* gscale,
+                     float* d_rerank, float* d_class, void* stream) {
+    RLT_CHECK_ARG(labels && terms && B > 0 && S > 0 && (d_rerank || d_class));
+    RLT_CHECK_ARG(!d_class || cls);
+    const size_t n = (size_t)B * S;
+    hipLaunchKernelGGL(mt_bwd_kernel, dim3(mt_grid(n)), dim3(256), 0, rlt_stream(stream), cls, labels, terms, n,
+                       w_rerank, w_class, gscale, d_rerank, d_class);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_weighted_sum(const float* const* x, const float* w, int n, float* out, void* stream) {
+    RLT_CHECK_ARG(x && w && out && n > 0);
+    RLT_CHECK_SHAPE(n <= 8);
+    WSumArgs a;
+    for (int i = 0; i < 8; ++i) { a.x[i] = i < n ? x[i] : nullptr; a.w[i] = i < n ? w[i] : 0.f; }
+    a.n = n;
+    for (int i = 0; i < n; ++i) RLT_CHECK_ARG(x[i]);
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(1), 0, rlt_stream(stream), a, out);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
+                    int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
+    RLT_CHECK_ARG(labels && (p || k_in) && B > 0 && S > 0);
+    RLT_CHECK_ARG(!sums || (f1_out && dcg_out));
+    hipStream_t st = rlt_stream(stream);
+    hipLaunchKernelGGL(cut_metrics_kernel, dim3(rlt_cdiv(B, 4)), dim3(256), 0, st, p, labels, k_in, B, S,
+                       k_out, f1_out, dcg_out);
+    if (sums) hipLaunchKernelGGL(sum2_f64_kernel, dim3(1), dim3(256), 0, st, f1_out, dcg_out, B, sums);
+    return RLT_LAUNCH_RESULT();
+}
+
+}  // extern "C"

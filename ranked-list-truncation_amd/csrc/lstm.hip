@@ -1,0 +1,227 @@
+// BiLSTM recurrence, hidden size 128 (row M2 of SURVEY.md section 8a; nn.LSTM call sites
+// models/AttnCut.py:8,17, models/MtAttnCut.py:8,22, models/MMOECut.py:63,88).
+//
+// The time loop is strictly sequential (S steps per direction), so it runs as ONE persistent
+// launch per layer: a workgroup of 16 wavefronts owns 32 ranked lists of one direction for all
+// S steps.  W_hh (512x128 fp32 = 256 KB) does not fit LDS (160 KB); it lives in REGISTERS,
+// 64 VGPRs per lane across the 1024 threads, as the A operand of v_mfma_f32_32x32x2_f32:
+//   wavefront w owns hidden units 8w..8w+7 and their 4 gates (32 rows of W_hh);
+//   accumulator row m <-> (gate m>>3, unit 8w + (m&7)), accumulator column <-> list.
+// In the MFMA accumulator layout a lane then holds i,f,g,o of the SAME (list, unit) in registers
+// r, r+4, r+8, r+12, so the cell update is lane-local.  h_{t-1} (32 lists x 128) is exchanged
+// through a double-buffered LDS tile; one barrier per step.  The input projections
+// x_t W_ih^T + b_ih + b_hh for all steps were produced beforehand by one large rlt_gemm and are
+// streamed in (loads issued before the MFMA chain, consumed after it).
+//
+// Backward is the reverse-time recurrence: dA_t (gradient of the pre-activation gates) is
+// computed lane-locally and fed straight from registers as the MFMA B operand of
+// dh_{t-1} = W_hh^T dA_t; the contraction runs over gate rows, which are spread over the 16
+// wavefronts, so the 16 partial products are reduced through LDS in a fixed order
+// (deterministic).  dA is written in place over the gate stash; dW_ih, dW_hh, db and dx are then
+// plain GEMMs / column sums on it (position-major layout makes h_{t-1} a row offset of B).
+#include "common.h"
+
+namespace {
+
+constexpr int HID = 128;
+constexpr int LISTS = 32;
+constexpr int LDH = 132;      // LDS row stride of the h tile (floats)
+constexpr int LDP = 68;       // LDS row stride of the partial dh tiles (floats)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                          const float* __restrict__ w_hh_r, int S, int B, float* __restrict__ h_out,
+                                                          float* __restrict__ c_out) {
+    __shared__ __attribute__((aligned(16))) float hs[2][LISTS * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+
+    // A operand: W_hh rows of this wavefront (gate l31>>3, unit 8w + (l31&7)), k = hh*64 + ks
+    float wreg[64];
+    {
+        const float* wp = (dir ? w_hh_r : w_hh_f) + (size_t)((l31 >> 3) * HID + 8 * w + (l31 & 7)) * HID + hh * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(wp + 4 * q);
+            wreg[4 * q + 0] = v.x; wreg[4 * q + 1] = v.y; wreg[4 * q + 2] = v.z; wreg[4 * q + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < LISTS * LDH; i += 1024) hs[0][i] = 0.f;      // h_0 = 0
+    float c[4] = {0.f, 0.f, 0.f, 0.f};                                  // c_0 = 0
+    const int ucol = 8 * w + 4 * hh;                                    // first of this lane's 4 units
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < S; ++t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        float4 gin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gin[g] = valid ? *reinterpret_cast<const float4*>(grow + g * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* hp = hs[cur] + l31 * LDH + hh * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * q);
+            acc = mfma32(wreg[4 * q + 0], hv.x, acc);
+            acc = mfma32(wreg[4 * q + 1], hv.y, acc);
+            acc = mfma32(wreg[4 * q + 2], hv.z, acc);
+            acc = mfma32(wreg[4 * q + 3], hv.w, acc);
+        }
+        const float* gi_ = reinterpret_cast<const float*>(&gin[0]);
+        float act[16], hnew[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = sigmoidf_(acc[u] + gi_[u]);
+            const float fg = sigmoidf_(acc[4 + u] + gi_[4 + u]);
+            const float gg = tanhf(acc[8 + u] + gi_[8 + u]);
+            const float og = sigmoidf_(acc[12 + u] + gi_[12 + u]);
+            c[u] = fg * c[u] + ig * gg;
+            hnew[u] = og * tanhf(c[u]);
+            act[u] = ig; act[4 + u] = fg; act[8 + u] = gg; act[12 + u] = og;
+        }
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(grow + g * HID) = make_float4(act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]);
+            *reinterpret_cast<float4*>(c_out + (tok * 2 + dir) * HID + ucol) = make_float4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+        }
+        *reinterpret_cast<float4*>(&hs[cur ^ 1][l31 * LDH + ucol]) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void bilstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                          const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
+                                                          const float* __restrict__ d_hout, int S, int B) {
+    extern __shared__ __attribute__((aligned(16))) float P[];           // [16][LISTS][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+    const int ucol = 8 * w + 4 * hh;
+
+    // A operand of dh = W_hh^T dA: wT[a][r] = W_hh[(r>>2)*128 + 8w + 4hh + (r&3)][a*32 + l31]
+    float wT[4][16];
+    {
+        const float* wp = dir ? w_hh_r : w_hh_f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* rp = wp + (size_t)((r >> 2) * HID + ucol + (r & 3)) * HID + l31;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wT[a][r] = rp[a * 32];
+        }
+    }
+    float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhrec[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int t = S - 1; t >= 0; --t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        float dA[16];
+        if (valid) {
+            float4 gv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+            const float4 ct4 = *reinterpret_cast<const float4*>(cst + (tok * 2 + dir) * HID + ucol);
+            float4 cp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t > 0) {
+                const size_t tokp = (size_t)(dir ? s + 1 : s - 1) * B + b;
+                cp4 = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol);
+            }
+            const float4 dh4 = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol);
+            const float* gf_ = reinterpret_cast<const float*>(&gv[0]);
+            const float* ct = reinterpret_cast<const float*>(&ct4);
+            const float* cp = reinterpret_cast<const float*>(&cp4);
+            const float* dho = reinterpret_cast<const float*>(&dh4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = gf_[u], fg = gf_[4 + u], gg = gf_[8 + u], og = gf_[12 + u];
+                const float dh = dho[u] + dhrec[u];
+                const float tc = tanhf(ct[u]);
+                const float dcu = dc[u] + dh * og * (1.f - tc * tc);
+                dA[u] = dcu * gg * ig * (1.f - ig);
+                dA[4 + u] = dcu * cp[u] * fg * (1.f - fg);
+                dA[8 + u] = dcu * ig * (1.f - gg * gg);
+                dA[12 + u] = dh * tc * og * (1.f - og);
+                dc[u] = dcu * fg;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(grow + g * HID) = make_float4(dA[4 * g], dA[4 * g + 1], dA[4 * g + 2], dA[4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dA[r] = 0.f;
+        }
+        if (t == 0) break;                         // dh_{-1} is not needed
+        // dh_{t-1}[list][k] = sum_rows dA[list][row] W_hh[row][k]; k tiles {0,1} then {2,3}
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0 = mfma32(wT[2 * rd][r], dA[r], acc0);
+                acc1 = mfma32(wT[2 * rd + 1][r], dA[r], acc1);
+            }
+            float* pw = P + (size_t)(w * LISTS + l31) * LDP + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(pw + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+                *reinterpret_cast<float4*>(pw + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+            }
+            __syncthreads();
+            if ((w >> 3) == rd) {
+                const float* pr = P + (size_t)l31 * LDP + 8 * (w & 7) + 4 * hh;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ww = 0; ww < 16; ++ww) {
+                    const float4 v = *reinterpret_cast<const float4*>(pr + (size_t)ww * LISTS * LDP);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+                dhrec[0] = sum.x; dhrec[1] = sum.y; dhrec[2] = sum.z; dhrec[3] = sum.w;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
+                       float* h_out, float* c_out, void* stream) {
+    RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
+    if (!(rlt_aligned16(gates) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(h_out) && rlt_aligned16(c_out)))
+        return RLT_E_ALIGN;
+    hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
+                       gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
+                       const float* d_hout, int S, int B, void* stream) {
+    RLT_CHECK_ARG(gates && c && w_hh_fwd && w_hh_rev && d_hout && S > 0 && B > 0);
+    if (!(rlt_aligned16(gates) && rlt_aligned16(c) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(d_hout)))
+        return RLT_E_ALIGN;
+    const size_t shm = (size_t)16 * LISTS * LDP * sizeof(float);
+    int rc = rlt_allow_lds(bilstm_bwd_kernel, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
+                       gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
+    return RLT_LAUNCH_RESULT();
+}
+
+}  // extern "C"

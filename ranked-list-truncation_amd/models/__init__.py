@@ -1,0 +1,9 @@
+"""Plug-in surface of the hot path: the same names the reference exports from models/__init__.py:2-6
+for the five in-scope model families."""
+from .Choopy import Choopy
+from .AttnCut import AttnCut
+from .MtChoopy import MtChoopy
+from .MtAttnCut import MtAttnCut
+from .MMOECut import MMOECut
+
+__all__ = ["Choopy", "AttnCut", "MtChoopy", "MtAttnCut", "MMOECut"]

@@ -1,0 +1,91 @@
+"""Shared building blocks of the HIP model classes.
+
+Parameters are held in `ParamTree`s that mirror the module tree (and therefore the
+`state_dict()` keys, shapes, order and init distributions) of the stock torch modules the
+reference builds (nn.LSTM, nn.TransformerEncoder, nn.Sequential(nn.Linear, ...)); the forward
+pass never calls those modules - it runs the HIP kernels through `rlt_hip.ops`.
+"""
+import torch
+from torch import nn
+
+from rlt_hip import native as N
+from rlt_hip import ops
+
+
+class ParamTree(nn.Module):
+    """Parameter-only mirror of `src`: same names, shapes, order and (cloned) initial values."""
+
+    def __init__(self, src: nn.Module):
+        super().__init__()
+        for name, p in src.named_parameters(recurse=False):
+            self.register_parameter(name, nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad))
+        for name, child in src.named_children():
+            sub = ParamTree(child)
+            if next(sub.parameters(), None) is not None:
+                self.add_module(name, sub)
+
+    def forward(self, *a, **k):          # pragma: no cover - holders are never called
+        raise RuntimeError("ParamTree only holds parameters")
+
+
+def bilstm_params(input_size, hidden=128):
+    # same construction as models/AttnCut.py:8
+    return ParamTree(nn.LSTM(input_size=input_size, hidden_size=hidden, num_layers=2,
+                             batch_first=True, bidirectional=True))
+
+
+def encoder_params(d_model, n_head, num_layers, dropout):
+    # same construction as models/AttnCut.py:9-10 (post-norm, ReLU, FF 2048, eps 1e-5)
+    layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=n_head, dropout=dropout)
+    return ParamTree(nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False))
+
+
+def head_params(d_model):
+    # nn.Sequential(nn.Linear(d_model, 1), <activation>): parameters live under key "0"
+    return ParamTree(nn.Sequential(nn.Linear(d_model, 1)))
+
+
+def check_input(x, ndim=3):
+    if not x.is_cuda:
+        raise RuntimeError("the HIP models run on the GPU only: move the model and its inputs to 'cuda' "
+                           "(no CPU fallback exists)")
+    if x.dim() != ndim:
+        raise ValueError(f"expected a {ndim}-d input, got {tuple(x.shape)}")
+    return N.f32c(x)
+
+
+def check_dropout(module, p):
+    if module.training and p > 0.0:
+        raise NotImplementedError(
+            "dropout > 0 in train() is not implemented on the HIP path yet; construct the model with "
+            "dropout=0.0 (as the reference's published runs do) or call .eval()")
+
+
+def bilstm(x_pm, params, S, B):
+    """2 stacked bidirectional layers, position-major in and out."""
+    h = ops.bilstm_layer(x_pm, params, 0, S, B)
+    return ops.bilstm_layer(h, params, 1, S, B)
+
+
+def encoder(x_pm, params, n_head, S, B):
+    """Stack of post-norm encoder layers with list-axis attention."""
+    h = x_pm
+    for layer in params.layers.children():
+        att = layer.self_attn
+        qkv = ops.linear(h, att.in_proj_weight, att.in_proj_bias)
+        ctx_ = ops.list_attention(qkv, S, B, n_head)
+        proj = ops.linear(ctx_, att.out_proj.weight, att.out_proj.bias)
+        h1 = ops.add_layernorm(h, proj, layer.norm1.weight, layer.norm1.bias)
+        ff = ops.linear(h1, layer.linear1.weight, layer.linear1.bias, relu=True)
+        ff = ops.linear(ff, layer.linear2.weight, layer.linear2.bias)
+        h = ops.add_layernorm(h1, ff, layer.norm2.weight, layer.norm2.bias)
+    return h
+
+
+def pick_tasks(num_tasks):
+    """Head list for the float task code of models/MtAttnCut.py:27-29."""
+    if num_tasks == 3:
+        return ["classi", "rerank", "decison_layer"]
+    if num_tasks == 2.1:
+        return ["classi", "decison_layer"]
+    return ["rerank", "decison_layer"]

@@ -1,0 +1,134 @@
+"""ctypes binding of librlt_hip.so (the C ABI declared in include/rlt_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, a RuntimeError is raised.
+PyTorch is used only to own device memory and streams; every tensor is handed to the library as
+a raw device pointer.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "csrc", "librlt_hip.so")
+
+# constants of include/rlt_hip.h
+METRIC_F1, METRIC_DCG = 0, 1
+LOSS_EXPECT, LOSS_CE, LOSS_KL, LOSS_JS = 0, 1, 2, 3
+GEMM_RELU, GEMM_ACCUMULATE = 1, 2
+HEAD_SOFTMAX, HEAD_SIGMOID, HEAD_IDENTITY = 0, 1, 2
+
+P = c_void_p
+_SIGNATURES = {
+    "rlt_abi_version": (c_int, []),
+    "rlt_error_string": (c_char_p, [c_int]),
+    "rlt_reward_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
+    "rlt_reward_matrix": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
+    "rlt_mt_terms_workspace": (c_size_t, [c_int, c_int]),
+    "rlt_mt_terms": (c_int, [P, P, P, c_int, c_int, c_float, P, P, c_size_t, P]),
+    "rlt_mt_terms_bwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "rlt_weighted_sum": (c_int, [P, P, c_int, P, P]),
+    "rlt_cut_metrics": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P]),
+    "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),
+    "rlt_colsum_workspace": (c_size_t, [c_int, c_int]),
+    "rlt_colsum": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
+    "rlt_segment_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "rlt_relu_bwd": (c_int, [P, P, c_size_t, P]),
+    "rlt_scale": (c_int, [P, P, c_size_t, P]),
+    "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P]),
+    "rlt_add_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, c_int, P, c_size_t, P]),
+    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
+    "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "rlt_from_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "rlt_choopy_embed": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "rlt_heads_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_heads_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rlt_heads_bwd": (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, P, c_int, P, P, P, c_size_t, P]),
+    "rlt_mmoe_gate_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_mmoe_gate_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_mmoe_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_size_t, P]),
+    "rlt_mmoe_mix_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_mmoe_mix_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "rlt_adam_step": (c_int, [P, P, P, P, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float, P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load librlt_hip.so (once) and declare every entry point; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python ranked-list-truncation_amd/rlt_hip/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rlt_abi_version() != 1:
+        raise RuntimeError("librlt_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rlt_error_string(int(rc))
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else rc} (code {rc})")
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero code."""
+    check(getattr(load(), name)(*args), name)
+
+
+def query(name, *args):
+    """Invoke a size_t-returning workspace query."""
+    return int(getattr(load(), name)(*args))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("the HIP hot path needs tensors on the GPU (cuda device); there is no CPU fallback")
+
+
+def f32c(t):
+    """fp32 + contiguous view/copy of a tensor (glue only)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(nbytes, device):
+    n = max(4, (int(nbytes) + 3) // 4)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def pointer_array(tensors):
+    """Host array of device pointers (const float* const*)."""
+    arr = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

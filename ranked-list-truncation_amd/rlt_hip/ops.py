@@ -1,0 +1,479 @@
+"""torch.autograd.Function wrappers around the C ABI (include/rlt_hip.h).
+
+PyTorch here is plumbing: it owns device buffers, the stream and the autograd tape.  Every
+arithmetic step of the hot path - forward AND backward - is a call into librlt_hip.so.
+Activations are "position-major": a (S*B, E) matrix whose row index is s*B + b.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import native as N
+from .native import call, ptr, query, stream, workspace
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------ raw helpers
+def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0):
+    """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors."""
+    ws_bytes = query("rlt_gemm_workspace", ta, tb, M, Nn, K)
+    ws = workspace(ws_bytes, C.device) if ws_bytes else None
+    esz = 4
+    call("rlt_gemm", ta, tb, M, Nn, K,
+         N.c_void_p(A.data_ptr() + a_off * esz), lda, N.c_void_p(B.data_ptr() + b_off * esz), ldb,
+         N.c_void_p(C.data_ptr() + c_off * esz), ldc, ptr(bias), ptr(bias2), flags,
+         ptr(ws), ws_bytes, stream())
+
+
+def colsum(X, ldx, T, Nn, out, accumulate=0, x_off=0):
+    ws_bytes = query("rlt_colsum_workspace", T, Nn)
+    ws = workspace(ws_bytes, X.device)
+    call("rlt_colsum", N.c_void_p(X.data_ptr() + 4 * x_off), ldx, T, Nn, ptr(out), accumulate, ptr(ws), ws_bytes, stream())
+
+
+# ------------------------------------------------------------------------------ Linear
+class LinearFn(Function):
+    """y = x W^T + b (optional fused ReLU).  x (T,K), W (N,K), b (N)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        T, K = x.shape
+        Nn = w.shape[0]
+        y = _empty((T, Nn), x)
+        gemm(0, 1, T, Nn, K, x, K, w, K, y, Nn, bias=b, flags=N.GEMM_RELU if relu else 0)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        T, K = x.shape
+        Nn = w.shape[0]
+        dy = N.f32c(dy)
+        if ctx.relu:
+            dy = dy.clone()
+            call("rlt_relu_bwd", ptr(dy), ptr(y), dy.numel(), stream())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((T, K), x)
+            gemm(0, 0, T, K, Nn, dy, Nn, w, K, dx, K)
+        if ctx.needs_input_grad[1]:
+            dw = _empty((Nn, K), x)
+            gemm(1, 0, Nn, K, T, dy, Nn, x, K, dw, K)
+        if ctx.needs_input_grad[2]:
+            db = _empty((Nn,), x)
+            colsum(dy, Nn, T, Nn, db)
+        return dx, dw, db, None
+
+
+def linear(x, w, b, relu=False):
+    return LinearFn.apply(x, w, b, relu)
+
+
+# ------------------------------------------------------------------------------ residual + LayerNorm
+class AddLayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        T, E = x.shape
+        y = _empty((T, E), x)
+        stats = _empty((T, 2), x)
+        call("rlt_add_layernorm_fwd", ptr(x), ptr(r), ptr(gamma), ptr(beta), T, E, eps, ptr(y), ptr(stats), stream())
+        ctx.save_for_backward(x, r, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, gamma, stats = ctx.saved_tensors
+        T, E = x.shape
+        dy = N.f32c(dy)
+        dz = _empty((T, E), x)
+        dgamma, dbeta = _empty((E,), x), _empty((E,), x)
+        ws_bytes = query("rlt_add_layernorm_bwd_workspace", T, E)
+        ws = workspace(ws_bytes, x.device)
+        call("rlt_add_layernorm_bwd", ptr(x), ptr(r), ptr(gamma), ptr(stats), ptr(dy), T, E,
+             ptr(dz), ptr(dgamma), ptr(dbeta), 0, ptr(ws), ws_bytes, stream())
+        return dz, dz, dgamma, dbeta, None
+
+
+def add_layernorm(x, r, gamma, beta, eps=1e-5):
+    return AddLayerNormFn.apply(x, r, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------ list-axis attention
+class ListAttentionFn(Function):
+    """qkv (S*B, 3E) -> concatenated heads (S*B, E); attention over the B lists at each position."""
+
+    @staticmethod
+    def forward(ctx, qkv, S, B, H):
+        E = qkv.shape[1] // 3
+        HD = E // H
+        out = _empty((S * B, E), qkv)
+        lse = _empty((S, H, B), qkv)
+        call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, ptr(out), ptr(lse), stream())
+        ctx.dims = (S, B, H, HD)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        S, B, H, HD = ctx.dims
+        dout = N.f32c(dout)
+        dqkv = torch.empty_like(qkv)
+        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
+        ws = workspace(ws_bytes, qkv.device)
+        call("rlt_list_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(dqkv),
+             ptr(ws), ws_bytes, stream())
+        return dqkv, None, None, None
+
+
+def list_attention(qkv, S, B, H):
+    return ListAttentionFn.apply(qkv, S, B, H)
+
+
+# ------------------------------------------------------------------------------ BiLSTM layer (H = 128)
+class BiLSTMLayerFn(Function):
+    """One bidirectional LSTM layer on position-major input x (S*B, I) -> (S*B, 256)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, S, B):
+        T, I = x.shape
+        H4 = w_ih_f.shape[0]
+        if H4 != 512 or w_hh_f.shape != (512, 128):
+            raise RuntimeError("the HIP BiLSTM kernel is specialised for hidden_size=128 (as the reference hard-codes)")
+        gates = _empty((T, 2 * H4), x)
+        # input projections of both directions, biases b_ih + b_hh folded in
+        gemm(0, 1, T, H4, I, x, I, w_ih_f, I, gates, 2 * H4, bias=b_ih_f, bias2=b_hh_f)
+        gemm(0, 1, T, H4, I, x, I, w_ih_r, I, gates, 2 * H4, bias=b_ih_r, bias2=b_hh_r, c_off=H4)
+        h = _empty((T, 256), x)
+        c = _empty((T, 256), x)
+        call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(h), ptr(c), stream())
+        ctx.dims = (S, B, I)
+        ctx.save_for_backward(x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h)
+        ctx.used = False
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        if ctx.used:
+            raise RuntimeError("BiLSTMLayerFn.backward overwrites its stash in place and can run only once")
+        ctx.used = True
+        x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h = ctx.saved_tensors
+        S, B, I = ctx.dims
+        T = S * B
+        dh = N.f32c(dh)
+        # gates <- d(pre-activation gates), in place
+        call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w_hh_f), ptr(w_hh_r), ptr(dh), S, B, stream())
+        dA = gates
+        db = _empty((1024,), x)
+        colsum(dA, 1024, T, 1024, db)
+        grads_w = []
+        for d, (w_ih, _w_hh) in enumerate(((w_ih_f, w_hh_f), (w_ih_r, w_hh_r))):
+            dw_ih = _empty((512, I), x)
+            gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d)
+            dw_hh = torch.zeros((512, 128), dtype=torch.float32, device=x.device)
+            if S > 1:
+                K = T - B
+                if d == 0:   # h_{t-1} of position s is the row block of position s-1
+                    gemm(1, 0, 512, 128, K, dA, 1024, h, 256, dw_hh, 128, a_off=B * 1024, b_off=0)
+                else:        # reverse direction: h_{t-1} of position s is position s+1
+                    gemm(1, 0, 512, 128, K, dA, 1024, h, 256, dw_hh, 128, a_off=512, b_off=B * 256 + 128)
+            grads_w.append((dw_ih, dw_hh))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((T, I), x)
+            gemm(0, 0, T, I, 512, dA, 1024, w_ih_f, I, dx, I)
+            gemm(0, 0, T, I, 512, dA, 1024, w_ih_r, I, dx, I, flags=N.GEMM_ACCUMULATE, a_off=512)
+        db_f, db_r = db[:512], db[512:]
+        (dwi_f, dwh_f), (dwi_r, dwh_r) = grads_w
+        return dx, dwi_f, dwh_f, db_f, db_f, dwi_r, dwh_r, db_r, db_r, None, None
+
+
+def bilstm_layer(x, params, layer, S, B):
+    p = lambda n: getattr(params, f"{n}_l{layer}")
+    pr = lambda n: getattr(params, f"{n}_l{layer}_reverse")
+    return BiLSTMLayerFn.apply(x, p("weight_ih"), p("weight_hh"), p("bias_ih"), p("bias_hh"),
+                               pr("weight_ih"), pr("weight_hh"), pr("bias_ih"), pr("bias_hh"), S, B)
+
+
+# ------------------------------------------------------------------------------ layout
+class ToPositionMajorFn(Function):
+    """(B,S,F) -> (S*B,F)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, S, F = x.shape
+        out = _empty((S * B, F), x)
+        call("rlt_to_position_major", ptr(x), B, S, F, ptr(out), stream())
+        ctx.dims = (B, S, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, F = ctx.dims
+        dout = N.f32c(dout)
+        dx = _empty((B, S, F), dout)
+        call("rlt_from_position_major", ptr(dout), B, S, F, ptr(dx), stream())
+        return dx
+
+
+def to_position_major(x):
+    return ToPositionMajorFn.apply(x)
+
+
+class ChoopyEmbedFn(Function):
+    """cat(score, position_encoding) in position-major layout: (B,S,1),(S,E-1) -> (S*B,E)."""
+
+    @staticmethod
+    def forward(ctx, score, pe):
+        B, S = score.shape[0], score.shape[1]
+        E = pe.shape[1] + 1
+        out = _empty((S * B, E), score)
+        call("rlt_choopy_embed", ptr(score), ptr(pe), B, S, E, ptr(out), stream())
+        ctx.dims = (B, S, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, E = ctx.dims
+        dout = N.f32c(dout)
+        dpe = _empty((S, E - 1), dout)
+        # dPE[s] = sum over the B rows of position s, columns 1..E-1
+        call("rlt_segment_colsum", N.c_void_p(dout.data_ptr() + 4), E, S, B, E - 1, ptr(dpe), E - 1, 0, stream())
+        dscore = None
+        if ctx.needs_input_grad[0]:
+            col = dout[:, 0].contiguous().view(S, B, 1)
+            dscore = _empty((B, S, 1), dout)
+            call("rlt_from_position_major", ptr(col), B, S, 1, ptr(dscore), stream())
+        return dscore, dpe
+
+
+def choopy_embed(score, pe):
+    return ChoopyEmbedFn.apply(score, pe)
+
+
+# ------------------------------------------------------------------------------ heads
+class HeadsFn(Function):
+    """n Linear(E,1) heads + {softmax over positions | sigmoid | identity}: x (S*B,E) -> (n,B,S)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kinds, S, B):
+        n, E = w.shape
+        out = _empty((n, B, S), x)
+        karr = (N.c_int * n)(*kinds)
+        call("rlt_heads_fwd", ptr(x), ptr(w), ptr(b), karr, n, S, B, E, ptr(out), stream())
+        ctx.meta = (tuple(kinds), S, B)
+        ctx.save_for_backward(x, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        kinds, S, B = ctx.meta
+        n, E = w.shape
+        dout = N.f32c(dout)
+        dx = _empty((S * B, E), x)
+        dw, db = _empty((n, E), x), _empty((n,), x)
+        karr = (N.c_int * n)(*kinds)
+        ws_bytes = query("rlt_heads_bwd_workspace", n, S, B, E)
+        ws = workspace(ws_bytes, x.device)
+        call("rlt_heads_bwd", ptr(x), ptr(w), karr, n, ptr(out), ptr(dout), S, B, E, ptr(dx), 0, ptr(dw), ptr(db),
+             ptr(ws), ws_bytes, stream())
+        return dx, dw, db, None, None, None
+
+
+def heads(x, weights, biases, kinds, S, B):
+    """weights: list of (1,E) parameters, biases: list of (1,) parameters (glue: tiny cat)."""
+    w = torch.cat([wi.reshape(1, -1) for wi in weights], dim=0) if len(weights) > 1 else weights[0].reshape(1, -1)
+    b = torch.cat([bi.reshape(1) for bi in biases], dim=0) if len(biases) > 1 else biases[0].reshape(1)
+    out = HeadsFn.apply(x, w, b, kinds, S, B)
+    return [out[i].unsqueeze(2) for i in range(len(kinds))]          # each (B,S,1)
+
+
+# ------------------------------------------------------------------------------ MMOE
+class MMOEGateFn(Function):
+    """gates (n_tasks,B,n_e) = softmax_e(flatten_s(h[b]) @ w_gate[t])."""
+
+    @staticmethod
+    def forward(ctx, h, S, B, *w_gates):
+        C = h.shape[1]
+        nt, ne = len(w_gates), w_gates[0].shape[1]
+        gates = _empty((nt, B, ne), h)
+        warr = N.pointer_array(w_gates)
+        call("rlt_mmoe_gate_fwd", ptr(h), warr, nt, ne, S, B, C, ptr(gates), stream())
+        ctx.dims = (S, B, C, nt, ne)
+        ctx.save_for_backward(h, gates, *w_gates)
+        return gates
+
+    @staticmethod
+    def backward(ctx, dgates):
+        h, gates, *w_gates = ctx.saved_tensors
+        S, B, C, nt, ne = ctx.dims
+        dgates = N.f32c(dgates)
+        dh = torch.empty_like(h)
+        dws = [torch.empty_like(w) for w in w_gates]
+        ws_bytes = query("rlt_mmoe_gate_bwd_workspace", nt, ne, S, B, C)
+        ws = workspace(ws_bytes, h.device)
+        call("rlt_mmoe_gate_bwd", ptr(h), N.pointer_array(w_gates), ptr(gates), ptr(dgates), nt, ne, S, B, C,
+             ptr(dh), 0, N.pointer_array(dws), ptr(ws), ws_bytes, stream())
+        return (dh, None, None, *dws)
+
+
+class MMOEMixFn(Function):
+    """mixed (n_tasks,S*B,E) = sum_e gates[t][b][e] * expert_e."""
+
+    @staticmethod
+    def forward(ctx, gates, S, B, *experts):
+        nt, _, ne = gates.shape
+        E = experts[0].shape[1]
+        mixed = _empty((nt, S * B, E), gates)
+        call("rlt_mmoe_mix_fwd", N.pointer_array(experts), ptr(gates), nt, ne, S, B, E, ptr(mixed), stream())
+        ctx.dims = (S, B, E, nt, ne)
+        ctx.save_for_backward(gates, *experts)
+        return mixed
+
+    @staticmethod
+    def backward(ctx, dmixed):
+        gates, *experts = ctx.saved_tensors
+        S, B, E, nt, ne = ctx.dims
+        dmixed = N.f32c(dmixed)
+        dex = [torch.empty_like(e) for e in experts]
+        dgates = torch.empty_like(gates)
+        call("rlt_mmoe_mix_bwd", N.pointer_array(experts), ptr(gates), ptr(dmixed), nt, ne, S, B, E,
+             N.pointer_array(dex), ptr(dgates), stream())
+        return (dgates, None, None, *dex)
+
+
+# ------------------------------------------------------------------------------ losses
+_COEF_CACHE = {}
+
+
+def dcg_coef(S, device):
+    """log2(j+2) table exactly as the reference builds it (utils/metrics.py:7), fp32 on device."""
+    key = (S, str(device))
+    if key not in _COEF_CACHE:
+        _COEF_CACHE[key] = torch.tensor([math.log(j + 2, 2) for j in range(S)], dtype=torch.float32, device=device)
+    return _COEF_CACHE[key]
+
+
+class RewardLossFn(Function):
+    """Fused reward matrix + {Choopy | AttnCut | KL | JS} loss; returns a 0-d tensor."""
+
+    @staticmethod
+    def forward(ctx, p, labels, metric, kind, tau):
+        B, S = labels.shape
+        coef = dcg_coef(S, p.device) if metric == N.METRIC_DCG else None
+        per_list = _empty((B,), p)
+        loss = _empty((1,), p)
+        dp = _empty((B, S), p)
+        call("rlt_reward_loss", ptr(p), ptr(labels), ptr(coef), B, S, metric, kind, tau,
+             ptr(per_list), ptr(loss), ptr(dp), stream())
+        ctx.save_for_backward(dp)
+        ctx.pshape = p.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (dp,) = ctx.saved_tensors
+        g = dp.clone()
+        go = N.f32c(go).reshape(1)
+        call("rlt_scale", ptr(g), ptr(go), g.numel(), stream())
+        return g.view(ctx.pshape), None, None, None, None
+
+
+class MtCutLossFn(Function):
+    """cut JS loss + w_r * rerank hinge + w_c * BCE, one tape node (utils/losses.py:180-191)."""
+
+    @staticmethod
+    def forward(ctx, cut_p, rerank, cls, labels, metric, tau, w_r, w_c, margin):
+        B, S = labels.shape
+        dev = cut_p.device
+        coef = dcg_coef(S, dev) if metric == N.METRIC_DCG else None
+        per_list = _empty((B,), cut_p)
+        cut = _empty((1,), cut_p)
+        dp = _empty((B, S), cut_p)
+        call("rlt_reward_loss", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, N.LOSS_JS, tau,
+             ptr(per_list), ptr(cut), ptr(dp), stream())
+        terms = _empty((4,), cut_p)
+        ws_bytes = query("rlt_mt_terms_workspace", B, S)
+        ws = workspace(ws_bytes, dev)
+        call("rlt_mt_terms", ptr(rerank), ptr(cls), ptr(labels), B, S, margin, ptr(terms), ptr(ws), ws_bytes, stream())
+        # loss = cut + w_r * hinge + w_c * bce, in the reference's order of additions
+        xs, ws_ = [cut], [1.0]
+        if rerank is not None:
+            xs.append(terms[0:1]); ws_.append(w_r)
+        if cls is not None:
+            xs.append(terms[1:2]); ws_.append(w_c)
+        loss = _empty((1,), cut_p)
+        warr = (N.c_float * len(ws_))(*ws_)
+        call("rlt_weighted_sum", N.pointer_array(xs), warr, len(xs), ptr(loss), stream())
+        ctx.save_for_backward(dp, cls, labels, terms)
+        ctx.meta = (w_r, w_c, rerank is not None, cut_p.shape, None if rerank is None else rerank.shape,
+                    None if cls is None else cls.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        dp, cls, labels, terms = ctx.saved_tensors
+        w_r, w_c, has_rr, pshape, rshape, cshape = ctx.meta
+        B, S = labels.shape
+        go = N.f32c(go).reshape(1)
+        g = dp.clone()
+        call("rlt_scale", ptr(g), ptr(go), g.numel(), stream())
+        d_rr = _empty((B, S), dp) if has_rr else None
+        d_cl = _empty((B, S), dp) if cls is not None else None
+        if has_rr or cls is not None:
+            call("rlt_mt_terms_bwd", ptr(cls), ptr(labels), ptr(terms), B, S, w_r, w_c, ptr(go), ptr(d_rr), ptr(d_cl), stream())
+        return (g.view(pshape), None if d_rr is None else d_rr.view(rshape), None if d_cl is None else d_cl.view(cshape),
+                None, None, None, None, None, None)
+
+
+class RerankLossFn(Function):
+    """Stand-alone RerankLoss (utils/losses.py:99-141)."""
+
+    @staticmethod
+    def forward(ctx, score, labels, margin):
+        B, S = labels.shape
+        terms = _empty((4,), score)
+        ws_bytes = query("rlt_mt_terms_workspace", B, S)
+        ws = workspace(ws_bytes, score.device)
+        call("rlt_mt_terms", ptr(score), None, ptr(labels), B, S, margin, ptr(terms), ptr(ws), ws_bytes, stream())
+        ctx.save_for_backward(labels, terms)
+        ctx.sshape = score.shape
+        return terms[0].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        labels, terms = ctx.saved_tensors
+        B, S = labels.shape
+        go = N.f32c(go).reshape(1)
+        d = _empty((B, S), labels)
+        call("rlt_mt_terms_bwd", None, ptr(labels), ptr(terms), B, S, 1.0, 0.0, ptr(go), ptr(d), None, stream())
+        return d.view(ctx.sshape), None, None
+
+
+# ------------------------------------------------------------------------------ metrics
+def cut_metrics(p, labels, k_in=None):
+    """Per-list (k, F1@k, DCG@k) on device; p (B,S) or (B,S,1), labels (B,S).  Returns tensors."""
+    B, S = labels.shape
+    dev = labels.device
+    k = torch.empty((B,), dtype=torch.int32, device=dev)
+    f1 = torch.empty((B,), dtype=torch.float64, device=dev)
+    dcg = torch.empty((B,), dtype=torch.float64, device=dev)
+    sums = torch.empty((2,), dtype=torch.float64, device=dev)
+    call("rlt_cut_metrics", ptr(p), ptr(labels), ptr(k_in), B, S, ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+    return k, f1, dcg, sums
+
+
+def reward_matrix(labels, metric, tau=1.0, want_q=False):
+    B, S = labels.shape
+    coef = dcg_coef(S, labels.device) if metric == N.METRIC_DCG else None
+    r = _empty((B, S), labels)
+    q = _empty((B, S), labels) if want_q else None
+    call("rlt_reward_matrix", ptr(labels), ptr(coef), B, S, metric, tau, ptr(r), ptr(q), stream())
+    return (r, q) if want_q else r

@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): run every HIP op against a torch-CPU / oracle reference and print the
+errors WITHOUT stopping at the first failure.  `python tools/gpu_probe.py [section ...]`.
+Not part of the test suite (tests/ holds the asserted versions)."""
+import math
+import os
+import sys
+import time
+import traceback
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "ranked-list-truncation_amd"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from rlt_hip import native as N
+from rlt_hip import ops
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+RESULTS = []
+
+
+def report(name, err, tol):
+    ok = err <= tol and not math.isnan(err)
+    RESULTS.append((name, err, tol, ok))
+    print(f"{'OK  ' if ok else 'FAIL'} {name:58s} err={err:.3e} tol={tol:.1e}", flush=True)
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def section(fn):
+    fn._is_section = True
+    return fn
+
+
+# ------------------------------------------------------------------------------------------------
+@section
+def gemm():
+    for (ta, tb, M, Nn, K) in [(0, 1, 300, 768, 256), (0, 1, 1500, 1024, 3), (0, 0, 1500, 256, 2048), (1, 0, 2048, 256, 1500),
+                               (0, 1, 129, 130, 17), (1, 1, 70, 33, 45), (1, 0, 512, 128, 40000), (0, 0, 257, 3, 512),
+                               (1, 0, 512, 3, 9000)]:
+        A = torch.randn((K, M) if ta else (M, K))
+        B = torch.randn((Nn, K) if tb else (K, Nn))
+        bias = torch.randn(Nn)
+        ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
+        C = torch.empty(M, Nn, device=dev)
+        Ad, Bd, bd = A.to(dev), B.to(dev), bias.to(dev)
+        ops.gemm(ta, tb, M, Nn, K, Ad, A.shape[1], Bd, B.shape[1], C, Nn, bias=bd)
+        report(f"gemm ta={ta} tb={tb} {M}x{Nn}x{K}", rel(C, ref), 2e-6 * math.sqrt(K) + 1e-6)
+    # relu + accumulate
+    A, B = torch.randn(200, 64), torch.randn(96, 64)
+    C0 = torch.randn(200, 96)
+    C = C0.clone().to(dev)
+    ops.gemm(0, 1, 200, 96, 64, A.to(dev), 64, B.to(dev), 64, C, 96, flags=N.GEMM_RELU | N.GEMM_ACCUMULATE)
+    report("gemm relu+accumulate", rel(C, torch.relu(A @ B.t() + C0)), 1e-5)
+    X = torch.randn(5000, 300)
+    out = torch.empty(300, device=dev)
+    ops.colsum(X.to(dev), 300, 5000, 300, out)
+    report("colsum 5000x300", rel(out, X.double().sum(0)), 1e-5)
+
+
+@section
+def losses():
+    import golden_util as gu
+    from oracle import losses as ol
+    from oracle.cases import SINGLE_CRITERIA, make_criterion
+    from utils import losses as hl
+    gold = gu.load("losses_edge_s300")
+    y = torch.from_numpy(gold["y"])
+    for cname in SINGLE_CRITERIA:
+        lg = torch.from_numpy(gold["logits"]).clone()
+        p = torch.softmax(lg, 1).unsqueeze(2).to(dev).requires_grad_(True)
+        loss = make_criterion(hl, cname)(p, y.to(dev))
+        loss.backward()
+        ref = float(gold["loss/" + cname])
+        report(f"loss {cname}", abs(loss.item() - ref) / max(1, abs(ref)), 1e-5)
+        scale = np.abs(gold["dp/" + cname]).max()
+        report(f"dloss/dp {cname}", float(np.abs(p.grad.squeeze(2).cpu().numpy() - gold["dp/" + cname]).max() / scale), 1e-4)
+    for metric in ("f1", "dcg"):
+        r = ops.reward_matrix(y.to(dev), N.METRIC_F1 if metric == "f1" else N.METRIC_DCG)
+        report(f"reward matrix {metric}", float(np.abs(r.cpu().numpy() - gold["reward/" + metric]).max()), 2e-5)
+    # odd S
+    for S in (40, 100, 200, 301, 777):
+        yy = (torch.rand(7, S) < 0.2).float()
+        pp = torch.softmax(torch.randn(7, S), 1).unsqueeze(2)
+        for cname in ("div_js_f1_aug1", "div_kl_dcg_aug0", "choopy_dcg"):
+            if "dcg" in cname and S > 300 and False:
+                continue
+            pr = pp.clone().requires_grad_(True)
+            lr = make_criterion(ol, cname)(pr, yy)
+            lr.backward()
+            pg = pp.clone().to(dev).requires_grad_(True)
+            lh = make_criterion(hl, cname)(pg, yy.to(dev))
+            lh.backward()
+            report(f"loss {cname} S={S}", abs(lh.item() - lr.item()) / max(1, abs(lr.item())), 2e-5)
+            report(f"dp   {cname} S={S}", rel(pg.grad, pr.grad), 1e-4)
+    # multi-task
+    for tag, nt in (("t3", 3), ("t21", 2.1), ("t22", 2.2)):
+        for metric in ("f1", "dcg"):
+            lg = torch.from_numpy(gold["logits"]).to(dev)
+            cl = torch.sigmoid(torch.from_numpy(gold["cls_logit"])).unsqueeze(2).to(dev).requires_grad_(True)
+            rr = torch.from_numpy(gold["rerank"]).unsqueeze(2).to(dev).requires_grad_(True)
+            p = torch.softmax(lg, 1).unsqueeze(2).requires_grad_(True)
+            outs = [cl, rr, p] if nt == 3 else ([cl, p] if nt == 2.1 else [rr, p])
+            loss = hl.MtCutLoss(metric=metric, rerank_weight=0.4, classi_weight=0.6, num_tasks=nt)(outs, y.to(dev))
+            loss.backward()
+            key = f"mtcut_{tag}_{metric}"
+            report(f"mtcut loss {key}", abs(loss.item() - float(gold["loss/" + key])), 1e-5)
+            if nt != 2.1:
+                report(f"mtcut drerank {key}", float(np.abs(rr.grad.squeeze(2).cpu().numpy() - gold["drerank/" + key]).max()), 1e-7)
+            if nt != 2.2:
+                c = torch.sigmoid(torch.from_numpy(gold["cls_logit"]))
+                dcl = torch.from_numpy(gold["dcls_logit/" + key]) / (c * (1 - c))     # d/dc from d/dlogit
+                report(f"mtcut dclass {key}", rel(cl.grad.squeeze(2), dcl), 1e-4)
+
+
+@section
+def metrics():
+    import golden_util as gu
+    from utils.metrics import Metric
+    gold = gu.load("losses_edge_s300")
+    report("Metric.f1 golden", abs(Metric.f1(gold["y"], gold["k_s"]) - float(gold["metric_f1"])), 1e-6)
+    report("Metric.dcg golden", abs(Metric.dcg(gold["y"], gold["k_s"]) - float(gold["metric_dcg"])), 1e-9)
+    kx = np.array([[1, 0, 1], [0, 0, 1], [1, 0, 0]], dtype=np.float32)
+    report("Metric.f1 KAT", abs(Metric.f1(kx, np.array([1, 2, 1])) - 0.5555555555555555), 1e-12)
+    report("Metric.dcg KAT", abs(Metric.dcg(kx, np.array([1, 2, 1])) - 0.1230234154761809), 1e-12)
+    p = torch.rand(33, 300)
+    k, f1, dcg, _ = ops.cut_metrics(p.to(dev), torch.from_numpy(gold["y"][:1]).repeat(33, 1).to(dev))
+    report("argmax", float((k.cpu().long() - (p.argmax(1) + 1)).abs().max()), 0)
+
+
+@section
+def layernorm():
+    for (T, E) in [(1500, 256), (333, 128), (70, 64), (10, 512)]:
+        x, r = torch.randn(T, E), torch.randn(T, E)
+        g, b = torch.randn(E), torch.randn(E)
+        dy = torch.randn(T, E)
+        xr, rr, gr, br = [t.clone().double().requires_grad_(True) for t in (x, r, g, b)]
+        yr = F.layer_norm(xr + rr, (E,), gr, br, 1e-5)
+        yr.backward(dy.double())
+        xd, rd, gd, bd = [t.clone().to(dev).requires_grad_(True) for t in (x, r, g, b)]
+        yd = ops.add_layernorm(xd, rd, gd, bd)
+        yd.backward(dy.to(dev))
+        report(f"add_ln fwd {T}x{E}", rel(yd, yr), 5e-6)
+        report(f"add_ln dx  {T}x{E}", rel(xd.grad, xr.grad), 2e-5)
+        report(f"add_ln dr  {T}x{E}", rel(rd.grad, rr.grad), 2e-5)
+        report(f"add_ln dg  {T}x{E}", rel(gd.grad, gr.grad), 2e-5)
+        report(f"add_ln db  {T}x{E}", rel(bd.grad, br.grad), 2e-5)
+
+
+def _pm(x):      # (B,S,E) -> (S*B,E)
+    return x.permute(1, 0, 2).reshape(-1, x.shape[2]).contiguous()
+
+
+def _unpm(x, B, S):
+    return x.reshape(S, B, -1).permute(1, 0, 2).contiguous()
+
+
+@section
+def heads():
+    for (B, S, E, kinds) in [(5, 300, 256, [0]), (7, 100, 128, [1, 2, 0]), (3, 40, 256, [1, 0])]:
+        n = len(kinds)
+        x = torch.randn(B, S, E)
+        w, b = torch.randn(n, E) / 16, torch.randn(n)
+        dout = torch.randn(n, B, S)
+        xr, wr, br = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+        outs = []
+        for i, k in enumerate(kinds):
+            z = xr @ wr[i] + br[i]
+            outs.append(torch.softmax(z, 1) if k == 0 else (torch.sigmoid(z) if k == 1 else z))
+        yr = torch.stack(outs)
+        yr.backward(dout.double())
+        xd = _pm(x).to(dev).requires_grad_(True)
+        wd, bd = w.clone().to(dev).requires_grad_(True), b.clone().to(dev).requires_grad_(True)
+        yd = ops.HeadsFn.apply(xd, wd, bd, kinds, S, B)
+        yd.backward(dout.to(dev))
+        report(f"heads fwd B{B} S{S} E{E} {kinds}", rel(yd, yr), 1e-5)
+        report(f"heads dx  B{B} S{S} E{E} {kinds}", rel(_unpm(xd.grad, B, S), xr.grad), 2e-5)
+        report(f"heads dw  B{B} S{S} E{E} {kinds}", rel(wd.grad, wr.grad), 2e-5)
+        # the bias of a softmax head has an analytically zero gradient: compare absolutely
+        report(f"heads db  B{B} S{S} E{E} {kinds}", float((bd.grad.double().cpu() - br.grad).abs().max()), 2e-5)
+
+
+def _attn_ref(qkv, H):          # qkv (B,S,3E) double; attention over axis 0
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    hd = E // H
+    q, k, v = qkv.split(E, dim=2)
+    sh = lambda t: t.reshape(B, S, H, hd).permute(1, 2, 0, 3)
+    q, k, v = sh(q), sh(k), sh(v)
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    o = torch.softmax(sc, -1) @ v
+    return o.permute(2, 0, 1, 3).reshape(B, S, E)
+
+
+@section
+def attention():
+    for (B, S, H, HD) in [(5, 7, 4, 64), (63, 5, 4, 64), (130, 3, 2, 64), (200, 2, 4, 64), (5, 9, 8, 16), (70, 4, 8, 16),
+                          (33, 3, 2, 32), (300, 2, 4, 64)]:
+        E = H * HD
+        qkv = torch.randn(B, S, 3 * E)
+        dout = torch.randn(B, S, E)
+        qr = qkv.clone().double().requires_grad_(True)
+        orf = _attn_ref(qr, H)
+        orf.backward(dout.double())
+        qd = _pm(qkv).to(dev).requires_grad_(True)
+        od = ops.list_attention(qd, S, B, H)
+        od.backward(_pm(dout).to(dev))
+        report(f"attn fwd  B{B} S{S} H{H} HD{HD}", rel(_unpm(od, B, S), orf), 1e-5)
+        g = _unpm(qd.grad, B, S)
+        report(f"attn dq   B{B} S{S} H{H} HD{HD}", rel(g[..., :E], qr.grad[..., :E]), 3e-5)
+        report(f"attn dk   B{B} S{S} H{H} HD{HD}", rel(g[..., E:2 * E], qr.grad[..., E:2 * E]), 3e-5)
+        report(f"attn dv   B{B} S{S} H{H} HD{HD}", rel(g[..., 2 * E:], qr.grad[..., 2 * E:]), 3e-5)
+    # sharp softmax (large scores) to exercise the online max
+    B, S, H, HD = 150, 2, 1, 64
+    qkv = torch.randn(B, S, 3 * HD) * 4
+    qr = qkv.clone().double()
+    od = ops.list_attention(_pm(qkv).to(dev), S, B, H)
+    report("attn fwd sharp", rel(_unpm(od, B, S), _attn_ref(qr, H)), 2e-5)
+
+
+@section
+def lstm():
+    import models as hm
+    for (B, S, I) in [(5, 12, 3), (40, 30, 3), (70, 9, 256), (33, 300, 3)]:
+        ref = torch.nn.LSTM(I, 128, num_layers=2, batch_first=True, bidirectional=True)
+        x = torch.randn(B, S, I)
+        dh = torch.randn(B, S, 256)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)[0]
+        yr.backward(dh)
+        from models._common import ParamTree, bilstm
+        pt = ParamTree(ref).to(dev)
+        xd = _pm(x).to(dev).requires_grad_(True)
+        yd = bilstm(xd, pt, S, B)
+        yd.backward(_pm(dh).to(dev))
+        report(f"bilstm fwd B{B} S{S} I{I}", rel(_unpm(yd, B, S), yr), 2e-5)
+        report(f"bilstm dx  B{B} S{S} I{I}", rel(_unpm(xd.grad, B, S), xr.grad), 1e-4)
+        for name, prm in ref.named_parameters():
+            report(f"bilstm d{name} B{B} S{S}", rel(getattr(pt, name).grad, prm.grad), 1e-4)
+
+
+@section
+def embed_mmoe():
+    B, S = 6, 40
+    score = torch.randn(B, S, 1)
+    pe = torch.randn(S, 127)
+    dout = torch.randn(B, S, 128)
+    per = pe.clone().requires_grad_(True)
+    outr = torch.cat((score, per.expand(B, S, 127)), 2)
+    outr.backward(dout)
+    ped = pe.clone().to(dev).requires_grad_(True)
+    outd = ops.choopy_embed(score.to(dev), ped)
+    outd.backward(_pm(dout).to(dev))
+    report("choopy_embed fwd", rel(_unpm(outd, B, S), outr), 0)
+    report("choopy_embed dpe", rel(ped.grad, per.grad), 1e-5)
+    # gates + mix
+    for (B, S, C, nt, ne) in [(5, 40, 256, 3, 3), (9, 300, 256, 2, 4)]:
+        h = torch.randn(B, S, C)
+        wg = [torch.randn(S * C, ne) / math.sqrt(S * C) for _ in range(nt)]
+        ex = [torch.randn(B, S, C) for _ in range(ne)]
+        dm = torch.randn(nt, B, S, C)
+        hr = h.clone().double().requires_grad_(True)
+        wr = [w.clone().double().requires_grad_(True) for w in wg]
+        er = [e.clone().double().requires_grad_(True) for e in ex]
+        gr = [torch.softmax(hr.reshape(B, -1) @ w, 1) for w in wr]
+        est = torch.stack(er)
+        mr = torch.stack([(g.t()[:, :, None, None] * est).sum(0) for g in gr])
+        mr.backward(dm.double())
+        hd = _pm(h).to(dev).requires_grad_(True)
+        wd = [w.clone().to(dev).requires_grad_(True) for w in wg]
+        ed = [_pm(e).to(dev).requires_grad_(True) for e in ex]
+        gd = ops.MMOEGateFn.apply(hd, S, B, *wd)
+        md = ops.MMOEMixFn.apply(gd, S, B, *ed)
+        md.backward(torch.stack([_pm(dm[t]) for t in range(nt)]).to(dev))
+        report(f"mmoe gates B{B} nt{nt} ne{ne}", rel(gd, torch.stack(gr)), 2e-5)
+        report(f"mmoe mixed B{B}", rel(torch.stack([_unpm(md[t], B, S) for t in range(nt)]), mr), 2e-5)
+        report(f"mmoe dh    B{B}", rel(_unpm(hd.grad, B, S), hr.grad), 1e-4)
+        for t in range(nt):
+            report(f"mmoe dwg{t} B{B}", rel(wd[t].grad, wr[t].grad), 1e-4)
+        for e in range(ne):
+            report(f"mmoe dex{e} B{B}", rel(_unpm(ed[e].grad, B, S), er[e].grad), 1e-4)
+
+
+@section
+def models():
+    import golden_util as gu
+    import models as hm
+    from oracle.cases import MODEL_CASES, make_criterion
+    from utils import losses as hl
+    from utils.metrics import Metric
+    only = os.environ.get("PROBE_CASES")
+    for case in MODEL_CASES:
+        if only and case["tag"] not in only.split(","):
+            continue
+        try:
+            gold = gu.load(case["tag"])
+            t0 = time.time()
+            model, x, y = gu.build(hm, case, device=dev)
+            model.train()
+            outs = gu.as_list(model(x))
+            for i, o in enumerate(outs):
+                report(f"{case['tag']} out{i}", float(np.abs(o.detach().squeeze(2).cpu().numpy() - gold[f'out{i}']).max()), 1e-5)
+            k, f1, dcg = Metric.evaluate(outs[-1], y)
+            report(f"{case['tag']} k mismatches", float((k.cpu().numpy() != gold["k_s"]).sum()), 0)
+            report(f"{case['tag']} f1", abs(float(f1) - float(gold["f1"])), 1e-4)
+            report(f"{case['tag']} dcg", abs(float(dcg) - float(gold["dcg"])), 1e-4)
+            for cname in case["criteria"]:
+                loss = make_criterion(hl, cname, case)(model(x), y)
+                ref = float(gold["loss/" + cname])
+                report(f"{case['tag']} loss {cname}", abs(loss.item() - ref) / max(1, abs(ref)), 1e-4)
+                if cname == case["grad_crit"]:
+                    model.zero_grad()
+                    loss.backward()
+                    try:
+                        worst = gu.check_grads(model, gold, rtol=1e-3, atol_frac=1e-3)
+                        report(f"{case['tag']} grads", worst, 1e-3)
+                    except AssertionError as exc:
+                        print("   grad mismatch:", str(exc)[:300])
+                        report(f"{case['tag']} grads", float("nan"), 1e-3)
+            print(f"   ({case['tag']} took {time.time() - t0:.1f}s)", flush=True)
+        except Exception:
+            traceback.print_exc()
+            report(f"{case['tag']} EXCEPTION", float("nan"), 0)
+
+
+if __name__ == "__main__":
+    want = sys.argv[1:]
+    secs = [v for v in list(globals().values()) if getattr(v, "_is_section", False)]
+    for fn in secs:
+        if want and fn.__name__ not in want:
+            continue
+        print(f"\n=== {fn.__name__} ===", flush=True)
+        try:
+            fn()
+            torch.cuda.synchronize()
+        except Exception:
+            traceback.print_exc()
+            RESULTS.append((fn.__name__ + " EXCEPTION", float("nan"), 0, False))
+    bad = [r for r in RESULTS if not r[3]]
+    print(f"\n{len(RESULTS) - len(bad)} ok, {len(bad)} failed")
+    for r in bad:
+        print("FAILED:", r[0], r[1])
+    sys.exit(1 if bad else 0)
