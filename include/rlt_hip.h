@@ -156,6 +156,14 @@ size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD);
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream);
+/* the three launches of rlt_list_attention_bwd on their own (same arguments; `delta` (S,H,B) is the
+ * workspace): delta = rowsum(dout*out); dK,dV columns of dqkv; dQ columns of dqkv. */
+int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int B, int H, int HD,
+                                 float* delta, void* stream);
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
+                               int S, int B, int H, int HD, float* dqkv, void* stream);
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
+                              int S, int B, int H, int HD, float* dqkv, void* stream);
 
 /* ------------------------------------------------------------------ BiLSTM recurrence (M2)
  * One bidirectional LSTM layer with hidden size 128 (nn.LSTM(..., hidden_size=128,

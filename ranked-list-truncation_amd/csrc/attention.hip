@@ -446,14 +446,29 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 template <int HD>
-int launch_bwd(const AttnArgs& a, hipStream_t st) {
+int launch_dkv(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
     int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD>, dkv_smem<HD>());
-    if (!rc) rc = rlt_allow_lds(attn_bwd_dq_kernel<HD>, fwd_smem<HD>());
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+    return RLT_LAUNCH_RESULT();
+}
+template <int HD>
+int launch_dq(const AttnArgs& a, hipStream_t st) {
+    const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
+    int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD>, fwd_smem<HD>());
+    if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
     return RLT_LAUNCH_RESULT();
+}
+
+AttnArgs bwd_args(const float* qkv, const float* dout, const float* lse, const float* delta,
+                  int S, int B, int H, int HD, float* dqkv) {
+    AttnArgs a{};
+    a.qkv = qkv; a.dout = dout; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
+    a.S = S; a.B = B; a.H = H;
+    a.scale = 1.0f / sqrtf((float)HD);
+    return a;
 }
 
 }  // namespace
@@ -480,24 +495,49 @@ size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
     return (size_t)S * H * B * sizeof(float);
 }
 
+int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int B, int H, int HD,
+                                 float* delta, void* stream) {
+    RLT_CHECK_ARG(out && dout && delta && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    const size_t T = (size_t)S * B;
+    const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, rlt_stream(stream), out, dout, S, B, H, HD, delta);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
+                               int S, int B, int H, int HD, float* dqkv, void* stream) {
+    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
+    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, dqkv);
+    hipStream_t st = rlt_stream(stream);
+    if (HD == 64) return launch_dkv<64>(a, st);
+    if (HD == 32) return launch_dkv<32>(a, st);
+    return launch_dkv<16>(a, st);
+}
+
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
+                              int S, int B, int H, int HD, float* dqkv, void* stream) {
+    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
+    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, dqkv);
+    hipStream_t st = rlt_stream(stream);
+    if (HD == 64) return launch_dq<64>(a, st);
+    if (HD == 32) return launch_dq<32>(a, st);
+    return launch_dq<16>(a, st);
+}
+
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream) {
-    RLT_CHECK_ARG(qkv && out && dout && lse && dqkv && ws && S > 0 && B > 0 && H > 0);
-    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    RLT_CHECK_ARG(ws);
     if (ws_bytes < rlt_list_attention_bwd_workspace(S, B, H, HD)) return RLT_E_WORKSPACE;
-    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
-    AttnArgs a{};
-    a.qkv = qkv; a.out = out; a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.dqkv = dqkv;
-    a.S = S; a.B = B; a.H = H;
-    a.scale = 1.0f / sqrtf((float)HD);
-    hipStream_t st = rlt_stream(stream);
-    const size_t T = (size_t)S * B;
-    const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
-    if (HD == 64) return launch_bwd<64>(a, st);
-    if (HD == 32) return launch_bwd<32>(a, st);
-    return launch_bwd<16>(a, st);
+    int rc = rlt_list_attention_bwd_delta(out, dout, S, B, H, HD, (float*)ws, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, (const float*)ws, S, B, H, HD, dqkv, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, (const float*)ws, S, B, H, HD, dqkv, stream);
+    return rc;
 }
 
 }  // extern "C"

@@ -43,6 +43,9 @@ _SIGNATURES = {
     "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "rlt_list_attention_bwd_delta": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),

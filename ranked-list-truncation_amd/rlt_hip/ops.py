@@ -17,6 +17,37 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+class KernelTimer:
+    """Optional HIP-event timing of named launches on the current stream (bench.py's live roofline
+    measurement).  Disabled unless `KernelTimer.active` is set to an instance."""
+    active = None
+
+    def __init__(self):
+        self.events = {}
+
+    def reset(self):
+        self.events = {}
+
+    def timed(self, name, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.events.setdefault(name, []).append((a, b))
+
+    def summary(self):
+        """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+def _launch(name, fn):
+    t = KernelTimer.active
+    if t is None:
+        fn()
+    else:
+        t.timed(name, fn)
+
+
 # ------------------------------------------------------------------------------ raw helpers
 def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0):
     """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors."""
@@ -114,7 +145,7 @@ class ListAttentionFn(Function):
         HD = E // H
         out = _empty((S * B, E), qkv)
         lse = _empty((S, H, B), qkv)
-        call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, ptr(out), ptr(lse), stream())
+        _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, ptr(out), ptr(lse), stream()))
         ctx.dims = (S, B, H, HD)
         ctx.save_for_backward(qkv, out, lse)
         return out
@@ -127,8 +158,11 @@ class ListAttentionFn(Function):
         dqkv = torch.empty_like(qkv)
         ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
         ws = workspace(ws_bytes, qkv.device)
-        call("rlt_list_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(dqkv),
-             ptr(ws), ws_bytes, stream())
+        call("rlt_list_attention_bwd_delta", ptr(out), ptr(dout), S, B, H, HD, ptr(ws), stream())
+        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
+                                             S, B, H, HD, ptr(dqkv), stream()))
+        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
+                                            S, B, H, HD, ptr(dqkv), stream()))
         return dqkv, None, None, None
 
 
