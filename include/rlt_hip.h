@@ -114,6 +114,15 @@ int rlt_gemm(int ta, int tb, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, const float* bias2, int flags,
              void* ws, size_t ws_bytes, void* stream);
+/* rlt_gemm plus two fused side products of the backward pass:
+ *   relu_mask (M x N, ldmask) : C = relu_mask > 0 ? C : 0 after the epilogue (dH = (dY W2) * (H > 0))
+ *   colsum_a  (M)             : = sum_k op(A)[m][k]; requires ta = 1.  With A = dY stored [T,N_out] this is
+ *                               the bias gradient, produced by the dW = dY^T X product at no extra HBM pass. */
+int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
+                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* bias2, int flags,
+                const float* relu_mask, int ldmask, float* colsum_a,
+                void* ws, size_t ws_bytes, void* stream);
 /* out[N] (+)= sum over the T rows of X[T,N] (ldx) - bias gradients.  ws: rlt_colsum_workspace bytes. */
 size_t rlt_colsum_workspace(int T, int N);
 int rlt_colsum(const float* X, int ldx, int T, int N, float* out, int accumulate,

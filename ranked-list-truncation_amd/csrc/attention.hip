@@ -20,6 +20,7 @@
 //
 // FLOPs per (s,h): forward 4*B^2*HD; backward 14*B^2*HD (7 products; 5 would need atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int HD, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int LD = HD + 4, DT = (HD + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                         // [2][KT*LD]
@@ -448,9 +449,16 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 template <int HD>
 int launch_dkv(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD>, dkv_smem<HD>());
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+    static const int occ = [] { const char* e = getenv("RLT_DKV_OCC"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    if (occ == 2) {
+        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 2>, dkv_smem<HD>());
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+    } else {
+        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 1>, dkv_smem<HD>());
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+    }
     return RLT_LAUNCH_RESULT();
 }
 template <int HD>

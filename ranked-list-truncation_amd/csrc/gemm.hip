@@ -10,10 +10,11 @@
 // prefetch of the next K tile overlaps the MFMAs of the current one.  blockIdx is remapped so that
 // the tiles an XCD runs are contiguous (they share the A panel in that XCD's L2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+constexpr int BM = 128, BN = 128, LDT = 132;
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -24,19 +25,22 @@ struct GemmArgs {
     int kchunk;          // K range per z-slice (multiple of BK); gridDim.z slices
     float* slab;         // split-K partials [z][M*N] or null
     int tiles_m, tiles_n;
+    const float* mask; int ldmask;   // epilogue: C = mask > 0 ? C : 0   (ReLU backward fused in dX)
+    float* colsum;       // [M]: sum_k op(A)[m][k] (bias gradient from the dW product), TA only; or null
+    float* cs_slab;      // split-K partials of colsum [z][M] or null
 };
 
 // KC = true : operand stored [MN][K] (K contiguous)   -> transposing LDS store
 // KC = false: operand stored [K][MN] (MN contiguous)  -> direct LDS store
-template <bool KC>
+template <bool KC, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend,
-                                          bool vec, int tid, float4 (&reg)[2]) {
+                                          bool vec, int tid, float4 (&reg)[BK / 8]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < BK / 8; ++i) {
         const int idx = tid + 256 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KC) {
-            const int row = mn0 + (idx >> 2), kk = k0 + 4 * (idx & 3);
+            const int row = mn0 + idx / (BK / 4), kk = k0 + 4 * (idx % (BK / 4));
             if (row < MN) {
                 const float* src = P + (size_t)row * ld + kk;
                 if (vec && kk + 3 < Kend) {
@@ -66,13 +70,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const float4 (&reg)[2]) {
+template <bool KC, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const float4 (&reg)[BK / 8]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < BK / 8; ++i) {
         const int idx = tid + 256 * i;
         if (KC) {
-            const int mn = idx >> 2, k = 4 * (idx & 3);
+            const int mn = idx / (BK / 4), k = 4 * (idx % (BK / 4));
             T[(k + 0) * LDT + mn] = reg[i].x;
             T[(k + 1) * LDT + mn] = reg[i].y;
             T[(k + 2) * LDT + mn] = reg[i].z;
@@ -84,10 +88,11 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
     }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+template <bool TA, bool TB, int BK, int OCC, bool PRIO>
+__global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float (*As)[BK * LDT] = reinterpret_cast<float (*)[BK * LDT]>(gsm);                    // [2][BK*LDT]
+    float (*Bs)[BK * LDT] = reinterpret_cast<float (*)[BK * LDT]>(gsm + 2 * BK * LDT);     // [2][BK*LDT]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
@@ -112,23 +117,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2], rb[2];
+    float4 ra[BK / 8], rb[BK / 8];
     // A operand: TA=0 -> stored [M][K] (K contiguous); B operand: TB=1 -> stored [N][K] (K contiguous)
-    load_tile<!TA>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
-    load_tile<TB>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
-    store_tile<!TA>(As[0], tid, ra);
-    store_tile<TB>(Bs[0], tid, rb);
+    load_tile<!TA, BK>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
+    load_tile<TB, BK>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
+    store_tile<!TA, BK>(As[0], tid, ra);
+    store_tile<TB, BK>(Bs[0], tid, rb);
     __syncthreads();
+
+    // bias gradient on the side: this thread's A elements are 4 consecutive m at fixed k rows
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_cs = [&]() {
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+    };
+    if (want_cs) add_cs();
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<!TA>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
-            load_tile<TB>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
+            load_tile<!TA, BK>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
+            load_tile<TB, BK>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
+            if (want_cs) add_cs();
         }
         const float* a_ = As[buf] + wm * 64 + l31;
         const float* b_ = Bs[buf] + wn * 64 + l31;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = (2 * ks + hh) * LDT;
@@ -139,9 +155,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
             acc[1][1] = mfma32(a1, b1, acc[1][1]);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (more) {
-            store_tile<!TA>(As[buf ^ 1], tid, ra);
-            store_tile<TB>(Bs[buf ^ 1], tid, rb);
+            store_tile<!TA, BK>(As[buf ^ 1], tid, ra);
+            store_tile<TB, BK>(Bs[buf ^ 1], tid, rb);
         }
         __syncthreads();
         buf ^= 1;
@@ -172,9 +189,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     v += bv;
                     if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
                     if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
+                    if (g.mask && !(g.mask[(size_t)row * g.ldmask + col] > 0.f)) v = 0.f;
                 }
                 *dst = v;
             }
+        }
+    }
+    if (want_cs) {
+        // 8 threads (tid>>5) hold partial sums of the same 4 columns m = 4*(tid&31)..+3: reduce through LDS
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(gsm);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 t = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 o = red[tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)blockIdx.z * g.M : g.colsum) + m0 + 4 * tid;
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m0 + 4 * tid + j < g.M) dst[j] = tv[j];
         }
     }
 }
@@ -191,14 +226,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int nspl
         float* dst = g.C + (size_t)row * g.ldc + col;
         if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
         if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (g.mask && !(g.mask[(size_t)row * g.ldmask + col] > 0.f)) v = 0.f;
         *dst = v;
     }
+    if (g.cs_slab)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)g.M; i += (size_t)gridDim.x * 256) {
+            float v = 0.f;
+            for (int z = 0; z < nsplit; ++z) v += g.cs_slab[(size_t)z * g.M + i];
+            g.colsum[i] = v;
+        }
+}
+
+template <bool TA, bool TB, int BK, int OCC, bool PRIO>
+int launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    const size_t shm = (size_t)4 * BK * LDT * sizeof(float);
+    int rc = rlt_allow_lds(gemm_kernel<TA, TB, BK, OCC, PRIO>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK, OCC, PRIO>), grid, dim3(256), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+int gemm_variant() {
+    static const int v = [] { const char* e = getenv("RLT_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
+    return v;
+}
+template <bool TA, bool TB, int BK>
+int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    switch (gemm_variant()) {
+        case 1: return launch_gemm_v<TA, TB, BK, 4, false>(g, grid, st);
+        case 2: return launch_gemm_v<TA, TB, BK, 1, true>(g, grid, st);
+        case 3: return launch_gemm_v<TA, TB, BK, 4, true>(g, grid, st);
+        default: return launch_gemm_v<TA, TB, BK, 1, false>(g, grid, st);
+    }
+}
+
+int gemm_bk() {
+    static const int bk = [] { const char* e = getenv("RLT_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+    return bk;
 }
 
 int choose_split(int M, int N, int K) {
     const long long tiles = (long long)rlt_cdiv(M, BM) * rlt_cdiv(N, BN);
     if (tiles >= 256 || K < 4096) return 1;
-    long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
+    static const int target = [] { const char* e = getenv("RLT_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 1024; }();
+    long long want = target / tiles > 0 ? target / tiles : 1;     // workgroups in flight: a whole number of waves of the grid
     const long long maxs = K / 512 > 0 ? K / 512 : 1;        // keep >= 512 of K per slice
     if (want > maxs) want = maxs;
     if (want > 256) want = 256;
@@ -271,16 +341,28 @@ size_t rlt_gemm_workspace(int ta, int tb, int M, int N, int K) {
     (void)ta; (void)tb;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int ns = choose_split(M, N, K);
-    return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+    return ns > 1 ? ((size_t)ns * M * N + (size_t)ns * M) * sizeof(float) : 0;
 }
 
 int rlt_gemm(int ta, int tb, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, const float* bias2, int flags,
              void* ws, size_t ws_bytes, void* stream) {
+    return rlt_gemm_ex(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, nullptr, 0, nullptr,
+                       ws, ws_bytes, stream);
+}
+
+int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
+                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* bias2, int flags,
+                const float* relu_mask, int ldmask, float* colsum_a,
+                void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
     RLT_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N);
+    RLT_CHECK_ARG(!relu_mask || ldmask >= N);
+    RLT_CHECK_ARG(!colsum_a || ta);          // the side column sum needs A stored [K,M]
     GemmArgs g;
+    g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.vecA = (lda % 4 == 0) && rlt_aligned16(A);
@@ -288,19 +370,29 @@ int rlt_gemm(int ta, int tb, int M, int N, int K,
     g.flags = flags;
     g.tiles_m = rlt_cdiv(M, BM); g.tiles_n = rlt_cdiv(N, BN);
     int ns = choose_split(M, N, K);
-    if (ns > 1 && (!ws || ws_bytes < (size_t)ns * M * N * sizeof(float))) {
+    if (ns > 1 && (!ws || ws_bytes < ((size_t)ns * M * N + (size_t)ns * M) * sizeof(float))) {
         if (ws == nullptr && ws_bytes == 0) ns = 1; else return RLT_E_WORKSPACE;
     }
-    int kchunk = rlt_cdiv(rlt_cdiv(K, ns), BK) * BK;
+    int kchunk = rlt_cdiv(rlt_cdiv(K, ns), 32) * 32;
     ns = rlt_cdiv(K, kchunk);
     g.kchunk = kchunk;
     g.slab = ns > 1 ? (float*)ws : nullptr;
+    g.cs_slab = (ns > 1 && colsum_a) ? (float*)ws + (size_t)ns * M * N : nullptr;
     hipStream_t st = rlt_stream(stream);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, ns), block(256);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, ns);
+    int rc = 0;
+    if (gemm_bk() == 32) {
+        if (!ta && tb) rc = launch_gemm<false, true, 32>(g, grid, st);
+        else if (!ta && !tb) rc = launch_gemm<false, false, 32>(g, grid, st);
+        else if (ta && !tb) rc = launch_gemm<true, false, 32>(g, grid, st);
+        else rc = launch_gemm<true, true, 32>(g, grid, st);
+    } else {
+        if (!ta && tb) rc = launch_gemm<false, true, 16>(g, grid, st);
+        else if (!ta && !tb) rc = launch_gemm<false, false, 16>(g, grid, st);
+        else if (ta && !tb) rc = launch_gemm<true, false, 16>(g, grid, st);
+        else rc = launch_gemm<true, true, 16>(g, grid, st);
+    }
+    if (rc) return rc;
     if (ns > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_grid((size_t)M * N)), dim3(256), 0, st, g, ns);
     return RLT_LAUNCH_RESULT();

@@ -76,8 +76,7 @@ def encoder(x_pm, params, n_head, S, B):
         ctx_ = ops.list_attention(qkv, S, B, n_head)
         proj = ops.linear(ctx_, att.out_proj.weight, att.out_proj.bias)
         h1 = ops.add_layernorm(h, proj, layer.norm1.weight, layer.norm1.bias)
-        ff = ops.linear(h1, layer.linear1.weight, layer.linear1.bias, relu=True)
-        ff = ops.linear(ff, layer.linear2.weight, layer.linear2.bias)
+        ff = ops.ffn(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias)
         h = ops.add_layernorm(h1, ff, layer.norm2.weight, layer.norm2.bias)
     return h
 

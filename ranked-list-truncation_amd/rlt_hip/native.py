@@ -32,6 +32,8 @@ _SIGNATURES = {
     "rlt_cut_metrics": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P]),
     "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),
+    "rlt_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int, P,
+                            P, c_size_t, P]),
     "rlt_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rlt_colsum": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rlt_segment_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),

@@ -49,15 +49,17 @@ def _launch(name, fn):
 
 
 # ------------------------------------------------------------------------------ raw helpers
-def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0):
-    """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors."""
+def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0,
+         relu_mask=None, ldmask=0, colsum_a=None):
+    """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors.
+    relu_mask: C = mask > 0 ? C : 0 (fused ReLU backward); colsum_a (M): row sums of op(A) (ta=1 only)."""
     ws_bytes = query("rlt_gemm_workspace", ta, tb, M, Nn, K)
     ws = workspace(ws_bytes, C.device) if ws_bytes else None
     esz = 4
-    call("rlt_gemm", ta, tb, M, Nn, K,
+    call("rlt_gemm_ex", ta, tb, M, Nn, K,
          N.c_void_p(A.data_ptr() + a_off * esz), lda, N.c_void_p(B.data_ptr() + b_off * esz), ldb,
          N.c_void_p(C.data_ptr() + c_off * esz), ldc, ptr(bias), ptr(bias2), flags,
-         ptr(ws), ws_bytes, stream())
+         ptr(relu_mask), ldmask, ptr(colsum_a), ptr(ws), ws_bytes, stream())
 
 
 def colsum(X, ldx, T, Nn, out, accumulate=0, x_off=0):
@@ -95,8 +97,9 @@ class LinearFn(Function):
             gemm(0, 0, T, K, Nn, dy, Nn, w, K, dx, K)
         if ctx.needs_input_grad[1]:
             dw = _empty((Nn, K), x)
-            gemm(1, 0, Nn, K, T, dy, Nn, x, K, dw, K)
-        if ctx.needs_input_grad[2]:
+            db = _empty((Nn,), x) if ctx.needs_input_grad[2] else None
+            gemm(1, 0, Nn, K, T, dy, Nn, x, K, dw, K, colsum_a=db)      # db rides on the dW product
+        elif ctx.needs_input_grad[2]:
             db = _empty((Nn,), x)
             colsum(dy, Nn, T, Nn, db)
         return dx, dw, db, None
@@ -104,6 +107,44 @@ class LinearFn(Function):
 
 def linear(x, w, b, relu=False):
     return LinearFn.apply(x, w, b, relu)
+
+
+class FFNFn(Function):
+    """y = relu(x W1^T + b1) W2^T + b2 (the encoder layer's feed-forward block) as one tape node:
+    backward fuses the ReLU mask into the dH product and the bias gradients into the dW products."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        T, E = x.shape
+        Fh = w1.shape[0]
+        h = _empty((T, Fh), x)
+        gemm(0, 1, T, Fh, E, x, E, w1, E, h, Fh, bias=b1, flags=N.GEMM_RELU)
+        y = _empty((T, w2.shape[0]), x)
+        gemm(0, 1, T, w2.shape[0], Fh, h, Fh, w2, Fh, y, w2.shape[0], bias=b2)
+        ctx.save_for_backward(x, w1, w2, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, h = ctx.saved_tensors
+        T, E = x.shape
+        Fh, Eo = w1.shape[0], w2.shape[0]
+        dy = N.f32c(dy)
+        dw2, db2 = _empty((Eo, Fh), x), _empty((Eo,), x)
+        gemm(1, 0, Eo, Fh, T, dy, Eo, h, Fh, dw2, Fh, colsum_a=db2)
+        dh = _empty((T, Fh), x)
+        gemm(0, 0, T, Fh, Eo, dy, Eo, w2, Fh, dh, Fh, relu_mask=h, ldmask=Fh)      # dH = (dY W2) * (H > 0)
+        dw1, db1 = _empty((Fh, E), x), _empty((Fh,), x)
+        gemm(1, 0, Fh, E, T, dh, Fh, x, E, dw1, E, colsum_a=db1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((T, E), x)
+            gemm(0, 0, T, E, Fh, dh, Fh, w1, E, dx, E)
+        return dx, dw1, db1, dw2, db2
+
+
+def ffn(x, w1, b1, w2, b2):
+    return FFNFn.apply(x, w1, b1, w2, b2)
 
 
 # ------------------------------------------------------------------------------ residual + LayerNorm
@@ -205,12 +246,12 @@ class BiLSTMLayerFn(Function):
         call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w_hh_f), ptr(w_hh_r), ptr(dh), S, B, stream())
         dA = gates
         db = _empty((1024,), x)
-        colsum(dA, 1024, T, 1024, db)
         grads_w = []
         for d, (w_ih, _w_hh) in enumerate(((w_ih_f, w_hh_f), (w_ih_r, w_hh_r))):
             dw_ih = _empty((512, I), x)
-            gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d)
-            dw_hh = torch.zeros((512, 128), dtype=torch.float32, device=x.device)
+            # bias gradient (column sums of dA) rides on the dW_ih product
+            gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d, colsum_a=db[512 * d:512 * (d + 1)])
+            dw_hh = _empty((512, 128), x) if S > 1 else torch.zeros((512, 128), dtype=torch.float32, device=x.device)
             if S > 1:
                 K = T - B
                 if d == 0:   # h_{t-1} of position s is the row block of position s-1

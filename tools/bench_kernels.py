@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark (GPU box): time the MFMA kernels at the BASELINE configs[1] shapes
+(AttnCut, 4096 lists x 300) with HIP events and print TFLOP/s.  Variants are selected with the
+RLT_* environment variables the library reads at launch."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "ranked-list-truncation_amd"))
+
+import torch
+
+from rlt_hip import native as N
+from rlt_hip import ops
+from rlt_hip.native import call, ptr, stream
+
+dev = torch.device("cuda")
+
+
+def timeit(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def attention(B=4096, S=60, H=4, HD=64):
+    E = H * HD
+    T = S * B
+    qkv = torch.randn(T, 3 * E, device=dev)
+    out = torch.empty(T, E, device=dev)
+    lse = torch.empty(S, H, B, device=dev)
+    dout = torch.randn(T, E, device=dev)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(S, H, B, device=dev)
+    unit = B * B * HD * S * H / 1e9     # GFLOP per "2*B*B*HD" product /2
+    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, ptr(out), ptr(lse), stream()))
+    print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * unit / ms:7.1f} TF/s", flush=True)
+    call("rlt_list_attention_bwd_delta", ptr(out), ptr(dout), S, B, H, HD, ptr(delta), stream())
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(delta), S, B, H, HD, ptr(dqkv), stream()))
+    print(f"attn_bwd_dkv  B{B} S{S} HD{HD}: {ms:8.3f} ms  {8 * unit / ms:7.1f} TF/s", flush=True)
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(delta), S, B, H, HD, ptr(dqkv), stream()))
+    print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
+
+
+def gemms(T=4096 * 300):
+    shapes = [("in_proj fwd NT", 0, 1, T, 768, 256), ("ffn1 fwd NT", 0, 1, T, 2048, 256), ("ffn2 fwd NT", 0, 1, T, 256, 2048),
+              ("ffn1 dX NN", 0, 0, T, 256, 2048), ("ffn2 dX NN", 0, 0, T, 2048, 256),
+              ("ffn1 dW TN", 1, 0, 2048, 256, T), ("ffn2 dW TN", 1, 0, 256, 2048, T), ("in_proj dW TN", 1, 0, 768, 256, T),
+              ("lstm dWhh TN", 1, 0, 512, 128, T)]
+    for name, ta, tb, M, Nn, K in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((Nn, K) if tb else (K, Nn), device=dev)
+        C = torch.empty(M, Nn, device=dev)
+        bias = torch.randn(Nn, device=dev)
+        ms = timeit(lambda: ops.gemm(ta, tb, M, Nn, K, A, A.shape[1], Bm, Bm.shape[1], C, Nn, bias=bias))
+        print(f"gemm {name:16s} {M}x{Nn}x{K}: {ms:8.3f} ms  {2.0 * M * Nn * K / ms / 1e9:7.1f} TF/s", flush=True)
+        del A, Bm, C
+
+
+def lstm(B=4096, S=300):
+    T = S * B
+    gates = torch.randn(T, 1024, device=dev) * 0.5
+    w = torch.randn(2, 512, 128, device=dev) / 12
+    h = torch.empty(T, 256, device=dev)
+    c = torch.empty(T, 256, device=dev)
+    dh = torch.randn(T, 256, device=dev)
+    fl = 2.0 * 512 * 128 * T * 2 / 1e9
+    ms = timeit(lambda: call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), stream()), reps=2)
+    print(f"bilstm_fwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
+    ms = timeit(lambda: call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, stream()), reps=2)
+    print(f"bilstm_bwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attention", "gemms", "lstm"]
+    print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
+    for w in which:
+        globals()[w]()

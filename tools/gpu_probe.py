@@ -62,6 +62,16 @@ def gemm():
     C = C0.clone().to(dev)
     ops.gemm(0, 1, 200, 96, 64, A.to(dev), 64, B.to(dev), 64, C, 96, flags=N.GEMM_RELU | N.GEMM_ACCUMULATE)
     report("gemm relu+accumulate", rel(C, torch.relu(A @ B.t() + C0)), 1e-5)
+    # fused side products: ReLU mask on the output, column sums of A^T (bias gradient) with and without split-K
+    for (M, Nn, K) in [(300, 200, 77), (512, 3, 9000), (768, 256, 50000)]:
+        A, B = torch.randn(K, M), torch.randn(K, Nn)
+        mask = torch.randn(M, Nn)
+        C = torch.empty(M, Nn, device=dev)
+        cs = torch.empty(M, device=dev)
+        ops.gemm(1, 0, M, Nn, K, A.to(dev), M, B.to(dev), Nn, C, Nn, relu_mask=mask.to(dev), ldmask=Nn, colsum_a=cs)
+        ref = (A.t().double() @ B.double()) * (mask > 0)
+        report(f"gemm_ex mask {M}x{Nn}x{K}", rel(C, ref), 2e-6 * math.sqrt(K) + 1e-6)
+        report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
     X = torch.randn(5000, 300)
     out = torch.empty(300, device=dev)
     ops.colsum(X.to(dev), 300, 5000, 300, out)
