@@ -115,13 +115,17 @@ int rlt_gemm(int ta, int tb, int M, int N, int K,
              const float* bias, const float* bias2, int flags,
              void* ws, size_t ws_bytes, void* stream);
 /* rlt_gemm plus two fused side products of the backward pass:
- *   relu_mask (M x N, ldmask) : C = relu_mask > 0 ? C : 0 after the epilogue (dH = (dY W2) * (H > 0))
+ *   relu_mask (M x N, ldmask) : C = relu_mask > 0 ? C * mask_scale : 0 after the epilogue
+ *                               (dH = (dY W2) * (H > 0) [/ (1-p) when the forward dropped H])
+ *   drop_p, seed              : dropout on the output after bias/ReLU: keep(seed,row,col) ? C/(1-p) : 0
+ *                               (the FFN hidden dropout of nn.TransformerEncoderLayer), 0 = off
  *   colsum_a  (M)             : = sum_k op(A)[m][k]; requires ta = 1.  With A = dY stored [T,N_out] this is
  *                               the bias gradient, produced by the dW = dY^T X product at no extra HBM pass. */
 int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, const float* bias2, int flags,
-                const float* relu_mask, int ldmask, float* colsum_a,
+                const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
+                float drop_p, uint32_t seed,
                 void* ws, size_t ws_bytes, void* stream);
 /* out[N] (+)= sum over the T rows of X[T,N] (ldx) - bias gradients.  ws: rlt_colsum_workspace bytes. */
 size_t rlt_colsum_workspace(int T, int N);
@@ -140,13 +144,20 @@ int rlt_scale(float* x, const float* scale, size_t n, void* stream);
  * (nn.TransformerEncoderLayer post-norm, models/AttnCut.py:9).  stats: (T,2) mean, rstd.
  * bwd: dz (T,E) = gradient w.r.t. (x + r) (identical for x and r); dgamma/dbeta (E) (+)=.
  * E multiple of 64, E <= 1024.
+ * Dropout (train mode, dropout1/dropout2 of the encoder layer): y = LN(x + drop(r)) with
+ * drop(r) = keep(seed,t,c) ? r/(1-p) : 0; bwd then also writes dr = dz * keep/(1-p) (dr may be NULL
+ * when drop_p == 0: the gradient of r is dz itself).
  */
 int rlt_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
-                          int T, int E, float eps, float* y, float* stats, void* stream);
+                          int T, int E, float eps, float drop_p, uint32_t seed,
+                          float* y, float* stats, void* stream);
 size_t rlt_add_layernorm_bwd_workspace(int T, int E);
 int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, const float* stats,
-                          const float* dy, int T, int E, float* dz, float* dgamma, float* dbeta,
+                          const float* dy, int T, int E, float drop_p, uint32_t seed,
+                          float* dz, float* dr, float* dgamma, float* dbeta,
                           int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* the dropout keep-mask of the kernels above as data (tests): out[r][c] = keep(seed,r,c) ? 1/(1-p) : 0 */
+int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, void* stream);
 
 /* ------------------------------------------------------------------ list-axis attention (M3)
  * Multi-head self-attention where, at every position s and head h, the B lists of the
@@ -156,23 +167,28 @@ int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, co
  *   qkv: (S*B, 3E) position-major, columns [q | k | v], head h = columns h*HD..h*HD+HD of each.
  *   out: (S*B, E) concatenated heads (input of out_proj).  lse: (S,H,B) log-sum-exp of the
  *   scaled scores (saved for backward).  scale = 1/sqrt(HD).
+ *   drop_p, seed: dropout on the attention probabilities (train mode, the `dropout` of
+ *   nn.MultiheadAttention); the mask is a pure function of (seed, s, h, query, key), recomputed in backward.
  * bwd: dqkv (S*B,3E) from dout; ws: rlt_list_attention_bwd_workspace bytes.
  * HD in {16, 32, 64}; E = H*HD.
  */
-int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD,
+int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* stream);
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD);
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                           int S, int B, int H, int HD, float* dqkv,
+                           int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream);
 /* the three launches of rlt_list_attention_bwd on their own (same arguments; `delta` (S,H,B) is the
  * workspace): delta = rowsum(dout*out); dK,dV columns of dqkv; dQ columns of dqkv. */
 int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int B, int H, int HD,
                                  float* delta, void* stream);
 int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
-                               int S, int B, int H, int HD, float* dqkv, void* stream);
+                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream);
 int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
-                              int S, int B, int H, int HD, float* dqkv, void* stream);
+                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream);
+/* keep-mask of the attention-probability dropout as data (tests, small B): out (S,H,B,B) =
+ * keep ? 1/(1-p) : 0 for (position, head, query, key) */
+int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, float* out, void* stream);
 
 /* ------------------------------------------------------------------ BiLSTM recurrence (M2)
  * One bidirectional LSTM layer with hidden size 128 (nn.LSTM(..., hidden_size=128,

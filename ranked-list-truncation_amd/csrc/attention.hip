@@ -34,7 +34,11 @@ struct AttnArgs {
     float* o; float* lse_o; float* dqkv;
     int S, B, H;
     float scale;
+    float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
 };
+
+// per-(position, head) stream of the dropout RNG; keep(pair_seed, query, key)
+__device__ __forceinline__ uint32_t pair_seed(uint32_t seed, int pair) { return rlt_mix32(seed ^ ((uint32_t)pair * 0x9E3779B9U)); }
 
 // flat block id -> (position*head pair, row tile); all row tiles of a pair go to one XCD (they
 // share that pair's K/V in the XCD's L2) when the pair count allows.
@@ -226,6 +230,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (a.drop_p > 0.f) {          // dropout acts on the normalised probabilities: the normaliser keeps all keys
+                const uint32_t ps = pair_seed(a.seed, pair);
+                const float inv_keep = 1.f / (1.f - a.drop_p);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KT + sub * 32 + acc_row(r, hh);
+                        sc[sub][r] = rlt_keep(ps, (uint32_t)q, (uint32_t)key, a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
+                    }
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -341,8 +356,15 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
                     const int ql = sub * 32 + acc_row(r, hh);
                     const bool ok = t * KT + ql < B;
                     const float p = ok ? exp2f(sc[r] - lt_[ql]) : 0.f;
-                    sc[r] = p;                                           // P
-                    dp[r] = p * (dp[r] - et_[ql]);                       // dS
+                    float pd = p, dpr = dp[r];
+                    if (a.drop_p > 0.f) {
+                        const bool keep = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
+                        const float m = keep ? 1.f / (1.f - a.drop_p) : 0.f;
+                        pd = p * m;
+                        dpr *= m;
+                    }
+                    sc[r] = pd;                                          // dropped P (feeds dV)
+                    dp[r] = p * (dpr - et_[ql]);                         // dS
                 }
                 mma_tile_cols<HD>(dt_, sub, l31, hh, sc, dv);            // dV^T[d][key] += dO^T P
                 mma_tile_cols<HD>(qt_, sub, l31, hh, dp, dk);            // dK^T[d][key] += Q^T dS
@@ -420,7 +442,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = t * KT + sub * 32 + acc_row(r, hh);
                     const float p = kidx < B ? exp2f(sc[r] - lse2) : 0.f;
-                    dp[r] = p * (dp[r] - del);                            // dS^T
+                    float dpr = dp[r];
+                    if (a.drop_p > 0.f)
+                        dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
+                    dp[r] = p * (dpr - del);                              // dS^T
                 }
                 mma_tile_cols<HD>(kt_, sub, l31, hh, dp, dq);             // dQ^T[d][q] += K^T dS^T
             }
@@ -471,26 +496,56 @@ int launch_dq(const AttnArgs& a, hipStream_t st) {
 }
 
 AttnArgs bwd_args(const float* qkv, const float* dout, const float* lse, const float* delta,
-                  int S, int B, int H, int HD, float* dqkv) {
+                  int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv) {
     AttnArgs a{};
     a.qkv = qkv; a.dout = dout; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
     a.S = S; a.B = B; a.H = H;
     a.scale = 1.0f / sqrtf((float)HD);
+    a.drop_p = drop_p; a.drop_thr = rlt_drop_threshold(drop_p); a.seed = seed;
     return a;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint32_t seed, size_t rows, int cols, float p, float* out) {
+    const uint32_t thr = rlt_drop_threshold(p);
+    const size_t n = rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = rlt_keep(seed, (uint32_t)(i / cols), (uint32_t)(i % cols), thr) ? 1.f / (1.f - p) : 0.f;
+}
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, int npair, int B, float p, float* out) {
+    const uint32_t thr = rlt_drop_threshold(p);
+    const size_t bb = (size_t)B * B, n = (size_t)npair * bb;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int pair = (int)(i / bb);
+        const size_t rem = i % bb;
+        out[i] = rlt_keep(pair_seed(seed, pair), (uint32_t)(rem / B), (uint32_t)(rem % B), thr) ? 1.f / (1.f - p) : 0.f;
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD,
+int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, void* stream) {
+    RLT_CHECK_ARG(out && rows > 0 && cols > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, rlt_stream(stream), seed, rows, cols, p, out);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, float* out, void* stream) {
+    RLT_CHECK_ARG(out && S > 0 && B > 0 && H > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(1024), dim3(256), 0, rlt_stream(stream), seed, S * H, B, p, out);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* stream) {
-    RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
     if (!(rlt_aligned16(qkv) && rlt_aligned16(out))) return RLT_E_ALIGN;
     AttnArgs a{};
     a.qkv = qkv; a.o = out; a.lse_o = lse; a.S = S; a.B = B; a.H = H;
     a.scale = 1.0f / sqrtf((float)HD);
+    a.drop_p = drop_p; a.drop_thr = rlt_drop_threshold(drop_p); a.seed = seed;
     hipStream_t st = rlt_stream(stream);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
@@ -514,11 +569,11 @@ int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int
 }
 
 int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
-                               int S, int B, int H, int HD, float* dqkv, void* stream) {
-    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0);
+                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
-    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, dqkv);
+    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
     if (HD == 64) return launch_dkv<64>(a, st);
     if (HD == 32) return launch_dkv<32>(a, st);
@@ -526,11 +581,11 @@ int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float*
 }
 
 int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
-                              int S, int B, int H, int HD, float* dqkv, void* stream) {
-    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0);
+                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
-    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, dqkv);
+    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
     if (HD == 64) return launch_dq<64>(a, st);
     if (HD == 32) return launch_dq<32>(a, st);
@@ -538,13 +593,13 @@ int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* 
 }
 
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                           int S, int B, int H, int HD, float* dqkv,
+                           int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(ws);
     if (ws_bytes < rlt_list_attention_bwd_workspace(S, B, H, HD)) return RLT_E_WORKSPACE;
     int rc = rlt_list_attention_bwd_delta(out, dout, S, B, H, HD, (float*)ws, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, (const float*)ws, S, B, H, HD, dqkv, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, (const float*)ws, S, B, H, HD, dqkv, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv, stream);
     return rc;
 }
 

@@ -58,3 +58,22 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 // row of the 32x32 accumulator tile held in register r by a lane of half hh = lane>>5
 __device__ __forceinline__ constexpr int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ---- counter-based dropout RNG -----------------------------------------------------------------
+// keep(seed, a, b) is a pure function of its arguments, so backward recomputes the forward mask
+// instead of storing it.  Two rounds of a 32-bit avalanche mixer ("lowbias32").
+__host__ __device__ __forceinline__ uint32_t rlt_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t rlt_rng(uint32_t seed, uint32_t a, uint32_t b) {
+    return rlt_mix32(seed + rlt_mix32(a + rlt_mix32(b + 0x9E3779B9U)));
+}
+// threshold for "drop": drop iff rng < thr, thr = p * 2^32
+__host__ __device__ __forceinline__ uint32_t rlt_drop_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+__host__ __device__ __forceinline__ bool rlt_keep(uint32_t seed, uint32_t a, uint32_t b, uint32_t thr) {
+    return rlt_rng(seed, a, b) >= thr;
+}

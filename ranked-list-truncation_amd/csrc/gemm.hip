@@ -28,7 +28,18 @@ struct GemmArgs {
     const float* mask; int ldmask;   // epilogue: C = mask > 0 ? C : 0   (ReLU backward fused in dX)
     float* colsum;       // [M]: sum_k op(A)[m][k] (bias gradient from the dW product), TA only; or null
     float* cs_slab;      // split-K partials of colsum [z][M] or null
+    float drop_p; uint32_t drop_thr, seed;   // epilogue dropout on the output (after ReLU), keep -> /(1-p)
+    float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
 };
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float bv, int row, int col, const float* dst) {
+    v += bv;
+    if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
+    if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
+    if (g.mask) v = (g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v * g.mask_scale : 0.f;
+    if (g.drop_p > 0.f) v = rlt_keep(g.seed, (uint32_t)row, (uint32_t)col, g.drop_thr) ? v * (1.f / (1.f - g.drop_p)) : 0.f;
+    return v;
+}
 
 // KC = true : operand stored [MN][K] (K contiguous)   -> transposing LDS store
 // KC = false: operand stored [K][MN] (MN contiguous)  -> direct LDS store
@@ -185,12 +196,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 float* dst = out + (size_t)row * ldo + col;
-                if (!to_slab) {
-                    v += bv;
-                    if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
-                    if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
-                    if (g.mask && !(g.mask[(size_t)row * g.ldmask + col] > 0.f)) v = 0.f;
-                }
+                if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
                 *dst = v;
             }
         }
@@ -221,13 +227,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int nspl
         float v = 0.f;
         for (int z = 0; z < nsplit; ++z) v += g.slab[(size_t)z * mn + i];
         const int row = (int)(i / g.N), col = (int)(i - (size_t)row * g.N);
-        if (g.bias) v += g.bias[col];
-        if (g.bias2) v += g.bias2[col];
+        float bv = 0.f;
+        if (g.bias) bv += g.bias[col];
+        if (g.bias2) bv += g.bias2[col];
         float* dst = g.C + (size_t)row * g.ldc + col;
-        if (g.flags & RLT_GEMM_ACCUMULATE) v += *dst;
-        if (g.flags & RLT_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (g.mask && !(g.mask[(size_t)row * g.ldmask + col] > 0.f)) v = 0.f;
-        *dst = v;
+        *dst = gemm_epilogue(g, v, bv, row, col, dst);
     }
     if (g.cs_slab)
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)g.M; i += (size_t)gridDim.x * 256) {
@@ -348,21 +352,24 @@ int rlt_gemm(int ta, int tb, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, const float* bias2, int flags,
              void* ws, size_t ws_bytes, void* stream) {
-    return rlt_gemm_ex(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, nullptr, 0, nullptr,
-                       ws, ws_bytes, stream);
+    return rlt_gemm_ex(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, nullptr, 0, 1.0f, nullptr,
+                       0.0f, 0u, ws, ws_bytes, stream);
 }
 
 int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, const float* bias2, int flags,
-                const float* relu_mask, int ldmask, float* colsum_a,
+                const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
+                float drop_p, uint32_t seed,
                 void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
     RLT_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N);
     RLT_CHECK_ARG(!relu_mask || ldmask >= N);
     RLT_CHECK_ARG(!colsum_a || ta);          // the side column sum needs A stored [K,M]
     GemmArgs g;
+    RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
+    g.mask_scale = mask_scale; g.drop_p = drop_p; g.drop_thr = rlt_drop_threshold(drop_p); g.seed = seed;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.vecA = (lda % 4 == 0) && rlt_aligned16(A);

@@ -35,7 +35,7 @@ template <int V>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int T, int E, float eps, float* __restrict__ y,
-                                                         float* __restrict__ stats) {
+                                                         float* __restrict__ stats, float drop_p, uint32_t seed) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nch = E / (64 * V);
     float gm[MAXCH][V], bt[MAXCH][V];
@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
     for (int c = 0; c < MAXCH; ++c)
         if (c < nch) { ldv<V>(gamma + c * 64 * V + lane * V, gm[c]); ldv<V>(beta + c * 64 * V + lane * V, bt[c]); }
     const float inv_e = 1.f / (float)E;
+    const bool drop = drop_p > 0.f;
+    const uint32_t thr = rlt_drop_threshold(drop_p);
+    const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
         const size_t row = (size_t)t * E;
         float z[MAXCH][V];
@@ -56,7 +59,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                     float rr[V];
                     ldv<V>(r + row + off, rr);
 #pragma unroll
-                    for (int i = 0; i < V; ++i) z[c][i] += rr[i];
+                    for (int i = 0; i < V; ++i) {
+                        float rv = rr[i];
+                        if (drop) rv = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? rv * keep_scale : 0.f;
+                        z[c][i] += rv;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < V; ++i) s += z[c][i];
@@ -87,7 +94,8 @@ template <int V>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
                                                          const float* __restrict__ dy, int T, int E,
-                                                         float* __restrict__ dz, float* __restrict__ partial) {
+                                                         float* __restrict__ dz, float* __restrict__ partial,
+                                                         float* __restrict__ dr, float drop_p, uint32_t seed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][2E]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nch = E / (64 * V);
@@ -99,6 +107,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         for (int i = 0; i < V; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; }
     }
     const float inv_e = 1.f / (float)E;
+    const bool drop = drop_p > 0.f;
+    const uint32_t thr = rlt_drop_threshold(drop_p);
+    const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
         const size_t row = (size_t)t * E;
         const float mean = stats[2 * (size_t)t], rstd = stats[2 * (size_t)t + 1];
@@ -114,7 +125,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                     float rr[V];
                     ldv<V>(r + row + off, rr);
 #pragma unroll
-                    for (int i = 0; i < V; ++i) z[i] += rr[i];
+                    for (int i = 0; i < V; ++i) {
+                        float rv = rr[i];
+                        if (drop) rv = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? rv * keep_scale : 0.f;
+                        z[i] += rv;
+                    }
                 }
                 ldv<V>(dy + row + off, d);
 #pragma unroll
@@ -135,6 +150,13 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < V; ++i) o[i] = rstd * (gy[c][i] - m1 - xh[c][i] * m2);
                 stv<V>(dz + row + c * 64 * V + lane * V, o);
+                if (dr) {       // gradient of the dropped branch: dz * keep / (1-p)
+                    const int off = c * 64 * V + lane * V;
+#pragma unroll
+                    for (int i = 0; i < V; ++i)
+                        o[i] = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? o[i] * keep_scale : 0.f;
+                    stv<V>(dr + row + off, o);
+                }
             }
     }
     // per-workgroup partial sums of dgamma | dbeta
@@ -172,17 +194,19 @@ int pick_v(int E) { return (E % 256 == 0) ? 4 : ((E % 128 == 0) ? 2 : 1); }
 extern "C" {
 
 int rlt_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
-                          int T, int E, float eps, float* y, float* stats, void* stream) {
+                          int T, int E, float eps, float drop_p, uint32_t seed,
+                          float* y, float* stats, void* stream) {
     RLT_CHECK_ARG(x && gamma && beta && y && T > 0 && E > 0);
+    RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     const int V = pick_v(E);
     RLT_CHECK_SHAPE(E % 64 == 0 && E / (64 * V) <= MAXCH);
     if (!(rlt_aligned16(x) && rlt_aligned16(y) && (!r || rlt_aligned16(r)) && rlt_aligned16(gamma) && rlt_aligned16(beta)))
         return RLT_E_ALIGN;
     hipStream_t st = rlt_stream(stream);
     dim3 grid(ln_grid(T)), block(256);
-    if (V == 4) hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats);
-    else if (V == 2) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats);
-    else hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats);
+    if (V == 4) hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats, drop_p, seed);
+    else if (V == 2) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats, drop_p, seed);
+    else hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, st, x, r, gamma, beta, T, E, eps, y, stats, drop_p, seed);
     return RLT_LAUNCH_RESULT();
 }
 
@@ -192,9 +216,12 @@ size_t rlt_add_layernorm_bwd_workspace(int T, int E) {
 }
 
 int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, const float* stats,
-                          const float* dy, int T, int E, float* dz, float* dgamma, float* dbeta,
+                          const float* dy, int T, int E, float drop_p, uint32_t seed,
+                          float* dz, float* dr, float* dgamma, float* dbeta,
                           int accumulate, void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(x && gamma && stats && dy && dz && dgamma && dbeta && ws && T > 0 && E > 0);
+    RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (r && dr)));
+    if (drop_p == 0.f) dr = nullptr;
     const int V = pick_v(E);
     RLT_CHECK_SHAPE(E % 64 == 0 && E / (64 * V) <= MAXCH);
     if (ws_bytes < rlt_add_layernorm_bwd_workspace(T, E)) return RLT_E_WORKSPACE;
@@ -205,9 +232,9 @@ int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, co
     dim3 grid(nblk), block(256);
     const size_t shm = (size_t)8 * E * sizeof(float);
     float* part = (float*)ws;
-    if (V == 4) hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part);
-    else if (V == 2) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part);
-    else hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part);
+    if (V == 4) hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
+    else if (V == 2) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
+    else hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
     hipLaunchKernelGGL(ln_param_final_kernel, dim3(rlt_cdiv(2 * E, 256)), dim3(256), 0, st, (const float*)part, nblk, E,
                        dgamma, dbeta, accumulate);
     return RLT_LAUNCH_RESULT();

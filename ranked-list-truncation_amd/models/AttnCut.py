@@ -20,9 +20,9 @@ class AttnCut(nn.Module):
 
     def forward(self, x):
         x = C.check_input(x)
-        C.check_dropout(self, self.dropout)
+        drop_p = C.check_dropout(self, self.dropout)
         B, S, _ = x.shape
         h = C.bilstm(ops.to_position_major(x), self.encoding_layer, S, B)
-        h = C.encoder(h, self.attention_layer, self.n_head, S, B)
+        h = C.encoder(h, self.attention_layer, self.n_head, S, B, drop_p)
         head = getattr(self.decison_layer, "0")
         return ops.heads(h, [head.weight], [head.bias], [N.HEAD_SOFTMAX], S, B)[0]

@@ -17,11 +17,11 @@ class Choopy(nn.Module):
 
     def forward(self, x):
         x = C.check_input(x)
-        C.check_dropout(self, self.dropout)
+        drop_p = C.check_dropout(self, self.dropout)
         B, S, _ = x.shape
         if S != self.seq_len:
             raise ValueError(f"Choopy was built for seq_len={self.seq_len}, got {S}")
         h = ops.choopy_embed(x, self.position_encoding)
-        h = C.encoder(h, self.attention_layer, self.n_head, S, B)
+        h = C.encoder(h, self.attention_layer, self.n_head, S, B, drop_p)
         head = getattr(self.decison_layer, "0")
         return ops.heads(h, [head.weight], [head.bias], [N.HEAD_SOFTMAX], S, B)[0]

@@ -71,12 +71,12 @@ class MMOECut(nn.Module):
 
     def forward(self, x):
         x = C.check_input(x)
-        C.check_dropout(self, self.dropout)
+        drop_p = C.check_dropout(self, self.dropout)
         B, S, _ = x.shape
         if S != self.seq_len:
             raise ValueError(f"MMOECut was built for seq_len={self.seq_len}, got {S}")
         h = C.bilstm(ops.to_position_major(x), self.pre_encoding, S, B)                  # (S*B, 256)
-        expert_out = [C.encoder(h, e.attention_layer, self.n_head, S, B) for e in self.experts]
+        expert_out = [C.encoder(h, e.attention_layer, self.n_head, S, B, drop_p) for e in self.experts]
         gates = ops.MMOEGateFn.apply(h, S, B, *self.w_gates)                              # (n_tasks,B,n_e)
         mixed = ops.MMOEMixFn.apply(gates, S, B, *expert_out)                             # (n_tasks,S*B,E)
         outs = []

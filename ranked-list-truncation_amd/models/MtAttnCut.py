@@ -19,8 +19,8 @@ class MtAttnCut(nn.Module):
 
     def forward(self, x):
         x = C.check_input(x)
-        C.check_dropout(self, self.dropout)
+        drop_p = C.check_dropout(self, self.dropout)
         B, S, _ = x.shape
         h = C.bilstm(ops.to_position_major(x), self.pre_encoding, S, B)
-        h = C.encoder(h, self.encoding_layer, self.n_head, S, B)
+        h = C.encoder(h, self.encoding_layer, self.n_head, S, B, drop_p)
         return mt_heads(self, h, S, B)

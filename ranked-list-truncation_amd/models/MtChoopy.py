@@ -20,10 +20,10 @@ class MtChoopy(nn.Module):
 
     def forward(self, x):
         x = C.check_input(x)
-        C.check_dropout(self, self.dropout)
+        drop_p = C.check_dropout(self, self.dropout)
         B, S, _ = x.shape
         if S != self.seq_len:
             raise ValueError(f"MtChoopy was built for seq_len={self.seq_len}, got {S}")
         h = ops.choopy_embed(x, self.position_encoding)
-        h = C.encoder(h, self.encoding_layer, self.n_head, S, B)
+        h = C.encoder(h, self.encoding_layer, self.n_head, S, B, drop_p)
         return mt_heads(self, h, S, B)

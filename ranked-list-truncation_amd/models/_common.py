@@ -55,10 +55,10 @@ def check_input(x, ndim=3):
 
 
 def check_dropout(module, p):
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            "dropout > 0 in train() is not implemented on the HIP path yet; construct the model with "
-            "dropout=0.0 (as the reference's published runs do) or call .eval()")
+    """Effective dropout probability: p in train(), 0 in eval() (nn.Dropout semantics)."""
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout must be in [0, 1), got {p}")
+    return float(p) if module.training else 0.0
 
 
 def bilstm(x_pm, params, S, B):
@@ -67,17 +67,19 @@ def bilstm(x_pm, params, S, B):
     return ops.bilstm_layer(h, params, 1, S, B)
 
 
-def encoder(x_pm, params, n_head, S, B):
-    """Stack of post-norm encoder layers with list-axis attention."""
+def encoder(x_pm, params, n_head, S, B, drop_p=0.0):
+    """Stack of post-norm encoder layers with list-axis attention.  drop_p > 0 applies the four
+    dropouts of nn.TransformerEncoderLayer: attention probabilities, dropout1 (attention branch),
+    the FFN hidden dropout and dropout2 (FFN branch)."""
     h = x_pm
     for layer in params.layers.children():
         att = layer.self_attn
         qkv = ops.linear(h, att.in_proj_weight, att.in_proj_bias)
-        ctx_ = ops.list_attention(qkv, S, B, n_head)
+        ctx_ = ops.list_attention(qkv, S, B, n_head, drop_p)
         proj = ops.linear(ctx_, att.out_proj.weight, att.out_proj.bias)
-        h1 = ops.add_layernorm(h, proj, layer.norm1.weight, layer.norm1.bias)
-        ff = ops.ffn(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias)
-        h = ops.add_layernorm(h1, ff, layer.norm2.weight, layer.norm2.bias)
+        h1 = ops.add_layernorm(h, proj, layer.norm1.weight, layer.norm1.bias, drop_p=drop_p)
+        ff = ops.ffn(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, drop_p)
+        h = ops.add_layernorm(h1, ff, layer.norm2.weight, layer.norm2.bias, drop_p=drop_p)
     return h
 
 

@@ -6,7 +6,7 @@ a raw device pointer.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 import torch
 
@@ -32,22 +32,24 @@ _SIGNATURES = {
     "rlt_cut_metrics": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P]),
     "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),
-    "rlt_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int, P,
-                            P, c_size_t, P]),
+    "rlt_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int, c_float,
+                            P, c_float, c_uint32, P, c_size_t, P]),
+    "rlt_dropout_mask": (c_int, [c_uint32, c_size_t, c_int, c_float, P, P]),
+    "rlt_attention_dropout_mask": (c_int, [c_uint32, c_int, c_int, c_int, c_float, P, P]),
     "rlt_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rlt_colsum": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rlt_segment_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
     "rlt_relu_bwd": (c_int, [P, P, c_size_t, P]),
     "rlt_scale": (c_int, [P, P, c_size_t, P]),
-    "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P]),
+    "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_uint32, P, P, P]),
     "rlt_add_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
-    "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, c_int, P, c_size_t, P]),
-    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_uint32, P, P, P, P, c_int, P, c_size_t, P]),
+    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P]),
     "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, c_size_t, P]),
     "rlt_list_attention_bwd_delta": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
-    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
-    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
+    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -40,6 +40,18 @@ class KernelTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
 
 
+_SEED_COUNTER = [0]
+
+
+def next_seed():
+    """A fresh 32-bit dropout seed: a function of torch's seed and a call counter, so that
+    torch.manual_seed(...) makes a training run reproducible."""
+    _SEED_COUNTER[0] += 1
+    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 29
+    return int((x * 0xBF58476D1CE4E5B9 >> 32) & 0xFFFFFFFF)
+
+
 def _launch(name, fn):
     t = KernelTimer.active
     if t is None:
@@ -50,16 +62,17 @@ def _launch(name, fn):
 
 # ------------------------------------------------------------------------------ raw helpers
 def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0,
-         relu_mask=None, ldmask=0, colsum_a=None):
+         relu_mask=None, ldmask=0, colsum_a=None, mask_scale=1.0, drop_p=0.0, seed=0):
     """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors.
-    relu_mask: C = mask > 0 ? C : 0 (fused ReLU backward); colsum_a (M): row sums of op(A) (ta=1 only)."""
+    relu_mask: C = mask > 0 ? C*mask_scale : 0 (fused ReLU/dropout backward); colsum_a (M): row sums of
+    op(A) (ta=1 only); drop_p/seed: dropout on the output."""
     ws_bytes = query("rlt_gemm_workspace", ta, tb, M, Nn, K)
     ws = workspace(ws_bytes, C.device) if ws_bytes else None
     esz = 4
     call("rlt_gemm_ex", ta, tb, M, Nn, K,
          N.c_void_p(A.data_ptr() + a_off * esz), lda, N.c_void_p(B.data_ptr() + b_off * esz), ldb,
          N.c_void_p(C.data_ptr() + c_off * esz), ldc, ptr(bias), ptr(bias2), flags,
-         ptr(relu_mask), ldmask, ptr(colsum_a), ptr(ws), ws_bytes, stream())
+         ptr(relu_mask), ldmask, mask_scale, ptr(colsum_a), drop_p, seed, ptr(ws), ws_bytes, stream())
 
 
 def colsum(X, ldx, T, Nn, out, accumulate=0, x_off=0):
@@ -114,14 +127,15 @@ class FFNFn(Function):
     backward fuses the ReLU mask into the dH product and the bias gradients into the dW products."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, drop_p=0.0, seed=0):
         T, E = x.shape
         Fh = w1.shape[0]
-        h = _empty((T, Fh), x)
-        gemm(0, 1, T, Fh, E, x, E, w1, E, h, Fh, bias=b1, flags=N.GEMM_RELU)
+        h = _empty((T, Fh), x)          # relu output, already dropped when drop_p > 0
+        gemm(0, 1, T, Fh, E, x, E, w1, E, h, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=seed)
         y = _empty((T, w2.shape[0]), x)
         gemm(0, 1, T, w2.shape[0], Fh, h, Fh, w2, Fh, y, w2.shape[0], bias=b2)
         ctx.save_for_backward(x, w1, w2, h)
+        ctx.drop_p = drop_p
         return y
 
     @staticmethod
@@ -133,29 +147,32 @@ class FFNFn(Function):
         dw2, db2 = _empty((Eo, Fh), x), _empty((Eo,), x)
         gemm(1, 0, Eo, Fh, T, dy, Eo, h, Fh, dw2, Fh, colsum_a=db2)
         dh = _empty((T, Fh), x)
-        gemm(0, 0, T, Fh, Eo, dy, Eo, w2, Fh, dh, Fh, relu_mask=h, ldmask=Fh)      # dH = (dY W2) * (H > 0)
+        # dH = (dY W2) * (H > 0) [/ (1-p)]: a dropped element has H == 0, so one mask covers ReLU and dropout
+        gemm(0, 0, T, Fh, Eo, dy, Eo, w2, Fh, dh, Fh, relu_mask=h, ldmask=Fh, mask_scale=1.0 / (1.0 - ctx.drop_p))
         dw1, db1 = _empty((Fh, E), x), _empty((Fh,), x)
         gemm(1, 0, Fh, E, T, dh, Fh, x, E, dw1, E, colsum_a=db1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty((T, E), x)
             gemm(0, 0, T, E, Fh, dh, Fh, w1, E, dx, E)
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None, None
 
 
-def ffn(x, w1, b1, w2, b2):
-    return FFNFn.apply(x, w1, b1, w2, b2)
+def ffn(x, w1, b1, w2, b2, drop_p=0.0):
+    return FFNFn.apply(x, w1, b1, w2, b2, drop_p, next_seed() if drop_p > 0 else 0)
 
 
 # ------------------------------------------------------------------------------ residual + LayerNorm
 class AddLayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps):
+    def forward(ctx, x, r, gamma, beta, eps, drop_p=0.0, seed=0):
         T, E = x.shape
         y = _empty((T, E), x)
         stats = _empty((T, 2), x)
-        call("rlt_add_layernorm_fwd", ptr(x), ptr(r), ptr(gamma), ptr(beta), T, E, eps, ptr(y), ptr(stats), stream())
+        call("rlt_add_layernorm_fwd", ptr(x), ptr(r), ptr(gamma), ptr(beta), T, E, eps, drop_p, seed,
+             ptr(y), ptr(stats), stream())
         ctx.save_for_backward(x, r, gamma, stats)
+        ctx.drop = (drop_p, seed)
         return y
 
     @staticmethod
@@ -163,17 +180,20 @@ class AddLayerNormFn(Function):
         x, r, gamma, stats = ctx.saved_tensors
         T, E = x.shape
         dy = N.f32c(dy)
+        drop_p, seed = ctx.drop
         dz = _empty((T, E), x)
+        dr = _empty((T, E), x) if drop_p > 0 else None
         dgamma, dbeta = _empty((E,), x), _empty((E,), x)
         ws_bytes = query("rlt_add_layernorm_bwd_workspace", T, E)
         ws = workspace(ws_bytes, x.device)
-        call("rlt_add_layernorm_bwd", ptr(x), ptr(r), ptr(gamma), ptr(stats), ptr(dy), T, E,
-             ptr(dz), ptr(dgamma), ptr(dbeta), 0, ptr(ws), ws_bytes, stream())
-        return dz, dz, dgamma, dbeta, None
+        call("rlt_add_layernorm_bwd", ptr(x), ptr(r), ptr(gamma), ptr(stats), ptr(dy), T, E, drop_p, seed,
+             ptr(dz), ptr(dr), ptr(dgamma), ptr(dbeta), 0, ptr(ws), ws_bytes, stream())
+        return dz, (dz if dr is None else dr), dgamma, dbeta, None, None, None
 
 
-def add_layernorm(x, r, gamma, beta, eps=1e-5):
-    return AddLayerNormFn.apply(x, r, gamma, beta, eps)
+def add_layernorm(x, r, gamma, beta, eps=1e-5, drop_p=0.0):
+    """LayerNorm(x + dropout(r)) * gamma + beta."""
+    return AddLayerNormFn.apply(x, r, gamma, beta, eps, drop_p, next_seed() if drop_p > 0 else 0)
 
 
 # ------------------------------------------------------------------------------ list-axis attention
@@ -181,13 +201,15 @@ class ListAttentionFn(Function):
     """qkv (S*B, 3E) -> concatenated heads (S*B, E); attention over the B lists at each position."""
 
     @staticmethod
-    def forward(ctx, qkv, S, B, H):
+    def forward(ctx, qkv, S, B, H, drop_p=0.0, seed=0):
         E = qkv.shape[1] // 3
         HD = E // H
         out = _empty((S * B, E), qkv)
         lse = _empty((S, H, B), qkv)
-        _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, ptr(out), ptr(lse), stream()))
+        _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, seed,
+                                         ptr(out), ptr(lse), stream()))
         ctx.dims = (S, B, H, HD)
+        ctx.drop = (drop_p, seed)
         ctx.save_for_backward(qkv, out, lse)
         return out
 
@@ -200,15 +222,16 @@ class ListAttentionFn(Function):
         ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
         ws = workspace(ws_bytes, qkv.device)
         call("rlt_list_attention_bwd_delta", ptr(out), ptr(dout), S, B, H, HD, ptr(ws), stream())
+        drop_p, seed = ctx.drop
         _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
-                                             S, B, H, HD, ptr(dqkv), stream()))
+                                             S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
         _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
-                                            S, B, H, HD, ptr(dqkv), stream()))
-        return dqkv, None, None, None
+                                            S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
+        return dqkv, None, None, None, None, None
 
 
-def list_attention(qkv, S, B, H):
-    return ListAttentionFn.apply(qkv, S, B, H)
+def list_attention(qkv, S, B, H, drop_p=0.0):
+    return ListAttentionFn.apply(qkv, S, B, H, drop_p, next_seed() if drop_p > 0 else 0)
 
 
 # ------------------------------------------------------------------------------ BiLSTM layer (H = 128)

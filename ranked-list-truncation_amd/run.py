@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Training loop of the truncation models on the HIP hot path - the mirror of the reference's
+run.py `Trainer` (:26-240) and `main` (:301-369) for the five in-scope models.
+
+Same flow per step (run.py:120-151): zero_grad -> model(X) -> criterion -> backward -> Adam ->
+k = argmax+1 -> F1/DCG; same per-epoch bookkeeping (unweighted means over steps, best / best-5 test F1,
+state_dict checkpoint on best test F1, run.py:153-232) and the same log lines.  What differs:
+  * model / criterion / metrics / optimizer run through librlt_hip.so; inputs are fed by the
+    pinned-memory loader in dataloader/ (the reference's pickle layout);
+  * F1/DCG are evaluated on the device (no (B,S) round trip per step); one host sync per step for
+    the three logged scalars;
+  * launched under torch.distributed.run it is data-parallel: every rank takes its shard of each batch,
+    one RCCL all-reduce of the flat gradient bucket per step (rlt_hip/parallel.py);
+  * not carried over: tensorboard, matplotlib plots, the hyper-parameter random search, and the
+    out-of-scope models (bicut / moecut / mtple).
+"""
+import argparse
+import configparser
+import logging
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+logging.basicConfig(level=logging.INFO)
+
+from dataloader import at_dataloader, cp_dataloader, write_synthetic_robust04  # noqa: E402
+from models import AttnCut, Choopy, MMOECut, MtAttnCut, MtChoopy  # noqa: E402
+from utils import losses  # noqa: E402
+from utils.metrics import Metric  # noqa: E402
+from rlt_hip.parallel import FlatModel, FusedAdam, shard_batch  # noqa: E402
+
+
+class Trainer:
+    def __init__(self, args):
+        self.args = args
+        self.seq_len = 300 if args.retrieve_data == 'robust04' else 40
+        self.model_name = args.model_name
+        self.epochs, self.batch_size = args.epochs, args.batch_size
+        self.model_persist, self.save_path, self.model_path = args.model_persist, args.save_path, args.model_path
+        self.best_test_f1, self.best_test_dcg = -float('inf'), -float('inf')
+        self.f1_record, self.dcg_record = [], []
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if not torch.cuda.is_available():
+            raise RuntimeError("run.py trains on the GPU through librlt_hip.so; there is no CPU fallback")
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.device)
+
+        feat = 3 if args.retrieve_data == 'robust04' else 25
+        name = self.model_name
+        loader = cp_dataloader if name in ('choopy', 'mtchoopy') else at_dataloader
+        self.train_loader, self.test_loader, _ = loader(args.retrieve_data, args.dataset_name, args.batch_size,
+                                                        device=self.device, base=args.dataset_base, seed=args.seed)
+        if name == 'choopy':                                                   # run.py:65-68
+            self.model = Choopy(seq_len=self.seq_len, dropout=args.dropout)
+            self.criterion = losses.ChoopyLoss(metric=args.criterion)
+        elif name == 'attncut':                                                # run.py:69-75
+            self.model = AttnCut(input_size=feat, dropout=args.dropout)
+            self.criterion = losses.DivLoss(metric=args.criterion, div_type=args.div_type,
+                                            augmented=args.augmented_reward)
+        elif name == 'mtchoopy':                                               # run.py:76-79
+            self.model = MtChoopy(seq_len=self.seq_len, num_tasks=args.num_tasks, dropout=args.dropout)
+            self.criterion = losses.MtCutLoss(metric=args.criterion, rerank_weight=args.rerank_weight,
+                                              classi_weight=args.class_weight, num_tasks=args.num_tasks)
+        elif name == 'mtattncut':                                              # run.py:80-84
+            self.model = MtAttnCut(input_size=feat, num_tasks=args.num_tasks, dropout=args.dropout)
+            self.criterion = losses.MtCutLoss(metric=args.criterion, rerank_weight=args.rerank_weight,
+                                              classi_weight=args.class_weight, num_tasks=args.num_tasks)
+        elif name == 'mmoecut':                                                # run.py:85-90 (num_experts exposed)
+            self.model = MMOECut(seq_len=self.seq_len, num_tasks=args.num_tasks, input_size=feat,
+                                 dropout=args.dropout, num_experts=args.num_experts)
+            self.criterion = losses.MtCutLoss(metric=args.criterion, num_tasks=args.num_tasks)
+        else:
+            raise ValueError(f"model {name!r} is outside the HIP hot path (choopy, attncut, mtchoopy, mtattncut, mmoecut)")
+        self.multi_task = name in ('mtchoopy', 'mtattncut', 'mmoecut')        # reference: `'m' in model_name`
+        self.model = self.model.to(self.device)
+        if args.ft and self.model_path and os.path.exists(self.model_path):
+            self.load_model()
+        self.flat = FlatModel(self.model)
+        self.flat.broadcast_params()
+        self.optimizer = FusedAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)   # run.py:104
+
+    # ------------------------------------------------------------------------------------------
+    def _shard(self, X, y):
+        if self.world == 1:
+            return X, y
+        n = (X.shape[0] // self.world) * self.world          # ragged tail lists are dropped per step
+        return shard_batch(X[:n], y[:n], self.rank, self.world)
+
+    def _step(self, X, y, train):
+        X, y = self._shard(X, y)
+        output = self.model(X)
+        loss = self.criterion(output, y)
+        if train:
+            loss.backward()
+            self.flat.all_reduce_grads()
+            self.optimizer.step()
+        cut = output[-1] if self.multi_task else output        # run.py:137-142
+        _k, f1, dcg = Metric.evaluate(cut, y)
+        stats = torch.stack([loss.detach().double(), f1, dcg])
+        if self.world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.AVG)
+        return stats.tolist()                                   # the step's only host sync
+
+    def train_epoch(self, epoch):
+        start = time.time()
+        tot, step = [0.0, 0.0, 0.0], 0
+        logging.info('-' * 100)
+        for X, y in self.train_loader:
+            self.model.train()
+            self.optimizer.zero_grad()
+            vals = self._step(X, y, True)
+            tot = [a + b for a, b in zip(tot, vals)]
+            step += 1
+        loss, f1, dcg = [v / step for v in tot]                 # unweighted over steps, run.py:153
+        if self.rank == 0:
+            logging.info('\nEpoch: {} | Epoch Time: {:.2f} s'.format(epoch, time.time() - start))
+            logging.info('\tTrain: loss = {} | f1 = {:.6f} | dcg = {:.6f}\n'.format(loss, f1, dcg))
+        return loss, f1, dcg
+
+    def test(self, epoch):
+        tot, step = [0.0, 0.0, 0.0], 0
+        for X, y in self.test_loader:
+            self.model.eval()
+            with torch.no_grad():
+                vals = self._step(X, y, False)
+            tot = [a + b for a, b in zip(tot, vals)]
+            step += 1
+        loss, f1, dcg = [v / step for v in tot]                 # run.py:195
+        self.f1_record.append(f1)
+        self.dcg_record.append(dcg)
+        if self.rank == 0:
+            logging.info('\tTest: loss = {} | f1 = {:.6f} | dcg = {:.6f}\n'.format(loss, f1, dcg))
+        if f1 > self.best_test_f1:                              # run.py:203-206
+            self.best_test_f1 = f1
+            if self.model_persist and self.rank == 0:
+                self.save_model()
+        if dcg > self.best_test_dcg:
+            self.best_test_dcg = dcg
+        return loss, f1, dcg
+
+    def save_model(self):
+        os.makedirs(self.save_path, exist_ok=True)
+        # clone: parameters are views of the flat bucket
+        state = {k: v.detach().clone().cpu() for k, v in self.model.state_dict().items()}
+        torch.save(state, os.path.join(self.save_path, '{}.pkl'.format(self.model_name)))
+        logging.info('The best model has beed updated and saved in {}\n'.format(self.save_path))
+
+    def load_model(self):
+        self.model.load_state_dict(torch.load(self.model_path, map_location=self.device))
+        logging.info('The best model has beed loaded from {}\n'.format(self.model_path))
+
+    def run(self):
+        if self.rank == 0:
+            logging.info('\nTrain the {} model: \n'.format(self.model_name))
+        for epoch in range(self.epochs):
+            self.train_epoch(epoch)
+            self.test(epoch)
+        top = sorted(self.f1_record, reverse=True)[:5]
+        topd = sorted(self.dcg_record, reverse=True)[:5]
+        best5_f1, best5_dcg = sum(top) / 5, sum(topd) / 5       # run.py:229-230 divides by 5 regardless
+        if self.rank == 0:
+            logging.info('the best metric of this model: f1: {} | dcg: {}'.format(self.best_test_f1, self.best_test_dcg))
+            logging.info('the best-5 metric of this model: f1: {} | dcg: {}'.format(best5_f1, best5_dcg))
+        return self.best_test_f1, self.best_test_dcg
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Truncation Model Trainer Args (HIP hot path)")
+    p.add_argument('--retrieve-data', type=str, default='robust04')
+    p.add_argument('--dataset-name', type=str, default='drmm_tks')
+    p.add_argument('--batch-size', type=int, default=63)
+    p.add_argument('--model-name', type=str, default='mmoecut')
+    p.add_argument('--augmented-reward', type=int, default=1)
+    p.add_argument('--div-type', type=str, default='js')
+    p.add_argument('--criterion', type=str, default='dcg')
+    p.add_argument('--model-path', type=str, default=None)
+    p.add_argument('--ft', type=int, default=0)
+    p.add_argument('--model-persist', type=int, default=0)
+    p.add_argument('--save-path', type=str, default=os.path.join(HERE, 'best_model'))
+    p.add_argument('--epochs', type=int, default=80)
+    p.add_argument('--lr', type=float, default=3e-5)
+    p.add_argument('--weight-decay', type=float, default=0.005)
+    p.add_argument('--dropout', type=float, default=0.1)
+    p.add_argument('--num-tasks', type=float, default=3)       # 2.1: class + cut | 2.2: rerank + cut
+    p.add_argument('--rerank-weight', type=float, default=0.3)
+    p.add_argument('--class-weight', type=float, default=0.4)
+    # additions
+    p.add_argument('--num-experts', type=int, default=3, help="MMOECut experts (the reference hard-codes 3, run.py:89)")
+    p.add_argument('--dataset-base', type=str, default=None, help="directory holding <retrieve_data>/*.pkl")
+    p.add_argument('--synthetic', type=int, default=0, help="write a robust04-shaped synthetic set into --dataset-base first")
+    p.add_argument('--use-conf', type=int, default=1, help="override lr/batch/dropout/wd/task weights from hyper_parameter_<dataset>.conf")
+    p.add_argument('--seed', type=int, default=None)
+    return p
+
+
+def apply_conf(args):
+    """run.py:338-347: the .conf section of the model overrides the CLI values."""
+    conf = configparser.ConfigParser()
+    path = os.path.join(HERE, 'hyper_parameter_{}.conf'.format(args.dataset_name))
+    if not conf.read(path):
+        return args
+    sec = '{}_conf'.format(args.model_name)
+    if not conf.has_section(sec):
+        return args
+    args.lr = conf.getfloat(sec, 'lr')
+    if args.retrieve_data == 'robust04':
+        args.batch_size = conf.getint(sec, 'batch_size')
+    args.dropout = conf.getfloat(sec, 'dropout')
+    args.weight_decay = conf.getfloat(sec, 'weight_decay')
+    if 'm' in args.model_name:
+        args.rerank_weight = conf.getfloat(sec, 'rerank_weight')
+        args.class_weight = conf.getfloat(sec, 'class_weight')
+    return args
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=dev)
+    if args.use_conf:
+        args = apply_conf(args)
+    if args.model_path is None:
+        args.model_path = os.path.join(args.save_path, '{}.pkl'.format(args.model_name))
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    if args.synthetic:
+        if not args.dataset_base:
+            raise SystemExit("--synthetic needs --dataset-base")
+        if (not dist.is_initialized()) or dist.get_rank() == 0:
+            write_synthetic_robust04(args.dataset_base, args.retrieve_data, args.dataset_name)
+        if dist.is_initialized():
+            dist.barrier()
+    logging.info('{}'.format(vars(args)))
+    trainer = Trainer(args)
+    result = trainer.run()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == '__main__':
+    main()

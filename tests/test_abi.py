@@ -39,7 +39,7 @@ def test_workspace_queries_need_no_gpu(native):
 def test_argument_errors_are_reported_not_crashed(native):
     lib = native.load()
     assert lib.rlt_gemm(0, 1, 0, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, None, None, None) == -1
+    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None) == -1
     assert lib.rlt_heads_fwd(None, None, None, None, 1, 1, 1, 64, None, None) == -1
 
 

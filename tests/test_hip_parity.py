@@ -13,6 +13,10 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     attention   list-axis attention forward/backward vs fp64 (B not multiple of any tile, HD 16/32/64)
     lstm        2-layer BiLSTM forward/backward vs nn.LSTM
     embed_mmoe  Choopy embedding, MMOE gates and mixture forward/backward vs fp64
+    dropout     the four dropout sites of the encoder layer against references built with the kernels'
+                own keep-masks; keep-rate statistics; eval() ignores dropout; reproducible under manual_seed
+    optimizer_and_trainer  FusedAdam vs torch.optim.Adam on the oracle over 3 real steps; run.py Trainer on a
+                synthetic robust04-format set for 4 models, checkpoints load into reference-shaped modules
     models      all 18 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
 Tolerances are written next to each case in tools/gpu_probe.py; BASELINE.json asks for 1e-4.
@@ -39,7 +43,7 @@ def probe():
 
 
 @pytest.mark.parametrize("name", ["gemm", "losses", "metrics", "layernorm", "heads", "attention", "lstm",
-                                  "embed_mmoe", "models"])
+                                  "embed_mmoe", "dropout", "optimizer_and_trainer", "models"])
 def test_section(probe, name):
     import torch
     probe.RESULTS.clear()

@@ -302,6 +302,154 @@ def embed_mmoe():
 
 
 @section
+def optimizer_and_trainer():
+    """FusedAdam == torch.optim.Adam (coupled L2) after real training steps; run.py Trainer end to end."""
+    import tempfile
+    import models as hm
+    from oracle import losses as olosses, models as omodels
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from utils import losses as hl
+    from rlt_hip.parallel import FlatModel, FusedAdam
+    x, y = synthetic_lists(6, 300, 3, 11)
+    ref = omodels.AttnCut(dropout=0.0)
+    fill_state_dict(ref, 21)
+    hip = hm.AttnCut(dropout=0.0)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    flat = FlatModel(hip)
+    opt_h = FusedAdam(flat, lr=1e-3, weight_decay=0.01)
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=0.01)
+    crit_r = olosses.DivLoss(metric='f1', div_type='js')
+    crit_h = hl.DivLoss(metric='f1', div_type='js')
+    for _ in range(3):
+        opt_r.zero_grad()
+        crit_r(ref(x), y).backward()
+        opt_r.step()
+        opt_h.zero_grad()
+        crit_h(hip(x.to(dev)), y.to(dev)).backward()
+        opt_h.step()
+    worst = 0.0
+    for (n, a), (_, b) in zip(hip.named_parameters(), ref.named_parameters()):
+        worst = max(worst, float((a.detach().cpu() - b.detach()).abs().max()))
+    report("3 Adam steps: max |param diff| vs torch.optim.Adam on the oracle", worst, 2e-5)
+    # Trainer on a synthetic robust04-format set
+    import run as hip_run
+    with tempfile.TemporaryDirectory() as tmp:
+        from dataloader import write_synthetic_robust04
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=24, n_test=8, seq_len=300, seed=5)
+        for name, extra in (("attncut", []), ("mmoecut", ["--num-tasks", "2.1", "--num-experts", "4"]),
+                            ("choopy", []), ("mtattncut", [])):
+            argv = ["--model-name", name, "--dataset-base", tmp, "--epochs", "2", "--use-conf", "0", "--batch-size", "8",
+                    "--criterion", "f1", "--dropout", "0.1", "--lr", "1e-3", "--weight-decay", "0", "--seed", "3",
+                    "--model-persist", "1", "--save-path", os.path.join(tmp, "ckpt")] + extra
+            f1, dcg = hip_run.main(argv)
+            report(f"Trainer {name}: best test F1 in [0,1]", 0.0 if 0.0 <= f1 <= 1.0 and math.isfinite(dcg) else 1.0, 0)
+            sd = torch.load(os.path.join(tmp, "ckpt", f"{name}.pkl"))
+            kw = {"attncut": {}, "mmoecut": {"num_tasks": 2.1, "num_experts": 4}, "choopy": {}, "mtattncut": {}}[name]
+            om = {"attncut": omodels.AttnCut, "mmoecut": omodels.MMOECut, "choopy": omodels.Choopy,
+                  "mtattncut": omodels.MtAttnCut}[name](**kw)
+            om.load_state_dict(sd)       # checkpoint loads into the reference-shaped module
+            report(f"Trainer {name}: checkpoint loads into the oracle module", 0.0, 0)
+
+
+@section
+def dropout():
+    """Dropout sites against torch references that use the SAME keep-masks (exported by the library)."""
+    p, seed = 0.3, 12345
+    # mask statistics
+    m = torch.empty(4096, 256, device=dev)
+    N.call("rlt_dropout_mask", seed, 4096, 256, p, N.ptr(m), N.stream())
+    keep = float((m > 0).float().mean())
+    report("dropout keep fraction", abs(keep - (1 - p)), 5e-3)
+    report("dropout mask mean", abs(float(m.mean()) - 1.0), 1e-2)
+    m2 = torch.empty_like(m)
+    N.call("rlt_dropout_mask", seed + 1, 4096, 256, p, N.ptr(m2), N.stream())
+    report("dropout masks decorrelated", abs(float(((m > 0) & (m2 > 0)).float().mean()) - (1 - p) ** 2), 5e-3)
+    # residual + LayerNorm with dropout on the branch
+    T, E = 700, 256
+    x, r, g, b, dy = torch.randn(T, E), torch.randn(T, E), torch.randn(E), torch.randn(E), torch.randn(T, E)
+    mk = torch.empty(T, E, device=dev)
+    N.call("rlt_dropout_mask", seed, T, E, p, N.ptr(mk), N.stream())
+    mkc = mk.cpu().double()
+    xr, rr, gr, br = [t.clone().double().requires_grad_(True) for t in (x, r, g, b)]
+    yr = F.layer_norm(xr + rr * mkc, (E,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    xd, rd, gd, bd = [t.clone().to(dev).requires_grad_(True) for t in (x, r, g, b)]
+    yd = ops.AddLayerNormFn.apply(xd, rd, gd, bd, 1e-5, p, seed)
+    yd.backward(dy.to(dev))
+    report("drop add_ln fwd", rel(yd, yr), 5e-6)
+    report("drop add_ln dx", rel(xd.grad, xr.grad), 2e-5)
+    report("drop add_ln dr", rel(rd.grad, rr.grad), 2e-5)
+    report("drop add_ln dgamma", rel(gd.grad, gr.grad), 2e-5)
+    # FFN with hidden dropout
+    T, E, Fh = 300, 128, 512
+    x = torch.randn(T, E)
+    w1, b1, w2, b2 = torch.randn(Fh, E) / 11, torch.randn(Fh) / 10, torch.randn(E, Fh) / 22, torch.randn(E) / 10
+    dy = torch.randn(T, E)
+    mk = torch.empty(T, Fh, device=dev)
+    N.call("rlt_dropout_mask", seed, T, Fh, p, N.ptr(mk), N.stream())
+    mkc = mk.cpu().double()
+    refs = [t.clone().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yr = (torch.relu(refs[0] @ refs[1].t() + refs[2]) * mkc) @ refs[3].t() + refs[4]
+    yr.backward(dy.double())
+    devs = [t.clone().to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yd = ops.FFNFn.apply(*devs, p, seed)
+    yd.backward(dy.to(dev))
+    report("drop ffn fwd", rel(yd, yr), 1e-5)
+    for nm, a, bref in zip(("dx", "dw1", "db1", "dw2", "db2"), devs, refs):
+        report(f"drop ffn {nm}", rel(a.grad, bref.grad), 3e-5)
+    # attention-probability dropout
+    for (B, S, H, HD) in [(70, 3, 2, 64), (40, 2, 4, 16)]:
+        E = H * HD
+        qkv = torch.randn(B, S, 3 * E)
+        dout = torch.randn(B, S, E)
+        mk = torch.empty(S, H, B, B, device=dev)
+        N.call("rlt_attention_dropout_mask", seed, S, B, H, p, N.ptr(mk), N.stream())
+        mkc = mk.cpu().double()
+        qr = qkv.clone().double().requires_grad_(True)
+        q, k, v = qr.split(E, dim=2)
+        sh = lambda t: t.reshape(B, S, H, HD).permute(1, 2, 0, 3)
+        sc = (sh(q) @ sh(k).transpose(-1, -2)) / math.sqrt(HD)
+        orf = ((torch.softmax(sc, -1) * mkc) @ sh(v)).permute(2, 0, 1, 3).reshape(B, S, E)
+        orf.backward(dout.double())
+        qd = _pm(qkv).to(dev).requires_grad_(True)
+        od = ops.ListAttentionFn.apply(qd, S, B, H, p, seed)
+        od.backward(_pm(dout).to(dev))
+        report(f"drop attn fwd B{B} HD{HD}", rel(_unpm(od, B, S), orf), 1e-5)
+        report(f"drop attn dqkv B{B} HD{HD}", rel(_unpm(qd.grad, B, S), qr.grad), 3e-5)
+    # model level: train() with dropout runs, stays a distribution, differs from eval(); eval() == dropout 0
+    import models as hm
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from utils import losses as hl
+    xm, ym = synthetic_lists(6, 300, 3, 5)
+    a = hm.AttnCut(dropout=0.2)
+    fill_state_dict(a, 3)
+    a = a.to(dev)
+    torch.manual_seed(0)
+    a.train()
+    pt = a(xm.to(dev))
+    loss = hl.DivLoss(metric='f1', div_type='js')(pt, ym.to(dev))
+    loss.backward()
+    report("drop model rows sum to 1", float((pt.squeeze(2).sum(1) - 1).abs().max()), 1e-5)
+    report("drop model grads finite", 0.0 if all(torch.isfinite(q.grad).all() for q in a.parameters()) else 1.0, 0)
+    a.eval()
+    pe = a(xm.to(dev))
+    b0 = hm.AttnCut(dropout=0.0)
+    fill_state_dict(b0, 3)
+    b0 = b0.to(dev)
+    report("eval() ignores dropout", float((pe - b0(xm.to(dev))).abs().max()), 0)
+    report("train() dropout changes output", 0.0 if float((pe - pt).abs().max()) > 1e-7 else 1.0, 0)
+    torch.manual_seed(0)
+    ops._SEED_COUNTER[0] = 0
+    a.train()
+    p1 = a(xm.to(dev))
+    torch.manual_seed(0)
+    ops._SEED_COUNTER[0] = 0
+    p2 = a(xm.to(dev))
+    report("dropout reproducible under manual_seed", float((p1 - p2).abs().max()), 0)
+
+
+@section
 def models():
     import golden_util as gu
     import models as hm

@@ -194,10 +194,39 @@ def loss_cases():
     print("losses_edge_s300: kat_f1=%.16f kat_dcg=%.16f" % (rec["kat_f1"], rec["kat_dcg"]), flush=True)
 
 
+def data_case():
+    """Run the reference's OWN loaders (dataloader/attncut_dataloader.py, choopy_dataloader.py) on a small
+    synthetic robust04-format pickle set written by our generator; store the tensors they produce."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "ranked-list-truncation_amd"))
+    from dataloader.synth import write_synthetic_robust04
+    sys.path.remove(os.path.join(REPO, "ranked-list-truncation_amd"))
+    for mod in [m for m in sys.modules if m == "dataloader" or m.startswith("dataloader.")]:
+        del sys.modules[mod]
+    sys.path.insert(0, REF)
+    import dataloader.attncut_dataloader as ref_at
+    import dataloader.choopy_dataloader as ref_cp
+    sys.path.remove(REF)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=7, n_test=3, seq_len=300, seed=77)
+        ref_at.DATASET_BASE = tmp
+        ref_cp.DATASET_BASE = tmp
+        a = ref_at.Rank_Dataset("robust04", "drmm_tks")
+        c = ref_cp.Rank_Dataset("robust04", "drmm_tks")
+        rec = {"at_X_train": a.getX_train().numpy(), "at_X_test": a.getX_test().numpy(),
+               "at_y_train": a.gety_train().numpy(), "at_y_test": a.gety_test().numpy(),
+               "cp_X_train": c.getX_train().numpy(), "cp_X_test": c.getX_test().numpy(),
+               "cp_y_train": c.gety_train().numpy(), "cp_y_test": c.gety_test().numpy()}
+    np.savez_compressed(os.path.join(OUT, "dataloader_synth77.npz"), **rec)
+    print("dataloader_synth77:", {k: v.shape for k, v in rec.items()}, flush=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else "all"
     if only in ("all", "losses"):
         loss_cases()
+    if only in ("all", "data"):
+        data_case()
     if only in ("all", "models"):
         model_cases(set(sys.argv[2:]) or None)
