@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 
 
 def synth_batch(batch, seq_len, n_feat, seed, device):
@@ -88,6 +89,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=300)
     ap.add_argument("--model", default="attncut", choices=["attncut", "choopy", "mtattncut", "mmoecut"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32"],
+                    help="MFMA product mode of the library (default: the library default, bf16x3)")
     ap.add_argument("--cpu-sample-batch", type=int, default=128)
     args = ap.parse_args()
 
@@ -107,8 +110,11 @@ def main():
     import models as hip_models
     from utils import losses as hip_losses
     from utils.metrics import Metric
-    from rlt_hip import ops
+    from rlt_hip import native, ops
     from rlt_hip.parallel import FlatModel, FusedAdam
+    if args.precision:
+        native.set_precision(args.precision)
+    precision = native.get_precision()
 
     torch.manual_seed(1234)
     S, B = args.seq_len, args.batch
@@ -176,23 +182,33 @@ def main():
 
     if rank == 0:
         ksum = timer.summary()
-        # dominant kernel: attention dK/dV backward; algorithmic FLOPs per launch = 4 MFMA products
-        # of 2*B*B*HD each per (position, head) = 8*B^2*HD*S*H  (DESIGN.md "roofline accounting")
+        # dominant launch: the attention dK/dV backward (one rlt_list_attention_bwd_dkv call).
+        #   fp32 mode  : one kernel, 4 MFMA products of 2*B*B*HD per (position, head) on the f32 MFMA
+        #   bf16x3 mode: two kernels (dV: S,dV; dK: S,dP,dK) = 5 products, each executed as 3 bf16 MFMA products
+        # `achieved` = MFMA FLOPs the launch executes / its HIP-event time; `algorithmic` = the fp32-level FLOPs
+        # (products x 2*B*B*HD*S*H) / time.  DESIGN.md section 5 "roofline accounting".
         name = "attn_bwd_dkv"
-        flops = 8.0 * B * B * hd * S * heads_
         launches, ms = ksum.get(name, (0, float("nan")))
-        achieved = flops / (ms * 1e-3) / 1e12 if launches else float("nan")
+        unit_flops = 2.0 * B * B * hd * S * heads_
+        if precision == "fp32":
+            kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2>" % hd, 4, 1, PEAK_F32_MFMA_TFLOPS
+        else:
+            kern, products, mult, peak = "attn3_bwd_dv_kernel<%d> + attn3_bwd_dk_kernel<%d>" % (hd, hd), 5, 3, PEAK_BF16_MFMA_TFLOPS
+        algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
+        achieved = algorithmic * mult
         out = {
             "metric": "ranked-lists/sec (fwd+bwd) at len=300; F1@k vs CPU ref",
             "value": round(value, 2), "unit": "lists/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "f32 (bf16x3 split MFMA products, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S} (BASELINE configs[1]), "
                                    f"full train step incl. Adam and cut metrics", "global_batch": B * world,
                        "seq_len": S, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel<%d>" % hd,
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kern,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "algorithmic_tflops": round(algorithmic, 2), "mfma_products_per_fp32_product": mult,
                          "launch_ms": round(ms, 3), "launches_timed": launches,
                          "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name}},
             "train_state": {"loss": round(float(loss.detach()), 6), "f1": round(float(f1), 6), "dcg": round(float(dcg), 6)},

@@ -37,6 +37,16 @@ extern "C" {
 
 #define RLT_ABI_VERSION 1
 int rlt_abi_version(void);
+/* Precision of the MFMA contractions (rlt_gemm*, rlt_list_attention_*); inputs, outputs, softmax, LayerNorm,
+ * LSTM and accumulators are fp32 in both modes.
+ *   RLT_PRECISION_FP32   exact fp32 products on the f32 MFMA (157 TFLOP/s peak) - bit-for-bit fp32 fma chains
+ *   RLT_PRECISION_BF16X3 every operand split into bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi on the bf16
+ *                        MFMA with fp32 accumulation (~2^-16 relative error per product, ~2x faster end to end)
+ * Default: BF16X3; the environment variable RLT_PRECISION=fp32|bf16x3 selects it at first use. */
+#define RLT_PRECISION_FP32   0
+#define RLT_PRECISION_BF16X3 1
+int rlt_set_precision(int mode);
+int rlt_get_precision(void);
 /* human-readable name of an RLT_E_* / hipError_t code (static storage) */
 const char* rlt_error_string(int code);
 

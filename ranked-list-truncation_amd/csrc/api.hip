@@ -1,7 +1,27 @@
 // ABI bookkeeping for librlt_hip.so.
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+// precision mode of the MFMA contractions: 0 = exact fp32 MFMA, 1 = split-bf16 (3 bf16 products, fp32 accumulate)
+static int g_precision = -1;
+int rlt_precision() {
+    if (g_precision < 0) {
+        const char* e = getenv("RLT_PRECISION");
+        g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+    }
+    return g_precision;
+}
+
 extern "C" {
+
+int rlt_set_precision(int mode) {
+    if (mode != RLT_PRECISION_FP32 && mode != RLT_PRECISION_BF16X3) return RLT_E_ARG;
+    g_precision = mode;
+    return 0;
+}
+int rlt_get_precision(void) { return rlt_precision(); }
 
 int rlt_abi_version(void) { return RLT_ABI_VERSION; }
 

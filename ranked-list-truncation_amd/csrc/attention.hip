@@ -19,39 +19,11 @@
 // so every gradient element is written exactly once: deterministic, no float atomics.
 //
 // FLOPs per (s,h): forward 4*B^2*HD; backward 14*B^2*HD (7 products; 5 would need atomics).
-#include "common.h"
+#include "attention_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
-
-constexpr int KT = 64;      // rows per LDS tile
-constexpr int QT = 128;     // rows owned by a workgroup (4 wavefronts x 32)
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-
-struct AttnArgs {
-    const float* qkv; const float* out; const float* dout; const float* lse; const float* delta;
-    float* o; float* lse_o; float* dqkv;
-    int S, B, H;
-    float scale;
-    float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
-};
-
-// per-(position, head) stream of the dropout RNG; keep(pair_seed, query, key)
-__device__ __forceinline__ uint32_t pair_seed(uint32_t seed, int pair) { return rlt_mix32(seed ^ ((uint32_t)pair * 0x9E3779B9U)); }
-
-// flat block id -> (position*head pair, row tile); all row tiles of a pair go to one XCD (they
-// share that pair's K/V in the XCD's L2) when the pair count allows.
-__device__ __forceinline__ void map_block(int bid, int npair, int ntile, int& pair, int& tile) {
-    if ((npair & 7) == 0) {
-        const int xcd = bid & 7, j = bid >> 3;
-        pair = (j / ntile) * 8 + xcd;
-        tile = j % ntile;
-    } else {
-        pair = bid / ntile;
-        tile = bid % ntile;
-    }
-}
 
 // stage a [KT][HD] tile (row stride ld floats in global, HD+4 in LDS) through registers
 template <int HD>
@@ -61,15 +33,16 @@ template <int HD>
 __device__ __forceinline__ void tile_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid,
                                           TileRegs<HD>& r) {
     constexpr int PER_ROW = HD / 4, N4 = KT * PER_ROW, NI = (N4 + 255) / 256;
+    static_assert(N4 % 256 == 0, "tile must be a whole number of 256-thread passes");
+    // branch-free: clamp the row into the matrix, load unconditionally, zero out-of-range rows with a
+    // select (a guarded load makes hipcc branch around it and drain vmcnt, serialising the burst)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int idx = tid + 256 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < N4) {
-            const int row = idx / PER_ROW, c4 = idx % PER_ROW;
-            if (row0 + row < nrows) v = *reinterpret_cast<const float4*>(base + (size_t)(row0 + row) * ld + 4 * c4);
-        }
-        r.v[i] = v;
+        const int row = row0 + idx / PER_ROW, c4 = idx % PER_ROW;
+        const bool ok = row < nrows;
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * ld + 4 * c4);
+        r.v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
 }
 template <int HD>
@@ -78,10 +51,8 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, int tid, con
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < N4) {
-            const int row = idx / PER_ROW, c4 = idx % PER_ROW;
-            *reinterpret_cast<float4*>(lds + row * LD + 4 * c4) = r.v[i];
-        }
+        const int row = idx / PER_ROW, c4 = idx % PER_ROW;
+        *reinterpret_cast<float4*>(lds + row * LD + 4 * c4) = r.v[i];
     }
 }
 
@@ -132,25 +103,6 @@ __device__ __forceinline__ void mma_tile_cols(const float* __restrict__ tile, in
             acc[dt] = mfma32(a, w[r], acc[dt]);
         }
     }
-}
-
-// store D^T accumulators (row = d, col = lane's row index) to global rows: dst + row*ld + d
-template <int HD>
-__device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh, const f32x16 (&acc)[(HD + 31) / 32],
-                                            float mul) {
-    constexpr int DT = (HD + 31) / 32;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = dt * 32 + 8 * g + 4 * hh;
-            if (d0 < HD) {
-                float4 v;
-                v.x = acc[dt][4 * g + 0] * mul; v.y = acc[dt][4 * g + 1] * mul;
-                v.z = acc[dt][4 * g + 2] * mul; v.w = acc[dt][4 * g + 3] * mul;
-                *reinterpret_cast<float4*>(dst_row + d0) = v;
-            }
-        }
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -319,9 +271,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int nt = rlt_cdiv_dev(B, KT);
     auto load_small = [&](int row0) {
         if (tid < KT) {
-            const int qi = row0 + tid;
-            rl = qi < B ? lsebase[qi] * LOG2E : 0.f;
-            re = qi < B ? delbase[qi] : 0.f;
+            const int qi = row0 + tid, qc = min(qi, B - 1);
+            const float l = lsebase[qc], e = delbase[qc];
+            rl = qi < B ? l * LOG2E : 0.f;
+            re = qi < B ? e : 0.f;
         }
     };
     tile_load<HD>(base, ld, 0, B, tid, rq);
@@ -523,6 +476,16 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, i
 
 }  // namespace
 
+// 0 = exact fp32 MFMA kernels (parity mode), 1 = split-bf16 kernels of attention3.hip
+static int attn_mode() {
+    static const int forced = [] {
+        const char* e = getenv("RLT_ATTN_MODE");
+        if (!e) return -1;
+        return (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : 0;
+    }();
+    return forced >= 0 ? forced : rlt_precision();
+}
+
 extern "C" {
 
 int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, void* stream) {
@@ -547,6 +510,7 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
     a.scale = 1.0f / sqrtf((float)HD);
     a.drop_p = drop_p; a.drop_thr = rlt_drop_threshold(drop_p); a.seed = seed;
     hipStream_t st = rlt_stream(stream);
+    if (attn_mode() == 1) return rlt_attn3_fwd(a, HD, st);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
     return launch_fwd<16>(a, st);
@@ -575,6 +539,7 @@ int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float*
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
     const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
+    if (attn_mode() == 1) return rlt_attn3_bwd_dkv(a, HD, st);
     if (HD == 64) return launch_dkv<64>(a, st);
     if (HD == 32) return launch_dkv<32>(a, st);
     return launch_dkv<16>(a, st);
@@ -587,6 +552,7 @@ int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* 
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
     const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
+    if (attn_mode() == 1) return rlt_attn3_bwd_dq(a, HD, st);
     if (HD == 64) return launch_dq<64>(a, st);
     if (HD == 32) return launch_dq<32>(a, st);
     return launch_dq<16>(a, st);

@@ -1,0 +1,62 @@
+// Shared between the exact-fp32 (attention.hip) and split-bf16 (attention3.hip) list-axis attention kernels.
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+    const float* qkv; const float* out; const float* dout; const float* lse; const float* delta;
+    float* o; float* lse_o; float* dqkv;
+    int S, B, H;
+    float scale;
+    float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
+};
+
+namespace {
+
+constexpr int KT = 64;      // rows per LDS tile
+constexpr int QT = 128;     // rows owned by a workgroup (4 wavefronts x 32)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+
+// per-(position, head) stream of the dropout RNG; keep(pair_seed, query, key)
+__device__ __forceinline__ uint32_t pair_seed(uint32_t seed, int pair) { return rlt_mix32(seed ^ ((uint32_t)pair * 0x9E3779B9U)); }
+
+// flat block id -> (position*head pair, row tile); all row tiles of a pair go to one XCD (they
+// share that pair's K/V in the XCD's L2) when the pair count allows.
+__device__ __forceinline__ void map_block(int bid, int npair, int ntile, int& pair, int& tile) {
+    if ((npair & 7) == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        pair = (j / ntile) * 8 + xcd;
+        tile = j % ntile;
+    } else {
+        pair = bid / ntile;
+        tile = bid % ntile;
+    }
+}
+
+// store D^T accumulators (row = d, col = lane's row index) to global rows: dst + row*ld + d
+template <int HD>
+__device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh, const f32x16 (&acc)[(HD + 31) / 32],
+                                            float mul) {
+    constexpr int DT = (HD + 31) / 32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * hh;
+            if (d0 < HD) {
+                float4 v;
+                v.x = acc[dt][4 * g + 0] * mul; v.y = acc[dt][4 * g + 1] * mul;
+                v.z = acc[dt][4 * g + 2] * mul; v.w = acc[dt][4 * g + 3] * mul;
+                *reinterpret_cast<float4*>(dst_row + d0) = v;
+            }
+        }
+}
+
+
+}  // namespace
+
+// split-bf16 ("bf16x3") launchers, defined in attention3.hip
+int rlt_attn3_fwd(const AttnArgs& a, int HD, hipStream_t st);
+int rlt_attn3_bwd_dkv(const AttnArgs& a, int HD, hipStream_t st);
+int rlt_attn3_bwd_dq(const AttnArgs& a, int HD, hipStream_t st);

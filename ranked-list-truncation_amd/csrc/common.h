@@ -24,6 +24,8 @@ static inline int rlt_allow_lds(K kernel, size_t bytes) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+int rlt_precision();     // api.hip: RLT_PRECISION_FP32 / RLT_PRECISION_BF16X3 (env RLT_PRECISION, rlt_set_precision)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -11,6 +11,7 @@
 // the tiles an XCD runs are contiguous (they share the A panel in that XCD's L2).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct GemmArgs {
     float* cs_slab;      // split-K partials of colsum [z][M] or null
     float drop_p; uint32_t drop_thr, seed;   // epilogue dropout on the output (after ReLU), keep -> /(1-p)
     float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
+    int nt_store;        // write C with non-temporal stores (streamed output: keep the operands in L2)
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float bv, int row, int col, const float* dst) {
@@ -43,14 +45,25 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float
 
 // KC = true : operand stored [MN][K] (K contiguous)   -> transposing LDS store
 // KC = false: operand stored [K][MN] (MN contiguous)  -> direct LDS store
-template <bool KC, int BK>
+// FAST (host-checked: 16-byte aligned operand, K % 4 == 0, and MN % 4 == 0 for an MN-contiguous operand):
+// branch-free - the address is clamped into the matrix, the load is unconditional and out-of-range
+// lanes are zeroed with a select.  Guarded loads make hipcc branch around every load and drain vmcnt
+// per element, which serialises the whole staging burst.
+template <bool KC, int BK, bool FAST>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend,
                                           bool vec, int tid, float4 (&reg)[BK / 8]) {
 #pragma unroll
     for (int i = 0; i < BK / 8; ++i) {
         const int idx = tid + 256 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KC) {
+        if (FAST) {
+            int r, c;          // r: row of the stored matrix, c: first of 4 contiguous columns
+            bool ok;
+            if (KC) { r = mn0 + idx / (BK / 4); c = k0 + 4 * (idx % (BK / 4)); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
+            else { r = k0 + (idx >> 5); c = mn0 + 4 * (idx & 31); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
+            const float4 t = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
+            v.x = ok ? t.x : 0.f; v.y = ok ? t.y : 0.f; v.z = ok ? t.z : 0.f; v.w = ok ? t.w : 0.f;
+        } else if (KC) {
             const int row = mn0 + idx / (BK / 4), kk = k0 + 4 * (idx % (BK / 4));
             if (row < MN) {
                 const float* src = P + (size_t)row * ld + kk;
@@ -99,7 +112,55 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
     }
 }
 
-template <bool TA, bool TB, int BK, int OCC, bool PRIO>
+// ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
+__device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0,
+                                             int wm, int wn, int l31, int hh) {
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        float bv = 0.f;
+        if (!to_slab) {
+            if (g.bias) bv += g.bias[col];
+            if (g.bias2) bv += g.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, hh);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                float* dst = out + (size_t)row * ldo + col;
+                if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
+                if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
+            }
+        }
+    }
+}
+
+// 8 threads (tid>>5) hold partial sums of the same 4 columns m = 4*(tid&31)..+3: reduce through LDS
+__device__ __forceinline__ void finish_colsum(const GemmArgs& g, float4 csum, float* lds, int tid, int m0) {
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 32) {
+        float4 t = red[tid];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { const float4 o = red[tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        float* dst = (g.cs_slab ? g.cs_slab + (size_t)blockIdx.z * g.M : g.colsum) + m0 + 4 * tid;
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + 4 * tid + j < g.M) dst[j] = tv[j];
+    }
+}
+
+template <bool TA, bool TB, int BK, int OCC, bool FAST>
 __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float (*As)[BK * LDT] = reinterpret_cast<float (*)[BK * LDT]>(gsm);                    // [2][BK*LDT]
@@ -130,8 +191,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
 
     float4 ra[BK / 8], rb[BK / 8];
     // A operand: TA=0 -> stored [M][K] (K contiguous); B operand: TB=1 -> stored [N][K] (K contiguous)
-    load_tile<!TA, BK>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
-    load_tile<TB, BK>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
+    load_tile<!TA, BK, FAST>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
+    load_tile<TB, BK, FAST>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
     store_tile<!TA, BK>(As[0], tid, ra);
     store_tile<TB, BK>(Bs[0], tid, rb);
     __syncthreads();
@@ -149,13 +210,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<!TA, BK>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
-            load_tile<TB, BK>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
+            load_tile<!TA, BK, FAST>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
+            load_tile<TB, BK, FAST>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
             if (want_cs) add_cs();
         }
         const float* a_ = As[buf] + wm * 64 + l31;
         const float* b_ = Bs[buf] + wn * 64 + l31;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = (2 * ks + hh) * LDT;
@@ -166,7 +226,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
             acc[1][1] = mfma32(a1, b1, acc[1][1]);
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (more) {
             store_tile<!TA, BK>(As[buf ^ 1], tid, ra);
             store_tile<TB, BK>(Bs[buf ^ 1], tid, rb);
@@ -175,49 +234,216 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
         buf ^= 1;
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------------
-    const bool to_slab = g.slab != nullptr;
-    float* out = to_slab ? g.slab + (size_t)blockIdx.z * g.M * g.N : g.C;
-    const int ldo = to_slab ? g.N : g.ldc;
+    write_output(g, acc, m0, n0, wm, wn, l31, hh);
+    if (want_cs) finish_colsum(g, csum, gsm, tid, m0);
+}
+
+// ======================================================================================================
+// Split-bf16 variant ("bf16x3"): every fp32 operand x is split on the fly into hi = bf16(x) and
+// lo = bf16(x - hi); a product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, 16x the rate of the f32 MFMA) with fp32 accumulation.  16 mantissa bits
+// per operand: relative error ~2^-16 per product (the dropped lo*lo term and the split residual),
+// about 5x the throughput of the exact-fp32 kernel above at the same interface.
+//
+// Both operands sit in LDS k-contiguous ([mn][k], rows of 32 bf16 + 8 pad = 80 B) so that a lane's MFMA
+// fragment (8 consecutive k of one row) is ONE ds_read_b128; K-contiguous global operands are split and
+// stored with ds_write_b64, MN-contiguous ones through a 4x4 register transpose.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK3 = 32, LDK3 = 40;                       // bf16 elements per LDS row
+constexpr int TILE3 = 128 * LDK3;                        // one hi or lo tile (elements)
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    v2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+    hi.x = pack_bf16x2(a, b);
+    hi.y = pack_bf16x2(c, d);
+    const float ah = __builtin_bit_cast(float, hi.x << 16), bh = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+    const float ch = __builtin_bit_cast(float, hi.y << 16), dh = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+    lo.x = pack_bf16x2(a - ah, b - bh);
+    lo.y = pack_bf16x2(c - ch, d - dh);
+}
+
+// registers of one staged operand tile: 4 float4 per thread
+struct Stage3 { float4 v[4]; };
+
+template <bool KC, bool FAST>
+__device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend, bool vec,
+                                      int tid, Stage3& st) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= g.N) continue;
-        float bv = 0.f;
-        if (!to_slab) {
-            if (g.bias) bv += g.bias[col];
-            if (g.bias2) bv += g.bias2[col];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, hh);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r];
-                float* dst = out + (size_t)row * ldo + col;
-                if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
-                *dst = v;
+    for (int i = 0; i < 4; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FAST) {     // branch-free: clamp, load, select (see load_tile)
+            int r, c;
+            bool ok;
+            if (KC) { const int idx = tid + 256 * i; r = mn0 + (idx >> 3); c = k0 + 4 * (idx & 7); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
+            else { r = k0 + 4 * (tid >> 5) + i; c = mn0 + 4 * (tid & 31); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
+            const float4 t = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
+            v.x = ok ? t.x : 0.f; v.y = ok ? t.y : 0.f; v.z = ok ? t.z : 0.f; v.w = ok ? t.w : 0.f;
+        } else if (KC) {       // [MN][K]: idx -> (row, 4 consecutive k)
+            const int idx = tid + 256 * i;
+            const int row = mn0 + (idx >> 3), kk = k0 + 4 * (idx & 7);
+            if (row < MN) {
+                const float* src = P + (size_t)row * ld + kk;
+                if (vec && kk + 3 < Kend) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (kk + 0 < Kend) v.x = src[0];
+                    if (kk + 1 < Kend) v.y = src[1];
+                    if (kk + 2 < Kend) v.z = src[2];
+                    if (kk + 3 < Kend) v.w = src[3];
+                }
+            }
+        } else {        // [K][MN]: thread owns a 4(k) x 4(mn) block, i = k row within the block
+            const int kk = k0 + 4 * (tid >> 5) + i, col = mn0 + 4 * (tid & 31);
+            if (kk < Kend) {
+                const float* src = P + (size_t)kk * ld + col;
+                if (vec && col + 3 < MN) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (col + 0 < MN) v.x = src[0];
+                    if (col + 1 < MN) v.y = src[1];
+                    if (col + 2 < MN) v.z = src[2];
+                    if (col + 3 < MN) v.w = src[3];
+                }
             }
         }
+        st.v[i] = v;
     }
-    if (want_cs) {
-        // 8 threads (tid>>5) hold partial sums of the same 4 columns m = 4*(tid&31)..+3: reduce through LDS
-        __syncthreads();
-        float4* red = reinterpret_cast<float4*>(gsm);
-        red[tid] = csum;
-        __syncthreads();
-        if (tid < 32) {
-            float4 t = red[tid];
+}
+
+template <bool KC>
+__device__ __forceinline__ void store3(uint16_t* __restrict__ Thi, uint16_t* __restrict__ Tlo, int tid, const Stage3& st) {
+    if (KC) {
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { const float4 o = red[tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-            float* dst = (g.cs_slab ? g.cs_slab + (size_t)blockIdx.z * g.M : g.colsum) + m0 + 4 * tid;
-            const float tv[4] = {t.x, t.y, t.z, t.w};
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int mn = idx >> 3, k = 4 * (idx & 7);
+            uint2 hi, lo;
+            split4(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, hi, lo);
+            *reinterpret_cast<uint2*>(Thi + mn * LDK3 + k) = hi;
+            *reinterpret_cast<uint2*>(Tlo + mn * LDK3 + k) = lo;
+        }
+    } else {
+        const int k = 4 * (tid >> 5), mn = 4 * (tid & 31);
+        const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
+        const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
+        const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
+        const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m0 + 4 * tid + j < g.M) dst[j] = tv[j];
+        for (int c = 0; c < 4; ++c) {
+            uint2 hi, lo;
+            split4(f0[c], f1[c], f2[c], f3[c], hi, lo);
+            *reinterpret_cast<uint2*>(Thi + (mn + c) * LDK3 + k) = hi;
+            *reinterpret_cast<uint2*>(Tlo + (mn + c) * LDK3 + k) = lo;
         }
     }
+}
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);        // [buf][A_hi | A_lo | B_hi | B_lo][TILE3]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // two register stages: while tile t is multiplied out of LDS, tile t+1 sits in registers and tile t+2 is
+    // in flight, i.e. two K tiles of global loads are outstanding per thread (the kernel is bound by
+    // bytes-in-flight x latency, not by the MFMA pipe)
+    Stage3 a0, b0, a1, b1;
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int t, Stage3& sa, Stage3& sb) {
+        const int k0 = kbeg + t * BK3;
+        load3<!TA, FAST>(g.A, g.lda, m0, k0, g.M, kend, g.vecA, tid, sa);
+        load3<TB, FAST>(g.B, g.ldb, n0, k0, g.N, kend, g.vecB, tid, sb);
+        if (want_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+        }
+    };
+    auto stash = [&](int buf, const Stage3& sa, const Stage3& sb) {
+        uint16_t* nb = lds + buf * 4 * TILE3;
+        store3<!TA>(nb + 0 * TILE3, nb + 1 * TILE3, tid, sa);
+        store3<TB>(nb + 2 * TILE3, nb + 3 * TILE3, tid, sb);
+    };
+    auto multiply = [&](int buf) {
+        const uint16_t* base = lds + buf * 4 * TILE3;
+        const uint16_t* pa = base + (wm * 64 + l31) * LDK3 + 8 * hh;
+        const uint16_t* pb = base + 2 * TILE3 + (wn * 64 + l31) * LDK3 + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * LDK3 + ks * 16);
+                al[i] = *reinterpret_cast<const bf16x8*>(pa + TILE3 + i * 32 * LDK3 + ks * 16);
+                bh[i] = *reinterpret_cast<const bf16x8*>(pb + i * 32 * LDK3 + ks * 16);
+                bl[i] = *reinterpret_cast<const bf16x8*>(pb + TILE3 + i * 32 * LDK3 + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    const int nt = (kend - kbeg + BK3 - 1) / BK3;
+    fetch(0, a0, b0);
+    stash(0, a0, b0);
+    if (nt > 1) fetch(1, a0, b0);
+    if (nt > 2) fetch(2, a1, b1);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        multiply(0);                                   // tile t;   regs0 = tile t+1, regs1 = tile t+2 (in flight)
+        if (t + 1 < nt) stash(1, a0, b0);
+        if (t + 3 < nt) fetch(t + 3, a0, b0);
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        multiply(1);                                   // tile t+1; regs1 = tile t+2, regs0 = tile t+3 (in flight)
+        if (t + 2 < nt) stash(0, a1, b1);
+        if (t + 4 < nt) fetch(t + 4, a1, b1);
+        __syncthreads();
+    }
+    write_output(g, acc, m0, n0, wm, wn, l31, hh);
+    if (want_cs) finish_colsum(g, csum, gsm, tid, m0);
+}
+
+template <bool TA, bool TB, bool FAST>
+int launch_gemm3_v(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    const size_t shm = (size_t)2 * 4 * TILE3 * sizeof(uint16_t);
+    int rc = rlt_allow_lds(gemm3_kernel<TA, TB, FAST>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm3_kernel<TA, TB, FAST>), grid, dim3(256), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+bool gemm_fast_ok(const GemmArgs& g, bool ta, bool tb);
+template <bool TA, bool TB>
+int launch_gemm3(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    if (gemm_fast_ok(g, TA, TB)) return launch_gemm3_v<TA, TB, true>(g, grid, st);
+    return launch_gemm3_v<TA, TB, false>(g, grid, st);
 }
 
 // C = sum_z slab[z] (+bias, relu, accumulate); fixed order => deterministic
@@ -241,26 +467,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int nspl
         }
 }
 
-template <bool TA, bool TB, int BK, int OCC, bool PRIO>
+template <bool TA, bool TB, int BK, int OCC, bool FAST>
 int launch_gemm_v(const GemmArgs& g, dim3 grid, hipStream_t st) {
     const size_t shm = (size_t)4 * BK * LDT * sizeof(float);
-    int rc = rlt_allow_lds(gemm_kernel<TA, TB, BK, OCC, PRIO>, shm);
+    int rc = rlt_allow_lds(gemm_kernel<TA, TB, BK, OCC, FAST>, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK, OCC, PRIO>), grid, dim3(256), shm, st, g);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK, OCC, FAST>), grid, dim3(256), shm, st, g);
     return RLT_LAUNCH_RESULT();
 }
-int gemm_variant() {
-    static const int v = [] { const char* e = getenv("RLT_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
-    return v;
+// the branch-free loaders need: aligned operands, K % 4 == 0, K-chunks >= 4, MN % 4 == 0 for MN-contiguous operands
+bool gemm_fast_ok(const GemmArgs& g, bool ta, bool tb) {
+    static const int off = [] { const char* e = getenv("RLT_GEMM_NOFAST"); return e ? atoi(e) : 0; }();
+    if (off) return false;
+    if (!g.vecA || !g.vecB || (g.K & 3) || g.K < 4) return false;
+    if (ta && ((g.M & 3) || g.M < 4)) return false;       // A stored [K][M]
+    if (!tb && ((g.N & 3) || g.N < 4)) return false;      // B stored [K][N]
+    return true;
 }
 template <bool TA, bool TB, int BK>
 int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
-    switch (gemm_variant()) {
-        case 1: return launch_gemm_v<TA, TB, BK, 4, false>(g, grid, st);
-        case 2: return launch_gemm_v<TA, TB, BK, 1, true>(g, grid, st);
-        case 3: return launch_gemm_v<TA, TB, BK, 4, true>(g, grid, st);
-        default: return launch_gemm_v<TA, TB, BK, 1, false>(g, grid, st);
-    }
+    if (gemm_fast_ok(g, TA, TB)) return launch_gemm_v<TA, TB, BK, 4, true>(g, grid, st);
+    return launch_gemm_v<TA, TB, BK, 4, false>(g, grid, st);
+}
+
+// 0 = exact fp32 MFMA (parity mode), 1 = split-bf16 (bf16x3); RLT_GEMM_MODE overrides the library-wide mode
+int gemm_mode() {
+    static const int forced = [] {
+        const char* e = getenv("RLT_GEMM_MODE");
+        if (!e) return -1;
+        return (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : 0;
+    }();
+    return forced >= 0 ? forced : rlt_precision();
 }
 
 int gemm_bk() {
@@ -369,6 +606,8 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
+    static const int nt = [] { const char* e = getenv("RLT_GEMM_NT"); return e ? atoi(e) : 0; }();
+    g.nt_store = nt;
     g.mask_scale = mask_scale; g.drop_p = drop_p; g.drop_thr = rlt_drop_threshold(drop_p); g.seed = seed;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -388,11 +627,11 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     hipStream_t st = rlt_stream(stream);
     dim3 grid(g.tiles_m * g.tiles_n, 1, ns);
     int rc = 0;
-    if (gemm_bk() == 32) {
-        if (!ta && tb) rc = launch_gemm<false, true, 32>(g, grid, st);
-        else if (!ta && !tb) rc = launch_gemm<false, false, 32>(g, grid, st);
-        else if (ta && !tb) rc = launch_gemm<true, false, 32>(g, grid, st);
-        else rc = launch_gemm<true, true, 32>(g, grid, st);
+    if (gemm_mode() == 1) {
+        if (!ta && tb) rc = launch_gemm3<false, true>(g, grid, st);
+        else if (!ta && !tb) rc = launch_gemm3<false, false>(g, grid, st);
+        else if (ta && !tb) rc = launch_gemm3<true, false>(g, grid, st);
+        else rc = launch_gemm3<true, true>(g, grid, st);
     } else {
         if (!ta && tb) rc = launch_gemm<false, true, 16>(g, grid, st);
         else if (!ta && !tb) rc = launch_gemm<false, false, 16>(g, grid, st);

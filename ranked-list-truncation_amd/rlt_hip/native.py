@@ -18,11 +18,14 @@ METRIC_F1, METRIC_DCG = 0, 1
 LOSS_EXPECT, LOSS_CE, LOSS_KL, LOSS_JS = 0, 1, 2, 3
 GEMM_RELU, GEMM_ACCUMULATE = 1, 2
 HEAD_SOFTMAX, HEAD_SIGMOID, HEAD_IDENTITY = 0, 1, 2
+PRECISION_FP32, PRECISION_BF16X3 = 0, 1
 
 P = c_void_p
 _SIGNATURES = {
     "rlt_abi_version": (c_int, []),
     "rlt_error_string": (c_char_p, [c_int]),
+    "rlt_set_precision": (c_int, [c_int]),
+    "rlt_get_precision": (c_int, []),
     "rlt_reward_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
     "rlt_reward_matrix": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
     "rlt_mt_terms_workspace": (c_size_t, [c_int, c_int]),
@@ -88,6 +91,16 @@ def load():
         raise RuntimeError("librlt_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def set_precision(mode):
+    """'fp32' (exact fp32 MFMA products) or 'bf16x3' (split-bf16 products, the default)."""
+    code = {"fp32": PRECISION_FP32, "bf16x3": PRECISION_BF16X3}.get(mode, mode)
+    check(load().rlt_set_precision(int(code)), "rlt_set_precision")
+
+
+def get_precision():
+    return "fp32" if load().rlt_get_precision() == PRECISION_FP32 else "bf16x3"
 
 
 def ptr(t):

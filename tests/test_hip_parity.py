@@ -42,9 +42,11 @@ def probe():
     return mod
 
 
-@pytest.mark.parametrize("name", ["gemm", "losses", "metrics", "layernorm", "heads", "attention", "lstm",
-                                  "embed_mmoe", "dropout", "optimizer_and_trainer", "models"])
-def test_section(probe, name):
+MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models"]
+MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
+
+
+def _run(probe, name):
     import torch
     probe.RESULTS.clear()
     getattr(probe, name)()
@@ -52,6 +54,25 @@ def test_section(probe, name):
     assert probe.RESULTS, "section produced no checks"
     bad = [(n, e, t) for (n, e, t, ok) in probe.RESULTS if not ok]
     assert not bad, f"{len(bad)} of {len(probe.RESULTS)} checks out of tolerance: {bad[:8]}"
+
+
+@pytest.mark.parametrize("name", MODE_FREE)
+def test_section(probe, name):
+    _run(probe, name)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", MODE_DEPENDENT)
+def test_section_by_precision(probe, name, precision):
+    """Both MFMA precision modes of the library: the default split-bf16 mode and the exact-fp32 mode.
+    Model-level tolerances are identical in both; op-level MFMA tolerances are 6x looser for bf16x3
+    (tools/gpu_probe.py: mfma_tol)."""
+    from rlt_hip import native
+    native.set_precision(precision)
+    try:
+        _run(probe, name)
+    finally:
+        native.set_precision("bf16x3")
 
 
 def test_full_size_properties(probe):

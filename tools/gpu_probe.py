@@ -25,6 +25,12 @@ torch.manual_seed(0)
 RESULTS = []
 
 
+def mfma_tol(tol):
+    """Op-level tolerance of an MFMA contraction: as written for the exact-fp32 mode; the split-bf16 mode carries
+    ~2^-16 relative error per product, so its op-level bound is 6x looser (model-level bounds are not scaled)."""
+    return tol * (6.0 if N.get_precision() == "bf16x3" else 1.0)
+
+
 def report(name, err, tol):
     ok = err <= tol and not math.isnan(err)
     RESULTS.append((name, err, tol, ok))
@@ -55,13 +61,13 @@ def gemm():
         C = torch.empty(M, Nn, device=dev)
         Ad, Bd, bd = A.to(dev), B.to(dev), bias.to(dev)
         ops.gemm(ta, tb, M, Nn, K, Ad, A.shape[1], Bd, B.shape[1], C, Nn, bias=bd)
-        report(f"gemm ta={ta} tb={tb} {M}x{Nn}x{K}", rel(C, ref), 2e-6 * math.sqrt(K) + 1e-6)
+        report(f"gemm ta={ta} tb={tb} {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
     # relu + accumulate
     A, B = torch.randn(200, 64), torch.randn(96, 64)
     C0 = torch.randn(200, 96)
     C = C0.clone().to(dev)
     ops.gemm(0, 1, 200, 96, 64, A.to(dev), 64, B.to(dev), 64, C, 96, flags=N.GEMM_RELU | N.GEMM_ACCUMULATE)
-    report("gemm relu+accumulate", rel(C, torch.relu(A @ B.t() + C0)), 1e-5)
+    report("gemm relu+accumulate", rel(C, torch.relu(A @ B.t() + C0)), mfma_tol(1e-5))
     # fused side products: ReLU mask on the output, column sums of A^T (bias gradient) with and without split-K
     for (M, Nn, K) in [(300, 200, 77), (512, 3, 9000), (768, 256, 50000)]:
         A, B = torch.randn(K, M), torch.randn(K, Nn)
@@ -70,7 +76,7 @@ def gemm():
         cs = torch.empty(M, device=dev)
         ops.gemm(1, 0, M, Nn, K, A.to(dev), M, B.to(dev), Nn, C, Nn, relu_mask=mask.to(dev), ldmask=Nn, colsum_a=cs)
         ref = (A.t().double() @ B.double()) * (mask > 0)
-        report(f"gemm_ex mask {M}x{Nn}x{K}", rel(C, ref), 2e-6 * math.sqrt(K) + 1e-6)
+        report(f"gemm_ex mask {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
         report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
     X = torch.randn(5000, 300)
     out = torch.empty(300, device=dev)
@@ -225,17 +231,17 @@ def attention():
         qd = _pm(qkv).to(dev).requires_grad_(True)
         od = ops.list_attention(qd, S, B, H)
         od.backward(_pm(dout).to(dev))
-        report(f"attn fwd  B{B} S{S} H{H} HD{HD}", rel(_unpm(od, B, S), orf), 1e-5)
+        report(f"attn fwd  B{B} S{S} H{H} HD{HD}", rel(_unpm(od, B, S), orf), mfma_tol(1e-5))
         g = _unpm(qd.grad, B, S)
-        report(f"attn dq   B{B} S{S} H{H} HD{HD}", rel(g[..., :E], qr.grad[..., :E]), 3e-5)
-        report(f"attn dk   B{B} S{S} H{H} HD{HD}", rel(g[..., E:2 * E], qr.grad[..., E:2 * E]), 3e-5)
-        report(f"attn dv   B{B} S{S} H{H} HD{HD}", rel(g[..., 2 * E:], qr.grad[..., 2 * E:]), 3e-5)
+        report(f"attn dq   B{B} S{S} H{H} HD{HD}", rel(g[..., :E], qr.grad[..., :E]), mfma_tol(3e-5))
+        report(f"attn dk   B{B} S{S} H{H} HD{HD}", rel(g[..., E:2 * E], qr.grad[..., E:2 * E]), mfma_tol(3e-5))
+        report(f"attn dv   B{B} S{S} H{H} HD{HD}", rel(g[..., 2 * E:], qr.grad[..., 2 * E:]), mfma_tol(3e-5))
     # sharp softmax (large scores) to exercise the online max
     B, S, H, HD = 150, 2, 1, 64
     qkv = torch.randn(B, S, 3 * HD) * 4
     qr = qkv.clone().double()
     od = ops.list_attention(_pm(qkv).to(dev), S, B, H)
-    report("attn fwd sharp", rel(_unpm(od, B, S), _attn_ref(qr, H)), 2e-5)
+    report("attn fwd sharp", rel(_unpm(od, B, S), _attn_ref(qr, H)), mfma_tol(2e-5))
 
 
 @section
@@ -321,17 +327,24 @@ def optimizer_and_trainer():
     opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=0.01)
     crit_r = olosses.DivLoss(metric='f1', div_type='js')
     crit_h = hl.DivLoss(metric='f1', div_type='js')
+    # both optimisers are driven by the SAME gradients (the HIP model's), so this isolates the Adam arithmetic:
+    # Adam normalises by sqrt(v), so analytically-zero gradients (rounding noise) would otherwise move parameters
+    # by +-lr with an implementation-dependent sign.
     for _ in range(3):
-        opt_r.zero_grad()
-        crit_r(ref(x), y).backward()
-        opt_r.step()
         opt_h.zero_grad()
         crit_h(hip(x.to(dev)), y.to(dev)).backward()
+        for (n, a), (_, b) in zip(hip.named_parameters(), ref.named_parameters()):
+            b.grad = a.grad.detach().cpu().clone()
+        opt_r.step()
         opt_h.step()
     worst = 0.0
     for (n, a), (_, b) in zip(hip.named_parameters(), ref.named_parameters()):
         worst = max(worst, float((a.detach().cpu() - b.detach()).abs().max()))
-    report("3 Adam steps: max |param diff| vs torch.optim.Adam on the oracle", worst, 2e-5)
+    report("3 Adam steps on identical gradients: max |param diff| vs torch.optim.Adam", worst, 2e-6)
+    # and the end-to-end loss after those steps agrees with the oracle evaluated at the oracle's parameters
+    l_h = float(crit_h(hip(x.to(dev)), y.to(dev)))
+    l_r = float(crit_r(ref(x), y))
+    report("loss after 3 steps vs oracle", abs(l_h - l_r), 1e-4)
     # Trainer on a synthetic robust04-format set
     import run as hip_run
     with tempfile.TemporaryDirectory() as tmp:
@@ -395,9 +408,9 @@ def dropout():
     devs = [t.clone().to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
     yd = ops.FFNFn.apply(*devs, p, seed)
     yd.backward(dy.to(dev))
-    report("drop ffn fwd", rel(yd, yr), 1e-5)
+    report("drop ffn fwd", rel(yd, yr), mfma_tol(1e-5))
     for nm, a, bref in zip(("dx", "dw1", "db1", "dw2", "db2"), devs, refs):
-        report(f"drop ffn {nm}", rel(a.grad, bref.grad), 3e-5)
+        report(f"drop ffn {nm}", rel(a.grad, bref.grad), mfma_tol(3e-5))
     # attention-probability dropout
     for (B, S, H, HD) in [(70, 3, 2, 64), (40, 2, 4, 16)]:
         E = H * HD
@@ -415,8 +428,8 @@ def dropout():
         qd = _pm(qkv).to(dev).requires_grad_(True)
         od = ops.ListAttentionFn.apply(qd, S, B, H, p, seed)
         od.backward(_pm(dout).to(dev))
-        report(f"drop attn fwd B{B} HD{HD}", rel(_unpm(od, B, S), orf), 1e-5)
-        report(f"drop attn dqkv B{B} HD{HD}", rel(_unpm(qd.grad, B, S), qr.grad), 3e-5)
+        report(f"drop attn fwd B{B} HD{HD}", rel(_unpm(od, B, S), orf), mfma_tol(1e-5))
+        report(f"drop attn dqkv B{B} HD{HD}", rel(_unpm(qd.grad, B, S), qr.grad), mfma_tol(3e-5))
     # model level: train() with dropout runs, stays a distribution, differs from eval(); eval() == dropout 0
     import models as hm
     from oracle.weights import fill_state_dict, synthetic_lists
@@ -492,7 +505,11 @@ def models():
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:]
+    want = [w for w in sys.argv[1:] if not w.startswith("--")]
+    for w in sys.argv[1:]:
+        if w.startswith("--precision="):
+            N.set_precision(w.split("=", 1)[1])
+    print("precision mode:", N.get_precision(), flush=True)
     secs = [v for v in list(globals().values()) if getattr(v, "_is_section", False)]
     for fn in secs:
         if want and fn.__name__ not in want:
