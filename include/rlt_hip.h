@@ -182,19 +182,25 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
  * bwd: dqkv (S*B,3E) from dout; ws: rlt_list_attention_bwd_workspace bytes.
  * HD in {16, 32, 64}; E = H*HD.
  */
+/* In the split-bf16 mode the forward first writes Q (pre-scaled), K and V as pre-split bf16 hi/lo tile
+ * records (64-row tiles in the kernels' LDS layout) into `images` (rlt_list_attention_fwd_workspace bytes; 0 in
+ * fp32 mode, then `images` may be NULL); the caller keeps `images` for the backward pass. */
+size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD);
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
-                           float* out, float* lse, void* stream);
+                           float* out, float* lse, void* images, size_t images_bytes, void* stream);
+/* backward: ws = [delta (S,H,B) | dO tile records], rlt_list_attention_bwd_workspace bytes.
+ *   _bwd_prepare: delta = rowsum(dout*out) and (split-bf16 mode) the dO records;
+ *   _bwd_dkv:     dK, dV columns of dqkv;   _bwd_dq: dQ columns of dqkv;
+ *   _bwd:         the three in sequence.  `images` = the forward's buffer (NULL => exact-fp32 kernels). */
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD);
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                           int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv,
+                           int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream);
-/* the three launches of rlt_list_attention_bwd on their own (same arguments; `delta` (S,H,B) is the
- * workspace): delta = rowsum(dout*out); dK,dV columns of dqkv; dQ columns of dqkv. */
-int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int B, int H, int HD,
-                                 float* delta, void* stream);
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
+int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+                                   const void* images, void* ws, size_t ws_bytes, void* stream);
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
                                int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream);
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream);
 /* keep-mask of the attention-probability dropout as data (tests, small B): out (S,H,B,B) =
  * keep ? 1/(1-p) : 0 for (position, head, query, key) */

@@ -500,8 +500,17 @@ int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, floa
     return RLT_LAUNCH_RESULT();
 }
 
+// ---- workspace layout of the backward pass: [ delta (S,H,B) floats, padded to 1 KiB | dO tile records (bf16x3) ]
+static size_t delta_bytes(int S, int B, int H) { return ((size_t)S * H * B * sizeof(float) + 1023) / 1024 * 1024; }
+
+size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD) {
+    if (S <= 0 || B <= 0 || H <= 0) return 0;
+    if (!(HD == 16 || HD == 32 || HD == 64)) return 0;
+    return attn_mode() == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 3) : 0;
+}
+
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
-                           float* out, float* lse, void* stream) {
+                           float* out, float* lse, void* images, size_t images_bytes, void* stream) {
     RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
     if (!(rlt_aligned16(qkv) && rlt_aligned16(out))) return RLT_E_ALIGN;
@@ -510,62 +519,73 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
     a.scale = 1.0f / sqrtf((float)HD);
     a.drop_p = drop_p; a.drop_thr = rlt_drop_threshold(drop_p); a.seed = seed;
     hipStream_t st = rlt_stream(stream);
-    if (attn_mode() == 1) return rlt_attn3_fwd(a, HD, st);
+    if (attn_mode() == 1 && images) {      // split-bf16: needs room for the Q/K/V tile records
+        if (images_bytes < rlt_attn3_images_bytes(S, B, H, HD, 3)) return RLT_E_WORKSPACE;
+        if (!rlt_aligned16(images)) return RLT_E_ALIGN;
+        return rlt_attn3_run(0, a, HD, images, nullptr, st);
+    }
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
     return launch_fwd<16>(a, st);
 }
 
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
-    (void)HD;
     if (S <= 0 || B <= 0 || H <= 0) return 0;
-    return (size_t)S * H * B * sizeof(float);
+    if (!(HD == 16 || HD == 32 || HD == 64)) return 0;
+    return delta_bytes(S, B, H) + (attn_mode() == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0);
 }
 
-int rlt_list_attention_bwd_delta(const float* out, const float* dout, int S, int B, int H, int HD,
-                                 float* delta, void* stream) {
-    RLT_CHECK_ARG(out && dout && delta && S > 0 && B > 0 && H > 0);
+int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+                                   const void* images, void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    const bool split = attn_mode() == 1 && images;
+    if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0)) return RLT_E_WORKSPACE;
+    hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, rlt_stream(stream), out, dout, S, B, H, HD, delta);
-    return RLT_LAUNCH_RESULT();
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
+    if (!split) return RLT_LAUNCH_RESULT();
+    AttnArgs a{};
+    a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.S = S; a.B = B; a.H = H;
+    return rlt_attn3_run(3, a, HD, nullptr, (uint8_t*)ws + delta_bytes(S, B, H), st);
 }
 
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const float* delta,
-                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
-    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
+static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+                    int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+    RLT_CHECK_ARG(qkv && dout && lse && ws && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
-    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
+    const AttnArgs a = bwd_args(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
-    if (attn_mode() == 1) return rlt_attn3_bwd_dkv(a, HD, st);
-    if (HD == 64) return launch_dkv<64>(a, st);
-    if (HD == 32) return launch_dkv<32>(a, st);
-    return launch_dkv<16>(a, st);
-}
-
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const float* delta,
-                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
-    RLT_CHECK_ARG(qkv && dout && lse && delta && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
-    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
-    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
-    const AttnArgs a = bwd_args(qkv, dout, lse, delta, S, B, H, HD, drop_p, seed, dqkv);
-    hipStream_t st = rlt_stream(stream);
-    if (attn_mode() == 1) return rlt_attn3_bwd_dq(a, HD, st);
+    if (attn_mode() == 1 && images)
+        return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
+    if (which == 1) {
+        if (HD == 64) return launch_dkv<64>(a, st);
+        if (HD == 32) return launch_dkv<32>(a, st);
+        return launch_dkv<16>(a, st);
+    }
     if (HD == 64) return launch_dq<64>(a, st);
     if (HD == 32) return launch_dq<32>(a, st);
     return launch_dq<16>(a, st);
 }
 
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+    return bwd_part(1, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+}
+
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+    return bwd_part(2, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+}
+
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                           int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv,
+                           int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream) {
-    RLT_CHECK_ARG(ws);
-    if (ws_bytes < rlt_list_attention_bwd_workspace(S, B, H, HD)) return RLT_E_WORKSPACE;
-    int rc = rlt_list_attention_bwd_delta(out, dout, S, B, H, HD, (float*)ws, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    int rc = rlt_list_attention_bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
     return rc;
 }
 

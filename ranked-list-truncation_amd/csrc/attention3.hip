@@ -161,28 +161,124 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
 template <int HD> constexpr int rows_elems() { return KT * (HD + 8); }     // one hi or lo rows image
 template <int HD> constexpr int T_elems() { return HD * LDT3; }             // one hi or lo transposed image
 
+// ---- pre-split tile images in HBM -----------------------------------------------------------------------
+// A one-time "prepare" pass splits each 64-row tile of Q, K, V (and dO) into bf16 hi/lo ONCE and writes it in
+// exactly the LDS image layout; the attention kernels then stage tiles with LDS-DMA (global_load_lds, no
+// registers, no VALU).  Without it every workgroup re-splits the same K/V tiles (32x redundant at B = 4096).
+// Record of one (matrix, position*head pair, 64-row tile):
+//   [ rows image hi | rows image lo | pad ] RP bytes   [ transposed image hi | lo | pad ] TP bytes   [ aux 1 KiB ]
+// aux (dO records only): lse*log2e [64 floats], delta [64 floats].
+constexpr int rup1k(int b) { return (b + 1023) / 1024 * 1024; }
+template <int HD> struct Rec {
+    static constexpr int RP = rup1k(2 * rows_elems<HD>() * 2);
+    static constexpr int TP = rup1k(2 * T_elems<HD>() * 2);
+    static constexpr int AUX = 1024;
+    static constexpr int BYTES = RP + TP + AUX;
+};
+constexpr int QT3 = 256;                  // rows owned by a workgroup of the split-bf16 kernels (8 wavefronts x 32)
+
+// LDS-DMA copy of NBYTES (multiple of 1 KiB) global -> LDS by the 8 wavefronts of the workgroup
+template <int NBYTES>
+__device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane) {
+    static_assert(NBYTES % 1024 == 0, "LDS-DMA pieces are 1 KiB per wavefront instruction");
+#pragma unroll
+    for (int c = 0; c < (NBYTES / 1024 + 7) / 8; ++c) {
+        const int chunk = wv + 8 * c;
+        if (chunk < NBYTES / 1024)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc + chunk * 1024 + lane * 16),
+                                             (void __attribute__((address_space(3)))*)(lds_dst + chunk * 1024), 16, 0, 0);
+    }
+}
+
+// fragments of one row of a rows image straight from HBM (no VALU): frag[ks] covers d = 16ks + 8h + j
+template <int HD>
+__device__ __forceinline__ void image_row_frags(const uint8_t* __restrict__ rec, int row, int hh, bf16x8 (&fh)[HD / 16], bf16x8 (&fl)[HD / 16]) {
+    const uint16_t* hi = reinterpret_cast<const uint16_t*>(rec);
+    const uint16_t* lo = hi + rows_elems<HD>();
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        fh[ks] = as_frag(*reinterpret_cast<const uint4*>(hi + row * (HD + 8) + 16 * ks + 8 * hh));
+        fl[ks] = as_frag(*reinterpret_cast<const uint4*>(lo + row * (HD + 8) + 16 * ks + 8 * hh));
+    }
+}
+
+struct PrepArgs {
+    const float* src[3]; size_t ld; float mul[3];      // up to 3 matrices (row-major tiles of HD columns), scale factors
+    const float* lse; const float* delta;              // optional aux (dO records)
+    uint8_t* out;                                       // records: [matrix][pair][tile]
+    int S, B, H, nmat;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint8_t* rec = reinterpret_cast<uint8_t*>(smem);
+    uint16_t* r_hi = reinterpret_cast<uint16_t*>(rec);
+    uint16_t* r_lo = r_hi + rows_elems<HD>();
+    uint16_t* t_hi = reinterpret_cast<uint16_t*>(rec + Rec<HD>::RP);
+    uint16_t* t_lo = t_hi + T_elems<HD>();
+    float* aux = reinterpret_cast<float*>(rec + Rec<HD>::RP + Rec<HD>::TP);
+    const int tid = threadIdx.x;
+    const int nt = rlt_cdiv_dev(a.B, KT);
+    const int pair = blockIdx.x / nt, tile = blockIdx.x % nt, m = blockIdx.y;
+    const int s = pair / a.H, h = pair % a.H;
+    // zero the pads so that the records are deterministic
+    for (int i = tid; i < Rec<HD>::BYTES / 16; i += 256) reinterpret_cast<uint4*>(rec)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const float* base = a.src[m] + (size_t)s * a.B * a.ld + h * HD;
+    Stage<HD> st;
+    stage_load<HD>(base, a.ld, tile * KT, a.B, tid, st);
+    if (stage_active<HD>(tid)) {
+        const float mul = a.mul[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { st.v[i].x *= mul; st.v[i].y *= mul; st.v[i].z *= mul; st.v[i].w *= mul; }
+    }
+    stage_store_rows<HD>(r_hi, r_lo, tid, st);
+    stage_store_T<HD>(t_hi, t_lo, tid, st);
+    if (a.lse && tid < KT) {
+        const int q = tile * KT + tid, qc = min(q, a.B - 1);
+        const float l = a.lse[((size_t)s * a.H + h) * a.B + qc], e = a.delta[((size_t)s * a.H + h) * a.B + qc];
+        aux[tid] = q < a.B ? l * LOG2E : 0.f;
+        aux[KT + tid] = q < a.B ? e : 0.f;
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(a.out + (((size_t)m * a.S * a.H + pair) * nt + tile) * Rec<HD>::BYTES);
+    for (int i = tid; i < Rec<HD>::BYTES / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(rec)[i];
+}
+
+struct Attn3Args {
+    AttnArgs a;
+    const uint8_t* img;       // Q | K | V records
+    const uint8_t* dimg;      // dO records (backward)
+};
+template <int HD>
+__device__ __forceinline__ const uint8_t* record(const uint8_t* img, int m, int npair, int nt, int pair, int tile) {
+    return img + (((size_t)m * npair + pair) * nt + tile) * Rec<HD>::BYTES;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn3_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
+    const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
-    constexpr int STAGE = 2 * rows_elems<HD>() + 2 * T_elems<HD>();       // K hi,lo (rows) | V hi,lo (transposed)
+    constexpr int STAGE = Rec<HD>::RP + Rec<HD>::TP;                        // K rows pair | V transposed pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD;
-    const size_t ld = (size_t)3 * E;
-    const int ntile = rlt_cdiv_dev(B, QT);
+    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
+    const int nt = rlt_cdiv_dev(B, KT);
+    const int ntile = rlt_cdiv_dev(B, QT3);
     int pair, qt;
-    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    map_block(blockIdx.x, npair, ntile, pair, qt);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
-    const int q = qt * QT + wv * 32 + l31;
-    const bool wave_live = qt * QT + wv * 32 < B;
-    const int qc = min(q, B - 1);
+    const int q = qt * QT3 + wv * 32 + l31;
+    const bool wave_live = qt * QT3 + wv * 32 < B;
 
     bf16x8 qh[HD / 16], ql[HD / 16];
-    row_frags<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qh, ql);
-
+    {
+        const int qtile = min(q >> 6, nt - 1);
+        image_row_frags<HD>(record<HD>(g.img, 0, npair, nt, pair, qtile), q & 63, hh, qh, ql);   // Q pre-scaled by scale*log2e
+    }
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -190,34 +286,27 @@ __global__ __launch_bounds__(256, 2) void attn3_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    auto k_hi = [&](int buf) { return lds + buf * STAGE; };
-    auto k_lo = [&](int buf) { return lds + buf * STAGE + rows_elems<HD>(); };
-    auto v_hi = [&](int buf) { return lds + buf * STAGE + 2 * rows_elems<HD>(); };
-    auto v_lo = [&](int buf) { return lds + buf * STAGE + 2 * rows_elems<HD>() + T_elems<HD>(); };
-
-    Stage<HD> rk, rv;
-    const int nt = rlt_cdiv_dev(B, KT);
-    stage_load<HD>(base + E, ld, 0, B, tid, rk);
-    stage_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
-    stage_store_rows<HD>(k_hi(0), k_lo(0), tid, rk);
-    stage_store_T<HD>(v_hi(0), v_lo(0), tid, rv);
+    auto issue = [&](int t, int buf) {
+        dma_copy<Rec<HD>::RP>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::TP>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
+    };
+    issue(0, 0);
     __syncthreads();
-
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) {
-            stage_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
-            stage_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
-        }
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
         if (wave_live) {
+            const uint16_t* k_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+            const uint16_t* k_lo = k_hi + rows_elems<HD>();
+            const uint16_t* v_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
+            const uint16_t* v_lo = v_hi + T_elems<HD>();
             f32x16 sc[2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
-                sc[sub] = mma_rows<HD>(k_hi(buf), k_lo(buf), sub, l31, hh, qh, ql, sc[sub]);     // S^T[key][q], log2 domain
+                sc[sub] = mma_rows<HD>(k_hi, k_lo, sub, l31, hh, qh, ql, sc[sub]);     // S^T[key][q], log2 domain
             }
-            float tmax = -INFINITY;
             if (t == nt - 1) {            // only the last tile can hold keys beyond B
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -225,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void attn3_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 16; ++r)
                         if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
             }
+            float tmax = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -232,38 +322,34 @@ __global__ __launch_bounds__(256, 2) void attn3_fwd_kernel(AttnArgs a) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = exp2f(m_run - m_new);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            // per 32-key sub-tile: exponentiate, (drop), feed P.V - the second sub-tile's VALU work is issued while
+            // the first sub-tile's MFMAs execute
             float psum = 0.f;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = exp2f(sc[sub][r] - m_new);
                     sc[sub][r] = p;
                     psum += p;
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            if (a.drop_p > 0.f) {
-                const uint32_t ps = pair_seed(a.seed, pair);
-                const float inv_keep = 1.f / (1.f - a.drop_p);
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
+                if (a.drop_p > 0.f) {
+                    const uint32_t ps = pair_seed(a.seed, pair);
+                    const float inv_keep = 1.f / (1.f - a.drop_p);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = t * KT + sub * 32 + acc_row(r, hh);
                         sc[sub][r] = rlt_keep(ps, (uint32_t)q, (uint32_t)key, a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
                     }
+                }
+                mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
             }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) mma_T<HD>(v_hi(buf), v_lo(buf), sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
-        }
-        if (t + 1 < nt) {
-            stage_store_rows<HD>(k_hi(buf ^ 1), k_lo(buf ^ 1), tid, rk);
-            stage_store_T<HD>(v_hi(buf ^ 1), v_lo(buf ^ 1), tid, rv);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
         }
         __syncthreads();
     }
@@ -276,29 +362,30 @@ __global__ __launch_bounds__(256, 2) void attn3_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-// workgroup = 128 queries; loops over 64-key tiles.  K is staged in both images (rows for S^T = K Q^T,
-// transposed for dQ^T = K^T dS^T), V in the rows image (dP^T = V dO^T).
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
+    const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
-    constexpr int STAGE = 4 * rows_elems<HD>() + 2 * T_elems<HD>();       // K rows hi,lo | V rows hi,lo | K^T hi,lo
+    constexpr int KREC = Rec<HD>::RP + Rec<HD>::TP;                         // K rows pair | K transposed pair
+    constexpr int STAGE = KREC + Rec<HD>::RP;                               // ... | V rows pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD;
+    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
-    const int ntile = rlt_cdiv_dev(B, QT);
+    const int nt = rlt_cdiv_dev(B, KT);
+    const int ntile = rlt_cdiv_dev(B, QT3);
     int pair, qt;
-    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    map_block(blockIdx.x, npair, ntile, pair, qt);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
-    const int q = qt * QT + wv * 32 + l31;
-    const bool wave_live = qt * QT + wv * 32 < B;
+    const int q = qt * QT3 + wv * 32 + l31;
+    const bool wave_live = qt * QT3 + wv * 32 < B;
     const int qc = min(q, B - 1);
 
     bf16x8 qh[HD / 16], ql[HD / 16], doh[HD / 16], dol[HD / 16];
-    row_frags<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qh, ql);
-    row_frags<HD>(a.dout + ((size_t)s * B + qc) * E + h * HD, hh, 1.f, doh, dol);
+    const int qtile = min(q >> 6, nt - 1);
+    image_row_frags<HD>(record<HD>(g.img, 0, npair, nt, pair, qtile), q & 63, hh, qh, ql);
+    image_row_frags<HD>(record<HD>(g.dimg, 0, npair, nt, pair, qtile), q & 63, hh, doh, dol);
     const float lse2 = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
     const float del = a.delta[((size_t)s * H + h) * B + qc];
 
@@ -308,29 +395,22 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    uint16_t* kr_hi = lds;
-    uint16_t* kr_lo = lds + rows_elems<HD>();
-    uint16_t* vr_hi = lds + 2 * rows_elems<HD>();
-    uint16_t* vr_lo = lds + 3 * rows_elems<HD>();
-    uint16_t* kt_hi = lds + 4 * rows_elems<HD>();
-    uint16_t* kt_lo = lds + 4 * rows_elems<HD>() + T_elems<HD>();
-    (void)STAGE;
-
-    Stage<HD> rk, rv;
-    const int nt = rlt_cdiv_dev(B, KT);
-    stage_load<HD>(base + E, ld, 0, B, tid, rk);
-    stage_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+    auto issue = [&](int t, int buf) {
+        dma_copy<KREC>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::RP>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
+    };
+    issue(0, 0);
+    __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        // single LDS stage: (stores for tile t) | barrier | (prefetch t+1 into registers, multiply tile t) | barrier
-        stage_store_rows<HD>(kr_hi, kr_lo, tid, rk);
-        stage_store_T<HD>(kt_hi, kt_lo, tid, rk);
-        stage_store_rows<HD>(vr_hi, vr_lo, tid, rv);
-        __syncthreads();
-        if (t + 1 < nt) {
-            stage_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
-            stage_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
-        }
+        const int buf = t & 1;
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
         if (wave_live) {
+            const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+            const uint16_t* kr_lo = kr_hi + rows_elems<HD>();
+            const uint16_t* kt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
+            const uint16_t* kt_lo = kt_hi + T_elems<HD>();
+            const uint16_t* vr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + KREC);
+            const uint16_t* vr_lo = vr_hi + rows_elems<HD>();
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 f32x16 sc, dp;
@@ -356,183 +436,63 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(AttnArgs a) {
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
 }
 
-// ------------------------------------------------------------------------------------------ dK, dV
-// workgroup = 128 keys; loops over 64-query tiles.  Q and dO are staged in both images (rows for
-// S = Q K^T and dP = dO V^T, transposed for dV^T = dO^T P and dK^T = Q^T dS).
+// ------------------------------------------------------------------------------------------ dV
+// workgroup = 256 keys, loops over 64-query tiles: dV^T[d][key] += dO^T P with P recomputed from the LSE
 template <int HD>
-__global__ __launch_bounds__(256, (HD > 32 ? 1 : 2)) void attn3_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
+    const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
+    constexpr int DPART = Rec<HD>::TP + Rec<HD>::AUX;                       // dO transposed pair | aux
+    constexpr int STAGE = Rec<HD>::RP + DPART;                              // Q rows pair | ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* qr_hi = lds;
-    uint16_t* qr_lo = lds + rows_elems<HD>();
-    uint16_t* dr_hi = lds + 2 * rows_elems<HD>();
-    uint16_t* dr_lo = lds + 3 * rows_elems<HD>();
-    uint16_t* qt_hi = lds + 4 * rows_elems<HD>();
-    uint16_t* qt_lo = qt_hi + T_elems<HD>();
-    uint16_t* dt_hi = qt_hi + 2 * T_elems<HD>();
-    uint16_t* dt_lo = qt_hi + 3 * T_elems<HD>();
-    float* Ls = reinterpret_cast<float*>(qt_hi + 4 * T_elems<HD>());       // [KT] lse * log2e
-    float* Es = Ls + KT;                                                     // [KT] delta
+    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD;
+    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
-    const int ntile = rlt_cdiv_dev(B, QT);
-    int pair, ktile;
-    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
-    const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
-    const float* dobase = a.dout + (size_t)s * B * E + h * HD;
-    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
-    const float* delbase = a.delta + ((size_t)s * H + h) * B;
-    const int key = ktile * QT + wv * 32 + l31;
-    const bool wave_live = ktile * QT + wv * 32 < B;
-    const int kc = min(key, B - 1);
-
-    bf16x8 kh[HD / 16], kl[HD / 16], vh[HD / 16], vl[HD / 16];
-    row_frags<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kh, kl);
-    row_frags<HD>(base + (size_t)kc * ld + 2 * E, hh, 1.f, vh, vl);
-
-    f32x16 dk[DT], dv[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-
-    Stage<HD> rq, rd;
-    float rl = 0.f, re = 0.f;
     const int nt = rlt_cdiv_dev(B, KT);
-    auto load_small = [&](int row0) {
-        if (tid < KT) {
-            const int qi = row0 + tid, qcl = min(qi, B - 1);
-            const float l = lsebase[qcl], e = delbase[qcl];
-            rl = qi < B ? l * LOG2E : 0.f;
-            re = qi < B ? e : 0.f;
-        }
-    };
-    stage_load<HD>(base, ld, 0, B, tid, rq);
-    stage_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
-    load_small(0);
-    for (int t = 0; t < nt; ++t) {
-        stage_store_rows<HD>(qr_hi, qr_lo, tid, rq);
-        stage_store_T<HD>(qt_hi, qt_lo, tid, rq);
-        stage_store_rows<HD>(dr_hi, dr_lo, tid, rd);
-        stage_store_T<HD>(dt_hi, dt_lo, tid, rd);
-        if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
-        __syncthreads();
-        if (t + 1 < nt) {
-            stage_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
-            stage_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
-            load_small((t + 1) * KT);
-        }
-        if (wave_live) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key]
-                dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    const bool ok = t * KT + ql < B;
-                    const float p = ok ? exp2f(sc[r] - Ls[ql]) : 0.f;
-                    float pd = p, dpr = dp[r];
-                    if (a.drop_p > 0.f) {
-                        const bool keep = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
-                        const float m = keep ? 1.f / (1.f - a.drop_p) : 0.f;
-                        pd = p * m;
-                        dpr *= m;
-                    }
-                    sc[r] = pd;                                                    // (dropped) P, feeds dV
-                    dp[r] = p * (dpr - Es[ql]);                                    // dS
-                }
-                mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
-                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += Q^T dS
-            }
-        }
-        __syncthreads();
-    }
-    if (!wave_live || key >= B) return;
-    float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
-    store_acc_T<HD>(drow + E, hh, dk, a.scale);
-    store_acc_T<HD>(drow + 2 * E, hh, dv, 1.f);
-}
-
-// ------------------------------------------------------------------------------------------ dV / dK (split)
-// The fused dK/dV kernel above needs ~340 registers (spills at 2 wavefronts/SIMD).  Split form: two kernels
-// of the dQ kernel's shape, each within 256 registers: dV = P^T dO (recomputes S), dK = dS^T Q (recomputes S, dP).
-// 5 MFMA products instead of 4, but both run at occupancy 2 with no scratch traffic.
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn3_bwd_dv_kernel(AttnArgs a) {
-    constexpr int DT = (HD + 31) / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* qr_hi = lds;
-    uint16_t* qr_lo = lds + rows_elems<HD>();
-    uint16_t* dt_hi = lds + 2 * rows_elems<HD>();
-    uint16_t* dt_lo = dt_hi + T_elems<HD>();
-    float* Ls = reinterpret_cast<float*>(dt_hi + 2 * T_elems<HD>());       // [KT] lse * log2e
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD;
-    const size_t ld = (size_t)3 * E;
-    const int ntile = rlt_cdiv_dev(B, QT);
+    const int ntile = rlt_cdiv_dev(B, QT3);
     int pair, ktile;
-    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
+    map_block(blockIdx.x, npair, ntile, pair, ktile);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
-    const float* dobase = a.dout + (size_t)s * B * E + h * HD;
-    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
-    const int key = ktile * QT + wv * 32 + l31;
-    const bool wave_live = ktile * QT + wv * 32 < B;
-    const int kc = min(key, B - 1);
+    const int key = ktile * QT3 + wv * 32 + l31;
+    const bool wave_live = ktile * QT3 + wv * 32 < B;
 
     bf16x8 kh[HD / 16], kl[HD / 16];
-    row_frags<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kh, kl);
+    image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, min(key >> 6, nt - 1)), key & 63, hh, kh, kl);
     f32x16 dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[dt][r] = 0.f;
 
-    Stage<HD> rq, rd;
-    float rl = 0.f;
-    const int nt = rlt_cdiv_dev(B, KT);
-    auto load_small = [&](int row0) {
-        if (tid < KT) {
-            const int qi = row0 + tid;
-            const float l = lsebase[min(qi, B - 1)];
-            rl = qi < B ? l * LOG2E : 0.f;
-        }
+    auto issue = [&](int t, int buf) {
+        dma_copy<Rec<HD>::RP>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<DPART>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.dimg, 0, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
     };
-    stage_load<HD>(base, ld, 0, B, tid, rq);
-    stage_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
-    load_small(0);
+    issue(0, 0);
+    __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        stage_store_rows<HD>(qr_hi, qr_lo, tid, rq);
-        stage_store_T<HD>(dt_hi, dt_lo, tid, rd);
-        if (tid < KT) Ls[tid] = rl;
-        __syncthreads();
-        if (t + 1 < nt) {
-            stage_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
-            stage_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
-            load_small((t + 1) * KT);
-        }
+        const int buf = t & 1;
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
         if (wave_live) {
+            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
+            const uint16_t* dt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
+            const uint16_t* dt_lo = dt_hi + T_elems<HD>();
+            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + Rec<HD>::RP + Rec<HD>::TP);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 f32x16 sc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key]
+                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] (Q carries scale*log2e)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
                     float p = (t * KT + ql < B) ? exp2f(sc[r] - Ls[ql]) : 0.f;
                     if (a.drop_p > 0.f)
                         p = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? p / (1.f - a.drop_p) : 0.f;
-                    sc[r] = p;                                                     // (dropped) P
+                    sc[r] = p;
                 }
                 mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
             }
@@ -543,69 +503,56 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dv_kernel(AttnArgs a) {
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + 2 * E, hh, dv, 1.f);
 }
 
+// ------------------------------------------------------------------------------------------ dK
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn3_bwd_dk_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
+    const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
+    constexpr int QREC = Rec<HD>::RP + Rec<HD>::TP;                         // Q rows pair | Q transposed pair
+    constexpr int STAGE = QREC + Rec<HD>::RP + Rec<HD>::AUX;                // ... | dO rows pair | aux
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* qr_hi = lds;
-    uint16_t* qr_lo = lds + rows_elems<HD>();
-    uint16_t* dr_hi = lds + 2 * rows_elems<HD>();
-    uint16_t* dr_lo = lds + 3 * rows_elems<HD>();
-    uint16_t* qt_hi = lds + 4 * rows_elems<HD>();
-    uint16_t* qt_lo = qt_hi + T_elems<HD>();
-    float* Ls = reinterpret_cast<float*>(qt_hi + 2 * T_elems<HD>());       // [KT] lse * log2e
-    float* Es = Ls + KT;                                                     // [KT] delta
+    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD;
+    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
-    const int ntile = rlt_cdiv_dev(B, QT);
+    const int nt = rlt_cdiv_dev(B, KT);
+    const int ntile = rlt_cdiv_dev(B, QT3);
     int pair, ktile;
-    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
+    map_block(blockIdx.x, npair, ntile, pair, ktile);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
-    const float* dobase = a.dout + (size_t)s * B * E + h * HD;
-    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
-    const float* delbase = a.delta + ((size_t)s * H + h) * B;
-    const int key = ktile * QT + wv * 32 + l31;
-    const bool wave_live = ktile * QT + wv * 32 < B;
-    const int kc = min(key, B - 1);
+    const int key = ktile * QT3 + wv * 32 + l31;
+    const bool wave_live = ktile * QT3 + wv * 32 < B;
 
     bf16x8 kh[HD / 16], kl[HD / 16], vh[HD / 16], vl[HD / 16];
-    row_frags<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kh, kl);
-    row_frags<HD>(base + (size_t)kc * ld + 2 * E, hh, 1.f, vh, vl);
+    const int ktl = min(key >> 6, nt - 1);
+    image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, ktl), key & 63, hh, kh, kl);
+    image_row_frags<HD>(record<HD>(g.img, 2, npair, nt, pair, ktl), key & 63, hh, vh, vl);
     f32x16 dk[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[dt][r] = 0.f;
 
-    Stage<HD> rq, rd;
-    float rl = 0.f, re = 0.f;
-    const int nt = rlt_cdiv_dev(B, KT);
-    auto load_small = [&](int row0) {
-        if (tid < KT) {
-            const int qi = row0 + tid, qcl = min(qi, B - 1);
-            const float l = lsebase[qcl], e = delbase[qcl];
-            rl = qi < B ? l * LOG2E : 0.f;
-            re = qi < B ? e : 0.f;
-        }
+    auto issue = [&](int t, int buf) {
+        const uint8_t* drec = record<HD>(g.dimg, 0, npair, nt, pair, t);
+        dma_copy<QREC>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::RP>(lds + buf * STAGE + QREC, drec, wv, lane);
+        dma_copy<Rec<HD>::AUX>(lds + buf * STAGE + QREC + Rec<HD>::RP, drec + Rec<HD>::RP + Rec<HD>::TP, wv, lane);
     };
-    stage_load<HD>(base, ld, 0, B, tid, rq);
-    stage_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
-    load_small(0);
+    issue(0, 0);
+    __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        stage_store_rows<HD>(qr_hi, qr_lo, tid, rq);
-        stage_store_T<HD>(qt_hi, qt_lo, tid, rq);
-        stage_store_rows<HD>(dr_hi, dr_lo, tid, rd);
-        if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
-        __syncthreads();
-        if (t + 1 < nt) {
-            stage_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
-            stage_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
-            load_small((t + 1) * KT);
-        }
+        const int buf = t & 1;
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
         if (wave_live) {
+            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
+            const uint16_t* qt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
+            const uint16_t* qt_lo = qt_hi + T_elems<HD>();
+            const uint16_t* dr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC);
+            const uint16_t* dr_lo = dr_hi + rows_elems<HD>();
+            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + QREC + Rec<HD>::RP);
+            const float* Es = Ls + KT;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 f32x16 sc, dp;
@@ -622,55 +569,84 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dk_kernel(AttnArgs a) {
                         dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
                     dp[r] = p * (dpr - Es[ql]);                                    // dS
                 }
-                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += Q^T dS
+                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
             }
         }
         __syncthreads();
     }
     if (!wave_live || key >= B) return;
-    store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + E, hh, dk, a.scale);
+    // the Q image carries c = scale*log2e, so dK = scale * dS^T Q = ln2 * dS^T (cQ)
+    store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + E, hh, dk, LN2);
 }
 
-template <int HD> size_t dv3_smem() { return (size_t)(2 * rows_elems<HD>() + 2 * T_elems<HD>()) * sizeof(uint16_t) + KT * sizeof(float); }
-template <int HD> size_t dk3_smem() { return (size_t)(4 * rows_elems<HD>() + 2 * T_elems<HD>()) * sizeof(uint16_t) + 2 * KT * sizeof(float); }
-template <int HD> size_t fwd3_smem() { return (size_t)2 * (2 * rows_elems<HD>() + 2 * T_elems<HD>()) * sizeof(uint16_t); }
-template <int HD> size_t dq3_smem() { return (size_t)(4 * rows_elems<HD>() + 2 * T_elems<HD>()) * sizeof(uint16_t); }
-template <int HD> size_t dkv3_smem() { return (size_t)(4 * rows_elems<HD>() + 4 * T_elems<HD>()) * sizeof(uint16_t) + 2 * KT * sizeof(float); }
+template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP); }
+template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP); }
+template <int HD> size_t dv3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
+template <int HD> size_t dk3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
 
 template <int HD>
-int launch3(int which, const AttnArgs& a, hipStream_t st) {
-    const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
+int prepare3(const PrepArgs& p, hipStream_t st) {
+    const int nt = rlt_cdiv(p.B, KT);
+    int rc = rlt_allow_lds(attn3_prepare_kernel<HD>, Rec<HD>::BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn3_prepare_kernel<HD>, dim3(p.S * p.H * nt, p.nmat), dim3(256), Rec<HD>::BYTES, st, p);
+    return RLT_LAUNCH_RESULT();
+}
+
+template <int HD>
+int launch3(int which, const Attn3Args& g, hipStream_t st) {
+    const AttnArgs& a = g.a;
+    const int grid = a.S * a.H * rlt_cdiv(a.B, QT3);
     int rc;
     if (which == 0) {
         if ((rc = rlt_allow_lds(attn3_fwd_kernel<HD>, fwd3_smem<HD>()))) return rc;
-        hipLaunchKernelGGL(attn3_fwd_kernel<HD>, dim3(grid), dim3(256), fwd3_smem<HD>(), st, a);
+        hipLaunchKernelGGL(attn3_fwd_kernel<HD>, dim3(grid), dim3(512), fwd3_smem<HD>(), st, g);
     } else if (which == 1) {
-        static const int fused = [] { const char* e = getenv("RLT_ATTN_DKV_FUSED"); return e ? atoi(e) : 0; }();
-        if (fused || HD <= 32) {       // small head dims fit the fused kernel at occupancy 2
-            if ((rc = rlt_allow_lds(attn3_bwd_dkv_kernel<HD>, dkv3_smem<HD>()))) return rc;
-            hipLaunchKernelGGL(attn3_bwd_dkv_kernel<HD>, dim3(grid), dim3(256), dkv3_smem<HD>(), st, a);
-        } else {
-            if ((rc = rlt_allow_lds(attn3_bwd_dv_kernel<HD>, dv3_smem<HD>()))) return rc;
-            if ((rc = rlt_allow_lds(attn3_bwd_dk_kernel<HD>, dk3_smem<HD>()))) return rc;
-            hipLaunchKernelGGL(attn3_bwd_dv_kernel<HD>, dim3(grid), dim3(256), dv3_smem<HD>(), st, a);
-            hipLaunchKernelGGL(attn3_bwd_dk_kernel<HD>, dim3(grid), dim3(256), dk3_smem<HD>(), st, a);
-        }
+        if ((rc = rlt_allow_lds(attn3_bwd_dv_kernel<HD>, dv3_smem<HD>()))) return rc;
+        if ((rc = rlt_allow_lds(attn3_bwd_dk_kernel<HD>, dk3_smem<HD>()))) return rc;
+        hipLaunchKernelGGL(attn3_bwd_dv_kernel<HD>, dim3(grid), dim3(512), dv3_smem<HD>(), st, g);
+        hipLaunchKernelGGL(attn3_bwd_dk_kernel<HD>, dim3(grid), dim3(512), dk3_smem<HD>(), st, g);
     } else {
         if ((rc = rlt_allow_lds(attn3_bwd_dq_kernel<HD>, dq3_smem<HD>()))) return rc;
-        hipLaunchKernelGGL(attn3_bwd_dq_kernel<HD>, dim3(grid), dim3(256), dq3_smem<HD>(), st, a);
+        hipLaunchKernelGGL(attn3_bwd_dq_kernel<HD>, dim3(grid), dim3(512), dq3_smem<HD>(), st, g);
     }
     return RLT_LAUNCH_RESULT();
 }
 
-int dispatch3(int which, const AttnArgs& a, int HD, hipStream_t st) {
-    if (HD == 64) return launch3<64>(which, a, st);
-    if (HD == 32) return launch3<32>(which, a, st);
-    if (HD == 16) return launch3<16>(which, a, st);
-    return RLT_E_SHAPE;
+template <int HD>
+int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t st) {
+    Attn3Args g;
+    g.a = a; g.img = (const uint8_t*)images; g.dimg = (const uint8_t*)dimages;
+    if (which == 0) {            // forward: split Q (scaled), K, V once, then attend
+        PrepArgs p{};
+        const int E = a.H * HD;
+        p.src[0] = a.qkv; p.src[1] = a.qkv + E; p.src[2] = a.qkv + 2 * E;
+        p.mul[0] = a.scale * LOG2E; p.mul[1] = 1.f; p.mul[2] = 1.f;
+        p.ld = (size_t)3 * E; p.out = (uint8_t*)images; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 3;
+        int rc = prepare3<HD>(p, st);
+        if (rc) return rc;
+    } else if (which == 3) {     // backward prepare: split dO (+ lse, delta)
+        PrepArgs p{};
+        p.src[0] = a.dout; p.mul[0] = 1.f; p.ld = (size_t)a.H * HD;
+        p.lse = a.lse; p.delta = a.delta;
+        p.out = (uint8_t*)dimages; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 1;
+        return prepare3<HD>(p, st);
+    }
+    return launch3<HD>(which, g, st);
 }
 
 }  // namespace
 
-int rlt_attn3_fwd(const AttnArgs& a, int HD, hipStream_t st) { return dispatch3(0, a, HD, st); }
-int rlt_attn3_bwd_dkv(const AttnArgs& a, int HD, hipStream_t st) { return dispatch3(1, a, HD, st); }
-int rlt_attn3_bwd_dq(const AttnArgs& a, int HD, hipStream_t st) { return dispatch3(2, a, HD, st); }
+size_t rlt_attn3_images_bytes(int S, int B, int H, int HD, int nmat) {
+    const size_t nt = (size_t)rlt_cdiv(B, KT);
+    const size_t rec = HD == 64 ? Rec<64>::BYTES : (HD == 32 ? Rec<32>::BYTES : Rec<16>::BYTES);
+    return (size_t)nmat * S * H * nt * rec;
+}
+
+// which: 0 forward (writes `images`), 1 dK+dV, 2 dQ, 3 backward prepare (writes `dimages` from dout, lse, delta)
+int rlt_attn3_run(int which, const AttnArgs& a, int HD, void* images, void* dimages, hipStream_t st) {
+    if (HD == 64) return run3<64>(which, a, images, dimages, st);
+    if (HD == 32) return run3<32>(which, a, images, dimages, st);
+    if (HD == 16) return run3<16>(which, a, images, dimages, st);
+    return RLT_E_SHAPE;
+}

@@ -56,7 +56,6 @@ __device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh,
 
 }  // namespace
 
-// split-bf16 ("bf16x3") launchers, defined in attention3.hip
-int rlt_attn3_fwd(const AttnArgs& a, int HD, hipStream_t st);
-int rlt_attn3_bwd_dkv(const AttnArgs& a, int HD, hipStream_t st);
-int rlt_attn3_bwd_dq(const AttnArgs& a, int HD, hipStream_t st);
+// split-bf16 ("bf16x3") path, defined in attention3.hip
+size_t rlt_attn3_images_bytes(int S, int B, int H, int HD, int nmat);
+int rlt_attn3_run(int which, const AttnArgs& a, int HD, void* images, void* dimages, hipStream_t st);

@@ -47,12 +47,13 @@ _SIGNATURES = {
     "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_uint32, P, P, P]),
     "rlt_add_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
     "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_uint32, P, P, P, P, c_int, P, c_size_t, P]),
-    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P]),
+    "rlt_list_attention_fwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, P]),
     "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, c_size_t, P]),
-    "rlt_list_attention_bwd_delta": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
-    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
-    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
+    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, P]),
+    "rlt_list_attention_bwd_prepare": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
+    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),

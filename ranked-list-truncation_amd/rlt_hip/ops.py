@@ -206,10 +206,13 @@ class ListAttentionFn(Function):
         HD = E // H
         out = _empty((S * B, E), qkv)
         lse = _empty((S, H, B), qkv)
+        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+        images = workspace(img_bytes, qkv.device) if img_bytes else None     # pre-split Q/K/V tile records (bf16x3 mode)
         _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, seed,
-                                         ptr(out), ptr(lse), stream()))
+                                         ptr(out), ptr(lse), ptr(images), img_bytes, stream()))
         ctx.dims = (S, B, H, HD)
         ctx.drop = (drop_p, seed)
+        ctx.images = images
         ctx.save_for_backward(qkv, out, lse)
         return out
 
@@ -217,16 +220,18 @@ class ListAttentionFn(Function):
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
         S, B, H, HD = ctx.dims
+        images = ctx.images
         dout = N.f32c(dout)
         dqkv = torch.empty_like(qkv)
         ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
         ws = workspace(ws_bytes, qkv.device)
-        call("rlt_list_attention_bwd_delta", ptr(out), ptr(dout), S, B, H, HD, ptr(ws), stream())
         drop_p, seed = ctx.drop
-        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
+        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, stream())
+        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
                                              S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
-        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(ws),
+        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
                                             S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
+        ctx.images = None
         return dqkv, None, None, None, None, None
 
 

@@ -32,14 +32,14 @@ def test_header_symbols_are_exported_and_bound(native):
 def test_workspace_queries_need_no_gpu(native):
     assert native.query("rlt_gemm_workspace", 1, 0, 2048, 256, 1228800) > 0     # split-K slabs for dW
     assert native.query("rlt_gemm_workspace", 0, 1, 1228800, 2048, 256) == 0
-    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64) == 300 * 4096 * 4 * 4
+    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64) >= 300 * 4096 * 4 * 4
     assert native.query("rlt_colsum_workspace", 1000, 64) > 0
 
 
 def test_argument_errors_are_reported_not_crashed(native):
     lib = native.load()
     assert lib.rlt_gemm(0, 1, 0, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None) == -1
+    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None, 0, None) == -1
     assert lib.rlt_heads_fwd(None, None, None, None, 1, 1, 1, 64, None, None) == -1
 
 

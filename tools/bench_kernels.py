@@ -41,12 +41,17 @@ def attention(B=4096, S=60, H=4, HD=64):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(S, H, B, device=dev)
     unit = B * B * HD * S * H / 1e9     # GFLOP per "2*B*B*HD" product /2
-    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 0, ptr(out), ptr(lse), stream()))
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+    images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD)
+    ws = torch.empty(wb // 4 + 4, device=dev)
+    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 0, ptr(out), ptr(lse), ptr(images), ib, stream()))
     print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * unit / ms:7.1f} TF/s", flush=True)
-    call("rlt_list_attention_bwd_delta", ptr(out), ptr(dout), S, B, H, HD, ptr(delta), stream())
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(delta), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, stream()))
+    print(f"attn_bwd_prep B{B} S{S} HD{HD}: {ms:8.3f} ms", flush=True)
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
     print(f"attn_bwd_dkv  B{B} S{S} HD{HD}: {ms:8.3f} ms  {8 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(delta), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
     print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
 
 
