@@ -121,19 +121,19 @@ def main():
     if args.model == "attncut":
         model = hip_models.AttnCut(input_size=3, dropout=0.0).to(dev)
         crit = hip_losses.DivLoss(metric='f1', div_type='js', augmented=True)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "AttnCut + DivLoss(js,f1,augmented)"
+        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "AttnCut + DivLoss(js,f1,augmented) [BASELINE configs[1]]"
     elif args.model == "choopy":
         model = hip_models.Choopy(seq_len=S, dropout=0.0).to(dev)
         crit = hip_losses.ChoopyLoss(metric='f1')
-        n_feat, heads_, hd, layers, wl = 1, 8, 16, 3, "Choopy + ChoopyLoss(f1)"
+        n_feat, heads_, hd, layers, wl = 1, 8, 16, 3, "Choopy + ChoopyLoss(f1) [BASELINE configs[2] at batch 8192]"
     elif args.model == "mtattncut":
         model = hip_models.MtAttnCut(input_size=3, num_tasks=3, dropout=0.0).to(dev)
         crit = hip_losses.MtCutLoss(metric='f1', num_tasks=3)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "MtAttnCut(3 tasks) + MtCutLoss(f1)"
+        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "MtAttnCut(3 tasks) + MtCutLoss(f1) [BASELINE configs[4], one length bucket]"
     else:
         model = hip_models.MMOECut(seq_len=S, num_experts=4, num_tasks=2.1, dropout=0.0).to(dev)
         crit = hip_losses.MtCutLoss(metric='f1', rerank_weight=0.4, classi_weight=0.6, num_tasks=2.1)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 4, "MMOECut(4 experts, tasks 2.1) + MtCutLoss(f1)"
+        n_feat, heads_, hd, layers, wl = 3, 4, 64, 4, "MMOECut(4 experts, tasks 2.1) + MtCutLoss(f1) [BASELINE configs[3]]"
     flat = FlatModel(model)
     flat.broadcast_params()
     opt = FusedAdam(flat, lr=3e-5, weight_decay=0.0014756345581373493)
@@ -202,7 +202,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "f32 (bf16x3 split MFMA products, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S} (BASELINE configs[1]), "
+            "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S}, "
                                    f"full train step incl. Adam and cut metrics", "global_batch": B * world,
                        "seq_len": S, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": kern,

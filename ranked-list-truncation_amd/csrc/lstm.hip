@@ -197,6 +197,222 @@ __global__ __launch_bounds__(1024) void bilstm_bwd_kernel(float* __restrict__ ga
     }
 }
 
+// ======================================================================================================
+// Split-bf16 ("bf16x3") variants: the recurrent products h W_hh^T and W_hh^T dA on v_mfma_f32_32x32x16_bf16 with
+// every operand split into bf16 hi + lo (3 products, fp32 accumulate); W_hh fragments still live in registers
+// (64 VGPRs), h_{t-1} is exchanged through LDS already split.  Gate nonlinearities use v_exp/v_rcp forms.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDH3 = 136;      // bf16 elements per row of the h tile images (272 B)
+
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    v2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+    hi.x = pk2(a, b);
+    hi.y = pk2(c, d);
+    lo.x = pk2(a - __builtin_bit_cast(float, hi.x << 16), b - __builtin_bit_cast(float, hi.x & 0xffff0000u));
+    lo.y = pk2(c - __builtin_bit_cast(float, hi.y << 16), d - __builtin_bit_cast(float, hi.y & 0xffff0000u));
+}
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+    uint2 h0, l0, h1, l1;
+    split4(x[0], x[1], x[2], x[3], h0, l0);
+    split4(x[4], x[5], x[6], x[7], h1, l1);
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+__device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+// sigmoid / tanh on the hardware exp2 + rcp (abs error ~1e-7, far inside the 1e-4 parity bound)
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.f * fsigmoid(2.f * x) - 1.f; }
+
+__global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                           const float* __restrict__ w_hh_r, int S, int B,
+                                                           float* __restrict__ h_out, float* __restrict__ c_out) {
+    __shared__ __attribute__((aligned(16))) uint16_t hs[2][2][LISTS * LDH3];        // [buffer][hi|lo]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+
+    // A operand: W_hh rows of this wavefront (gate l31>>3, unit 8w + (l31&7)); fragment ks covers k = 16ks + 8hh + j
+    bf16x8 wh[8], wl[8];
+    {
+        const float* wp = (dir ? w_hh_r : w_hh_f) + (size_t)((l31 >> 3) * HID + 8 * w + (l31 & 7)) * HID + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4*>(wp + 16 * ks);
+            const float4 v1 = *reinterpret_cast<const float4*>(wp + 16 * ks + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split8(x, wh[ks], wl[ks]);
+        }
+    }
+    for (int i = tid; i < 2 * LISTS * LDH3; i += 1024) (&hs[0][0][0])[i] = 0;       // h_0 = 0 (hi and lo images)
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ucol = 8 * w + 4 * hh;
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < S; ++t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        float4 gin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {      // branch-free: invalid lists read list 0's row and are never stored
+            const float4 tv = *reinterpret_cast<const float4*>(grow + g * HID);
+            gin[g] = valid ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const uint16_t* hph = hs[cur][0] + l31 * LDH3 + 8 * hh;
+        const uint16_t* hpl = hs[cur][1] + l31 * LDH3 + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hph + 16 * ks);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hpl + 16 * ks);
+            acc = mfma3(wh[ks], wl[ks], bh, bl, acc);
+        }
+        const float* gi_ = reinterpret_cast<const float*>(&gin[0]);
+        float act[16], hnew[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = fsigmoid(acc[u] + gi_[u]);
+            const float fg = fsigmoid(acc[4 + u] + gi_[4 + u]);
+            const float gg = ftanh(acc[8 + u] + gi_[8 + u]);
+            const float og = fsigmoid(acc[12 + u] + gi_[12 + u]);
+            c[u] = fg * c[u] + ig * gg;
+            hnew[u] = og * ftanh(c[u]);
+            act[u] = ig; act[4 + u] = fg; act[8 + u] = gg; act[12 + u] = og;
+        }
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(grow + g * HID) = make_float4(act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]);
+            *reinterpret_cast<float4*>(c_out + (tok * 2 + dir) * HID + ucol) = make_float4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+        }
+        uint2 h2, l2;
+        split4(hnew[0], hnew[1], hnew[2], hnew[3], h2, l2);
+        *reinterpret_cast<uint2*>(&hs[cur ^ 1][0][l31 * LDH3 + ucol]) = h2;
+        *reinterpret_cast<uint2*>(&hs[cur ^ 1][1][l31 * LDH3 + ucol]) = l2;
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void bilstm3_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                           const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
+                                                           const float* __restrict__ d_hout, int S, int B) {
+    extern __shared__ __attribute__((aligned(16))) float P[];           // [16][LISTS][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+    const int ucol = 8 * w + 4 * hh;
+
+    // dh = W_hh^T dA.  B operand = this lane's dA registers: k-step s2 <- registers 8*s2..8*s2+7, i.e. element j is the
+    // gate row (2*s2 + (j>>2))*128 + 8w + 4hh + (j&3).  A fragment (tile a, step s2) must hold the same rows of W_hh at
+    // column a*32 + l31.
+    bf16x8 wth[4][2], wtl[4][2];
+    {
+        const float* wp = dir ? w_hh_r : w_hh_f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = wp[(size_t)((2 * s2 + (j >> 2)) * HID + ucol + (j & 3)) * HID + a * 32 + l31];
+                split8(x, wth[a][s2], wtl[a][s2]);
+            }
+    }
+    float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhrec[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int t = S - 1; t >= 0; --t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        float dA[16];
+        {
+            float4 gv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+            const float4 ct4 = *reinterpret_cast<const float4*>(cst + (tok * 2 + dir) * HID + ucol);
+            const size_t tokp = (size_t)(t > 0 ? (dir ? s + 1 : s - 1) : s) * B + (valid ? b : 0);
+            const float4 cpl = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol);
+            const float4 cp4 = t > 0 ? cpl : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 dh4 = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol);
+            const float* gf_ = reinterpret_cast<const float*>(&gv[0]);
+            const float* ct = reinterpret_cast<const float*>(&ct4);
+            const float* cp = reinterpret_cast<const float*>(&cp4);
+            const float* dho = reinterpret_cast<const float*>(&dh4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = gf_[u], fg = gf_[4 + u], gg = gf_[8 + u], og = gf_[12 + u];
+                const float dh = dho[u] + dhrec[u];
+                const float tc = ftanh(ct[u]);
+                const float dcu = dc[u] + dh * og * (1.f - tc * tc);
+                dA[u] = valid ? dcu * gg * ig * (1.f - ig) : 0.f;
+                dA[4 + u] = valid ? dcu * cp[u] * fg * (1.f - fg) : 0.f;
+                dA[8 + u] = valid ? dcu * ig * (1.f - gg * gg) : 0.f;
+                dA[12 + u] = valid ? dh * tc * og * (1.f - og) : 0.f;
+                dc[u] = dcu * fg;
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(grow + g * HID) = make_float4(dA[4 * g], dA[4 * g + 1], dA[4 * g + 2], dA[4 * g + 3]);
+            }
+        }
+        if (t == 0) break;
+        bf16x8 dah[2], dal[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float x[8] = {dA[8 * s2 + 0], dA[8 * s2 + 1], dA[8 * s2 + 2], dA[8 * s2 + 3],
+                                dA[8 * s2 + 4], dA[8 * s2 + 5], dA[8 * s2 + 6], dA[8 * s2 + 7]};
+            split8(x, dah[s2], dal[s2]);
+        }
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                acc0 = mfma3(wth[2 * rd][s2], wtl[2 * rd][s2], dah[s2], dal[s2], acc0);
+                acc1 = mfma3(wth[2 * rd + 1][s2], wtl[2 * rd + 1][s2], dah[s2], dal[s2], acc1);
+            }
+            float* pw = P + (size_t)(w * LISTS + l31) * LDP + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(pw + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+                *reinterpret_cast<float4*>(pw + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+            }
+            __syncthreads();
+            if ((w >> 3) == rd) {
+                const float* pr = P + (size_t)l31 * LDP + 8 * (w & 7) + 4 * hh;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ww = 0; ww < 16; ++ww) {
+                    const float4 v = *reinterpret_cast<const float4*>(pr + (size_t)ww * LISTS * LDP);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+                dhrec[0] = sum.x; dhrec[1] = sum.y; dhrec[2] = sum.z; dhrec[3] = sum.w;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,8 +422,12 @@ int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_re
     RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
     if (!(rlt_aligned16(gates) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(h_out) && rlt_aligned16(c_out)))
         return RLT_E_ALIGN;
-    hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
-                       gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
+    if (rlt_precision() == RLT_PRECISION_BF16X3)
+        hipLaunchKernelGGL(bilstm3_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
+                           gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
+    else
+        hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
+                           gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
     return RLT_LAUNCH_RESULT();
 }
 
@@ -218,9 +438,14 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
         return RLT_E_ALIGN;
     const size_t shm = (size_t)16 * LISTS * LDP * sizeof(float);
     int rc = rlt_allow_lds(bilstm_bwd_kernel, shm);
+    if (!rc) rc = rlt_allow_lds(bilstm3_bwd_kernel, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
-                       gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
+    if (rlt_precision() == RLT_PRECISION_BF16X3)
+        hipLaunchKernelGGL(bilstm3_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
+                           gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
+    else
+        hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
+                           gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
     return RLT_LAUNCH_RESULT();
 }
 
