@@ -196,6 +196,17 @@ def main():
             kern, products, mult, peak = "attn3_bwd_dv_kernel<%d> + attn3_bwd_dk_kernel<%d>" % (hd, hd), 5, 3, PEAK_BF16_MFMA_TFLOPS
         algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
         achieved = algorithmic * mult
+        # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
+        # same command (profiles/r01_e_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction applied); only quoted for the
+        # exact workload it was measured on
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_e_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if args.model == "attncut" and B == 4096 and S == 300 and precision == "bf16x3":
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ranked-lists/sec (fwd+bwd) at len=300; F1@k vs CPU ref",
             "value": round(value, 2), "unit": "lists/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,7 +218,7 @@ def main():
                        "seq_len": S, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "algorithmic_tflops": round(algorithmic, 2), "mfma_products_per_fp32_product": mult,
                          "launch_ms": round(ms, 3), "launches_timed": launches,
                          "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name}},
