@@ -57,9 +57,9 @@ class FlatModel:
         world = dist.get_world_size(group)
         if world == 1:
             return
-        if self.flat_grad.is_cuda:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)     # RCCL
-        else:                                                                       # gloo (CPU tests)
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)     # RCCL over xGMI
+        else:                                                                       # gloo (CPU tests, rehearsals)
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.mul_(1.0 / world)
 
