@@ -61,8 +61,10 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
             bool ok;
             if (KC) { r = mn0 + idx / (BK / 4); c = k0 + 4 * (idx % (BK / 4)); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
             else { r = k0 + (idx >> 5); c = mn0 + 4 * (idx & 31); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
-            const float4 t = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
-            v.x = ok ? t.x : 0.f; v.y = ok ? t.y : 0.f; v.z = ok ? t.z : 0.f; v.w = ok ? t.w : 0.f;
+            // NOTE: the zero-select for out-of-range lanes is applied in store_tile, NOT here: consuming the
+            // loaded value right away would put an s_waitcnt directly behind the load and expose its latency
+            (void)ok;
+            v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
         } else if (KC) {
             const int row = mn0 + idx / (BK / 4), kk = k0 + 4 * (idx % (BK / 4));
             if (row < MN) {
@@ -91,6 +93,19 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
             }
         }
         reg[i] = v;
+    }
+}
+
+// FAST path: zero, in place, the lanes whose (clamped) load was out of range - called just before the registers
+// are consumed (LDS store / bias-gradient side sum), i.e. as late as possible
+template <bool KC, int BK>
+__device__ __forceinline__ void mask_tile(float4 (&reg)[BK / 8], int tid, int mn0, int k0, int MN, int Kend) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        const int idx = tid + 256 * i;
+        const bool ok = KC ? (mn0 + idx / (BK / 4) < MN && k0 + 4 * (idx % (BK / 4)) < Kend)
+                           : (k0 + (idx >> 5) < Kend && mn0 + 4 * (idx & 31) < MN);
+        reg[i] = make_float4(ok ? reg[i].x : 0.f, ok ? reg[i].y : 0.f, ok ? reg[i].z : 0.f, ok ? reg[i].w : 0.f);
     }
 }
 
@@ -193,9 +208,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     // A operand: TA=0 -> stored [M][K] (K contiguous); B operand: TB=1 -> stored [N][K] (K contiguous)
     load_tile<!TA, BK, FAST>(g.A, g.lda, m0, kbeg, g.M, kend, g.vecA, tid, ra);
     load_tile<TB, BK, FAST>(g.B, g.ldb, n0, kbeg, g.N, kend, g.vecB, tid, rb);
-    store_tile<!TA, BK>(As[0], tid, ra);
-    store_tile<TB, BK>(Bs[0], tid, rb);
-    __syncthreads();
 
     // bias gradient on the side: this thread's A elements are 4 consecutive m at fixed k rows
     const bool want_cs = TA && g.colsum != nullptr && tn == 0;
@@ -204,7 +216,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < BK / 8; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
     };
-    if (want_cs) add_cs();
+    auto consume = [&](int k0, int buf) {        // mask (fast path), bias-gradient side sum, LDS store
+        __builtin_amdgcn_sched_barrier(0);       // do not hoist the first use of the loaded registers above the MFMAs
+        if (FAST) {
+            mask_tile<!TA, BK>(ra, tid, m0, k0, g.M, kend);
+            mask_tile<TB, BK>(rb, tid, n0, k0, g.N, kend);
+        }
+        if (want_cs) add_cs();
+        store_tile<!TA, BK>(As[buf], tid, ra);
+        store_tile<TB, BK>(Bs[buf], tid, rb);
+    };
+    consume(kbeg, 0);
+    __syncthreads();
 
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -212,7 +235,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
         if (more) {
             load_tile<!TA, BK, FAST>(g.A, g.lda, m0, k0 + BK, g.M, kend, g.vecA, tid, ra);
             load_tile<TB, BK, FAST>(g.B, g.ldb, n0, k0 + BK, g.N, kend, g.vecB, tid, rb);
-            if (want_cs) add_cs();
         }
         const float* a_ = As[buf] + wm * 64 + l31;
         const float* b_ = Bs[buf] + wn * 64 + l31;
@@ -226,10 +248,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
             acc[1][1] = mfma32(a1, b1, acc[1][1]);
         }
-        if (more) {
-            store_tile<!TA, BK>(As[buf ^ 1], tid, ra);
-            store_tile<TB, BK>(Bs[buf ^ 1], tid, rb);
-        }
+        if (more) consume(k0 + BK, buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -280,8 +299,8 @@ __device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int m
             bool ok;
             if (KC) { const int idx = tid + 256 * i; r = mn0 + (idx >> 3); c = k0 + 4 * (idx & 7); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
             else { r = k0 + 4 * (tid >> 5) + i; c = mn0 + 4 * (tid & 31); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
-            const float4 t = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
-            v.x = ok ? t.x : 0.f; v.y = ok ? t.y : 0.f; v.z = ok ? t.z : 0.f; v.w = ok ? t.w : 0.f;
+            (void)ok;          // the zero-select is applied by mask3 just before the registers are consumed
+            v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
         } else if (KC) {       // [MN][K]: idx -> (row, 4 consecutive k)
             const int idx = tid + 256 * i;
             const int row = mn0 + (idx >> 3), kk = k0 + 4 * (idx & 7);
@@ -309,6 +328,17 @@ __device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int m
             }
         }
         st.v[i] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void mask3(Stage3& st, int tid, int mn0, int k0, int MN, int Kend) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bool ok;
+        if (KC) { const int idx = tid + 256 * i; ok = mn0 + (idx >> 3) < MN && k0 + 4 * (idx & 7) < Kend; }
+        else ok = k0 + 4 * (tid >> 5) + i < Kend && mn0 + 4 * (tid & 31) < MN;
+        st.v[i] = make_float4(ok ? st.v[i].x : 0.f, ok ? st.v[i].y : 0.f, ok ? st.v[i].z : 0.f, ok ? st.v[i].w : 0.f);
     }
 }
 
@@ -376,12 +406,22 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         const int k0 = kbeg + t * BK3;
         load3<!TA, FAST>(g.A, g.lda, m0, k0, g.M, kend, g.vecA, tid, sa);
         load3<TB, FAST>(g.B, g.ldb, n0, k0, g.N, kend, g.vecB, tid, sb);
+    };
+    // consume tile t's registers: mask (fast path), bias-gradient side sum, split + LDS store.  Nothing touches
+    // the loaded values before this point, so the loads stay in flight across the MFMA block.
+    auto stash = [&](int t, int buf, Stage3& sa, Stage3& sb) {
+        // keep the compiler from hoisting the first use of the loaded registers (and with it their s_waitcnt)
+        // above the MFMA block that is meant to hide the load latency
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = kbeg + t * BK3;
+        if (FAST) {
+            mask3<!TA>(sa, tid, m0, k0, g.M, kend);
+            mask3<TB>(sb, tid, n0, k0, g.N, kend);
+        }
         if (want_cs) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
         }
-    };
-    auto stash = [&](int buf, const Stage3& sa, const Stage3& sb) {
         uint16_t* nb = lds + buf * 4 * TILE3;
         store3<!TA>(nb + 0 * TILE3, nb + 1 * TILE3, tid, sa);
         store3<TB>(nb + 2 * TILE3, nb + 3 * TILE3, tid, sb);
@@ -412,18 +452,18 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     };
     const int nt = (kend - kbeg + BK3 - 1) / BK3;
     fetch(0, a0, b0);
-    stash(0, a0, b0);
+    stash(0, 0, a0, b0);
     if (nt > 1) fetch(1, a0, b0);
     if (nt > 2) fetch(2, a1, b1);
     __syncthreads();
     for (int t = 0; t < nt; t += 2) {
         multiply(0);                                   // tile t;   regs0 = tile t+1, regs1 = tile t+2 (in flight)
-        if (t + 1 < nt) stash(1, a0, b0);
+        if (t + 1 < nt) stash(t + 1, 1, a0, b0);
         if (t + 3 < nt) fetch(t + 3, a0, b0);
         __syncthreads();
         if (t + 1 >= nt) break;
         multiply(1);                                   // tile t+1; regs1 = tile t+2, regs0 = tile t+3 (in flight)
-        if (t + 2 < nt) stash(0, a1, b1);
+        if (t + 2 < nt) stash(t + 2, 0, a1, b1);
         if (t + 4 < nt) fetch(t + 4, a1, b1);
         __syncthreads();
     }

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
         float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
         float4 gin[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            gin[g] = valid ? *reinterpret_cast<const float4*>(grow + g * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < 4; ++g)        // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
+            gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
 
         f32x16 acc;
 #pragma unroll
@@ -265,10 +265,8 @@ __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ g
         float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
         float4 gin[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {      // branch-free: invalid lists read list 0's row and are never stored
-            const float4 tv = *reinterpret_cast<const float4*>(grow + g * HID);
-            gin[g] = valid ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int g = 0; g < 4; ++g)        // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
+            gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;

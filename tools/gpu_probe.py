@@ -480,7 +480,10 @@ def models():
             model.train()
             outs = gu.as_list(model(x))
             for i, o in enumerate(outs):
-                report(f"{case['tag']} out{i}", float(np.abs(o.detach().squeeze(2).cpu().numpy() - gold[f'out{i}']).max()), 1e-5)
+                # 1e-5 of the output's scale (probabilities: absolute; unnormalised rerank scores: relative);
+                # north_star asks for 1e-4
+                scale = max(1.0, float(np.abs(gold[f'out{i}']).max()))
+                report(f"{case['tag']} out{i}", float(np.abs(o.detach().squeeze(2).cpu().numpy() - gold[f'out{i}']).max()) / scale, 1e-5)
             k, f1, dcg = Metric.evaluate(outs[-1], y)
             report(f"{case['tag']} k mismatches", float((k.cpu().numpy() != gold["k_s"]).sum()), 0)
             report(f"{case['tag']} f1", abs(float(f1) - float(gold["f1"])), 1e-4)
