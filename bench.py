@@ -80,6 +80,12 @@ def cpu_baseline(seq_len, sample_batch, steps):
                       f"batch 4096 is higher than at this sample"}
 
 
+def step_algorithmic_flops(model, B, S):
+    """AttnCut fwd FLOPs per token = 3,676,672 + 1024*L (L = lists the attention spans); fwd+bwd = 3x."""
+    assert model == "attncut"
+    return 3.0 * (3676672 + 1024 * B) * S * B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,18 +197,24 @@ def main():
         ksum = timer.summary()
         # dominant launch: the attention dK/dV backward (one rlt_list_attention_bwd_dkv call).
         #   fp32 mode  : one kernel, 4 MFMA products of 2*B*B*HD per (position, head) on the f32 MFMA
-        #   bf16x3 mode: two kernels (dV: S,dV; dK: S,dP,dK) = 5 products, each executed as 3 bf16 MFMA products
-        # `achieved` = MFMA FLOPs the launch executes / its HIP-event time; `algorithmic` = the fp32-level FLOPs
-        # (products x 2*B*B*HD*S*H) / time.  DESIGN.md section 5 "roofline accounting".
+        #   bf16x3 mode: one fused kernel (S, dP, dV, dK) = 4 products, each executed as 3 bf16 MFMA products
+        # `achieved` = ALGORITHMIC fp32-level FLOPs of the launch (products x 2*B*B*HD*S*H) / its HIP-event time.
+        # `peak` = the dense MFMA peak of the arithmetic the launch runs in: 157.3 TF/s (f32 MFMA) in fp32 mode;
+        # in bf16x3 mode every fp32 product costs 3 bf16 MFMA products, so the peak for fp32-level FLOPs is
+        # 2500/3 = 833.3 TF/s (`executed_bf16_tflops` / 2500 is the same fraction).  DESIGN.md section 5.
         name = "attn_bwd_dkv"
         launches, ms = ksum.get(name, (0, float("nan")))
         unit_flops = 2.0 * B * B * hd * S * heads_
         if precision == "fp32":
             kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2>" % hd, 4, 1, PEAK_F32_MFMA_TFLOPS
         else:
-            kern, products, mult, peak = "attn3_bwd_dv_kernel<%d> + attn3_bwd_dk_kernel<%d>" % (hd, hd), 5, 3, PEAK_BF16_MFMA_TFLOPS
+            kern, products, mult, peak = "attn3_bwd_dkv_kernel<%d,false>" % hd, 4, 3, PEAK_BF16_MFMA_TFLOPS
         algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
-        achieved = algorithmic * mult
+        achieved, executed = algorithmic, algorithmic * mult
+        peak = round(peak / mult, 1)
+        # whole-step fractions SURVEY.md 8(d) asks for beside the kernel's: algorithmic fwd+bwd FLOPs and bytes per list
+        step_flop = step_algorithmic_flops(args.model, B, S) if args.model == "attncut" else None
+        step_bytes = 16.0e6 * B if args.model == "attncut" else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
         # same command (profiles/r01_e_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction applied); only quoted for the
         # exact workload it was measured on
@@ -226,9 +238,17 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "algorithmic_tflops": round(algorithmic, 2), "mfma_products_per_fp32_product": mult,
+                         "executed_bf16_tflops": round(executed, 2) if mult > 1 else None,
+                         "mfma_products_per_fp32_product": mult,
                          "launch_ms": round(ms, 3), "launches_timed": launches,
-                         "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name}},
+                         "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name},
+                         "whole_step": None if step_flop is None else {
+                             "algorithmic_tflop": round(step_flop / 1e12, 2),
+                             "tflops": round(step_flop / (ms_per_step * 1e-3) / 1e12, 1),
+                             "frac_of_f32_mfma_peak": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                             "algorithmic_GB": round(step_bytes / 1e9, 1),
+                             "hbm_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 8.0e12, 4)}},
             "train_state": {"loss": round(float(loss.detach()), 6), "f1": round(float(f1), 6), "dcg": round(float(dcg), 6)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = rlt_exp2(m_run - m_new);
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(sc[sub][r] - m_new);
+                    const float p = rlt_exp2(sc[sub][r] - m_new);
                     sc[sub][r] = p;
                     psum += p;
                 }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
                     const bool ok = t * KT + ql < B;
-                    const float p = ok ? exp2f(sc[r] - lt_[ql]) : 0.f;
+                    const float p = ok ? rlt_exp2(sc[r] - lt_[ql]) : 0.f;
                     float pd = p, dpr = dp[r];
                     if (a.drop_p > 0.f) {
                         const bool keep = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = t * KT + sub * 32 + acc_row(r, hh);
-                    const float p = kidx < B ? exp2f(sc[r] - lse2) : 0.f;
+                    const float p = kidx < B ? rlt_exp2(sc[r] - lse2) : 0.f;
                     float dpr = dp[r];
                     if (a.drop_p > 0.f)
                         dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;

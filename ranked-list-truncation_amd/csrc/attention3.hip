@@ -257,14 +257,14 @@ __device__ __forceinline__ const uint8_t* record(const uint8_t* img, int m, int 
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
     constexpr int STAGE = Rec<HD>::RP + Rec<HD>::TP;                        // K rows pair | V transposed pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const int nt = rlt_cdiv_dev(B, KT);
     const int ntile = rlt_cdiv_dev(B, QT3);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = rlt_exp2(m_run - m_new);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -333,11 +333,11 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(sc[sub][r] - m_new);
+                    const float p = rlt_exp2(sc[sub][r] - m_new);
                     sc[sub][r] = p;
                     psum += p;
                 }
-                if (a.drop_p > 0.f) {
+                if (DROP) {
                     const uint32_t ps = pair_seed(a.seed, pair);
                     const float inv_keep = 1.f / (1.f - a.drop_p);
 #pragma unroll
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     constexpr int STAGE = KREC + Rec<HD>::RP;                               // ... | V rows pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
     const int nt = rlt_cdiv_dev(B, KT);
@@ -381,6 +381,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     const int q = qt * QT3 + wv * 32 + l31;
     const bool wave_live = qt * QT3 + wv * 32 < B;
     const int qc = min(q, B - 1);
+    const uint32_t ps = pair_seed(a.seed, pair);
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
     bf16x8 qh[HD / 16], ql[HD / 16], doh[HD / 16], dol[HD / 16];
     const int qtile = min(q >> 6, nt - 1);
@@ -418,13 +420,18 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
                 sc = mma_rows<HD>(kr_hi, kr_lo, sub, l31, hh, qh, ql, sc);       // S^T[key][q]
                 dp = mma_rows<HD>(vr_hi, vr_lo, sub, l31, hh, doh, dol, dp);     // dP^T[key][q]
+                if (t == nt - 1) {            // only the last tile can hold keys beyond B
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[r] = -INFINITY;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = t * KT + sub * 32 + acc_row(r, hh);
-                    const float p = kidx < B ? exp2f(sc[r] - lse2) : 0.f;
+                    const float p = rlt_exp2(sc[r] - lse2);
                     float dpr = dp[r];
-                    if (a.drop_p > 0.f)
-                        dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
+                    if (DROP)
+                        dpr = rlt_keep(ps, (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr * inv_keep : 0.f;
                     dp[r] = p * (dpr - del);                                       // dS^T
                 }
                 mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);                     // dQ^T[d][q] += K^T dS^T
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
 
 // ------------------------------------------------------------------------------------------ dV
 // workgroup = 256 keys, loops over 64-query tiles: dV^T[d][key] += dO^T P with P recomputed from the LSE
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
     constexpr int STAGE = Rec<HD>::RP + DPART;                              // Q rows pair | ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
     const int nt = rlt_cdiv_dev(B, KT);
@@ -456,6 +463,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
     const int s = pair / H, h = pair % H;
     const int key = ktile * QT3 + wv * 32 + l31;
     const bool wave_live = ktile * QT3 + wv * 32 < B;
+    const uint32_t ps = pair_seed(a.seed, pair);
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
     bf16x8 kh[HD / 16], kl[HD / 16];
     image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, min(key >> 6, nt - 1)), key & 63, hh, kh, kl);
@@ -489,9 +498,10 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
-                    float p = (t * KT + ql < B) ? exp2f(sc[r] - Ls[ql]) : 0.f;
-                    if (a.drop_p > 0.f)
-                        p = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? p / (1.f - a.drop_p) : 0.f;
+                    // queries beyond B need no mask: their columns of the transposed dO image are zero, p is finite
+                    float p = rlt_exp2(sc[r] - Ls[ql]);
+                    if (DROP)
+                        p = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? p * inv_keep : 0.f;
                     sc[r] = p;
                 }
                 mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
 }
 
 // ------------------------------------------------------------------------------------------ dK
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
     constexpr int STAGE = QREC + Rec<HD>::RP + Rec<HD>::AUX;                // ... | dO rows pair | aux
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
     const size_t ld = (size_t)3 * E;
     const int nt = rlt_cdiv_dev(B, KT);
@@ -522,6 +532,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
     const int s = pair / H, h = pair % H;
     const int key = ktile * QT3 + wv * 32 + l31;
     const bool wave_live = ktile * QT3 + wv * 32 < B;
+    const uint32_t ps = pair_seed(a.seed, pair);
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
     bf16x8 kh[HD / 16], kl[HD / 16], vh[HD / 16], vl[HD / 16];
     const int ktl = min(key >> 6, nt - 1);
@@ -563,10 +575,11 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
-                    const float p = (t * KT + ql < B) ? exp2f(sc[r] - Ls[ql]) : 0.f;
+                    // queries beyond B need no mask: their columns of the transposed Q image are zero, p is finite
+                    const float p = rlt_exp2(sc[r] - Ls[ql]);
                     float dpr = dp[r];
-                    if (a.drop_p > 0.f)
-                        dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
+                    if (DROP)
+                        dpr = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? dpr * inv_keep : 0.f;
                     dp[r] = p * (dpr - Es[ql]);                                    // dS
                 }
                 mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
@@ -579,9 +592,99 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + E, hh, dk, LN2);
 }
 
+// ------------------------------------------------------------------------------------------ dK + dV fused
+// One pass over the query tiles computes S and P once for both gradients (4 products per tile instead of the 5 of
+// the separate dV and dK kernels); ~200 unified VGPRs, one 512-thread workgroup per CU.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
+    const AttnArgs& a = g.a;
+    constexpr int DT = (HD + 31) / 32;
+    constexpr int QREC = Rec<HD>::RP + Rec<HD>::TP;                         // Q rows pair | Q transposed pair
+    constexpr int STAGE = 2 * QREC + Rec<HD>::AUX;                          // ... | dO rows pair | dO transposed pair | aux
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
+    const size_t ld = (size_t)3 * E;
+    const int nt = rlt_cdiv_dev(B, KT);
+    const int ntile = rlt_cdiv_dev(B, QT3);
+    int pair, ktile;
+    map_block(blockIdx.x, npair, ntile, pair, ktile);
+    const int s = pair / H, h = pair % H;
+    const int key = ktile * QT3 + wv * 32 + l31;
+    const bool wave_live = ktile * QT3 + wv * 32 < B;
+    const uint32_t ps = pair_seed(a.seed, pair);
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    bf16x8 kh[HD / 16], kl[HD / 16], vh[HD / 16], vl[HD / 16];
+    const int ktl = min(key >> 6, nt - 1);
+    image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, ktl), key & 63, hh, kh, kl);
+    image_row_frags<HD>(record<HD>(g.img, 2, npair, nt, pair, ktl), key & 63, hh, vh, vl);
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+    auto issue = [&](int t, int buf) {
+        dma_copy<QREC>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<STAGE - QREC>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
+    };
+    issue(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
+        if (wave_live) {
+            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
+            const uint16_t* qt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
+            const uint16_t* qt_lo = qt_hi + T_elems<HD>();
+            const uint16_t* dr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC);
+            const uint16_t* dr_lo = dr_hi + rows_elems<HD>();
+            const uint16_t* dt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC + Rec<HD>::RP);
+            const uint16_t* dt_lo = dt_hi + T_elems<HD>();
+            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + 2 * QREC);
+            const float* Es = Ls + KT;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] (Q carries scale*log2e)
+                dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key]
+                // queries beyond B need no mask: their columns of the transposed Q / dO images are zero, p is finite
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + acc_row(r, hh);
+                    float p = rlt_exp2(sc[r] - Ls[ql]);
+                    float dpr = dp[r];
+                    if (DROP) {
+                        const bool keep = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
+                        dpr = keep ? dpr * inv_keep : 0.f;
+                        dp[r] = p * (dpr - Es[ql]);                                // dS uses the undropped p
+                        p = keep ? p * inv_keep : 0.f;
+                    } else {
+                        dp[r] = p * (dpr - Es[ql]);
+                    }
+                    sc[r] = p;
+                }
+                mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
+                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
+            }
+        }
+        __syncthreads();
+    }
+    if (!wave_live || key >= B) return;
+    float* row = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
+    store_acc_T<HD>(row + E, hh, dk, LN2);          // the Q image carries c = scale*log2e: dK = ln2 * dS^T (cQ)
+    store_acc_T<HD>(row + 2 * E, hh, dv, 1.f);
+}
+
 template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP); }
 template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP); }
 template <int HD> size_t dv3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
+template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX); }
 template <int HD> size_t dk3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
 
 template <int HD>
@@ -593,22 +696,28 @@ int prepare3(const PrepArgs& p, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
-template <int HD>
+template <int HD, bool DROP>
 int launch3(int which, const Attn3Args& g, hipStream_t st) {
     const AttnArgs& a = g.a;
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT3);
     int rc;
     if (which == 0) {
-        if ((rc = rlt_allow_lds(attn3_fwd_kernel<HD>, fwd3_smem<HD>()))) return rc;
-        hipLaunchKernelGGL(attn3_fwd_kernel<HD>, dim3(grid), dim3(512), fwd3_smem<HD>(), st, g);
+        if ((rc = rlt_allow_lds(attn3_fwd_kernel<HD, DROP>, fwd3_smem<HD>()))) return rc;
+        hipLaunchKernelGGL((attn3_fwd_kernel<HD, DROP>), dim3(grid), dim3(512), fwd3_smem<HD>(), st, g);
     } else if (which == 1) {
-        if ((rc = rlt_allow_lds(attn3_bwd_dv_kernel<HD>, dv3_smem<HD>()))) return rc;
-        if ((rc = rlt_allow_lds(attn3_bwd_dk_kernel<HD>, dk3_smem<HD>()))) return rc;
-        hipLaunchKernelGGL(attn3_bwd_dv_kernel<HD>, dim3(grid), dim3(512), dv3_smem<HD>(), st, g);
-        hipLaunchKernelGGL(attn3_bwd_dk_kernel<HD>, dim3(grid), dim3(512), dk3_smem<HD>(), st, g);
+        static const bool split = getenv("RLT_ATTN_SPLIT_DKV") != nullptr;      // experiment switch: separate dV and dK kernels
+        if (split) {
+            if ((rc = rlt_allow_lds(attn3_bwd_dv_kernel<HD, DROP>, dv3_smem<HD>()))) return rc;
+            if ((rc = rlt_allow_lds(attn3_bwd_dk_kernel<HD, DROP>, dk3_smem<HD>()))) return rc;
+            hipLaunchKernelGGL((attn3_bwd_dv_kernel<HD, DROP>), dim3(grid), dim3(512), dv3_smem<HD>(), st, g);
+            hipLaunchKernelGGL((attn3_bwd_dk_kernel<HD, DROP>), dim3(grid), dim3(512), dk3_smem<HD>(), st, g);
+        } else {
+            if ((rc = rlt_allow_lds(attn3_bwd_dkv_kernel<HD, DROP>, dkv3_smem<HD>()))) return rc;
+            hipLaunchKernelGGL((attn3_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(512), dkv3_smem<HD>(), st, g);
+        }
     } else {
-        if ((rc = rlt_allow_lds(attn3_bwd_dq_kernel<HD>, dq3_smem<HD>()))) return rc;
-        hipLaunchKernelGGL(attn3_bwd_dq_kernel<HD>, dim3(grid), dim3(512), dq3_smem<HD>(), st, g);
+        if ((rc = rlt_allow_lds(attn3_bwd_dq_kernel<HD, DROP>, dq3_smem<HD>()))) return rc;
+        hipLaunchKernelGGL((attn3_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(512), dq3_smem<HD>(), st, g);
     }
     return RLT_LAUNCH_RESULT();
 }
@@ -632,7 +741,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         p.out = (uint8_t*)dimages; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 1;
         return prepare3<HD>(p, st);
     }
-    return launch3<HD>(which, g, st);
+    return a.drop_p > 0.f ? launch3<HD, true>(which, g, st) : launch3<HD, false>(which, g, st);
 }
 
 }  // namespace

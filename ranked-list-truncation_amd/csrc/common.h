@@ -30,6 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- wavefront (64 lanes) reductions / scans ------------------------------------------------
+// raw v_exp_f32 (2^x, 1 ulp): unlike exp2f() no denormal-range rescue sequence (6 extra VALU ops); results
+// below 2^-126 flush to zero, which every caller (softmax weights, sigmoid) tolerates
+__device__ __forceinline__ float rlt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

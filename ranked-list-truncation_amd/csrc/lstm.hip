@@ -229,7 +229,7 @@ __device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 
     return c;
 }
 // sigmoid / tanh on the hardware exp2 + rcp (abs error ~1e-7, far inside the 1e-4 parity bound)
-__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + rlt_exp2(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.f * fsigmoid(2.f * x) - 1.f; }
 
 __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_voi
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "csrc", "librlt_hip.so")
+LIB_PATH = os.environ.get("RLT_HIP_LIB") or os.path.join(_PKG, "csrc", "librlt_hip.so")   # env override: kernel experiments
 
 # constants of include/rlt_hip.h
 METRIC_F1, METRIC_DCG = 0, 1
