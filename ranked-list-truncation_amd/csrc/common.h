@@ -83,3 +83,36 @@ __host__ __device__ __forceinline__ uint32_t rlt_drop_threshold(float p) {
 __host__ __device__ __forceinline__ bool rlt_keep(uint32_t seed, uint32_t a, uint32_t b, uint32_t thr) {
     return rlt_rng(seed, a, b) >= thr;
 }
+
+// ---- deterministic column sums of a tall partial matrix -------------------------------------------------
+// out[col] (+)= sum_{r < R} partial[r * ld + col] for col < ncol; columns >= split go to out1[col - split].
+// One 256-thread workgroup per 16 columns: 16 row lanes x 16 columns, four loads in flight per lane, then a
+// fixed-order LDS reduction over the row lanes (bitwise reproducible).  Launch with grid = cdiv(ncol, 16).
+static __global__ __launch_bounds__(256) void rlt_rows_reduce_kernel(const float* __restrict__ partial, int R, int ld, int ncol,
+                                                                     int split, float* __restrict__ out0,
+                                                                     float* __restrict__ out1, int accumulate) {
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < ncol) {
+        const float* p = partial + col;
+        int r = ry;
+        for (; r + 48 < R; r += 64) {
+            a0 += p[(size_t)r * ld];
+            a1 += p[(size_t)(r + 16) * ld];
+            a2 += p[(size_t)(r + 32) * ld];
+            a3 += p[(size_t)(r + 48) * ld];
+        }
+        for (; r < R; r += 16) a0 += p[(size_t)r * ld];
+    }
+    red[ry][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && col < ncol) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += red[i][cx];
+        float* dst = col < split ? out0 + col : out1 + (col - split);
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}

@@ -486,24 +486,62 @@ int launch_gemm3(const GemmArgs& g, dim3 grid, hipStream_t st) {
     return launch_gemm3_v<TA, TB, false>(g, grid, st);
 }
 
-// C = sum_z slab[z] (+bias, relu, accumulate); fixed order => deterministic
+// C = sum_z slab[z] (+bias, relu, accumulate); fixed order => deterministic.  Four independent partial sums per
+// element keep four slab loads in flight (the z loop is otherwise one dependent chain of L2/HBM latencies).
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int nsplit) {
     const size_t mn = (size_t)g.M * g.N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int z = 0; z < nsplit; ++z) v += g.slab[(size_t)z * mn + i];
-        const int row = (int)(i / g.N), col = (int)(i - (size_t)row * g.N);
-        float bv = 0.f;
-        if (g.bias) bv += g.bias[col];
-        if (g.bias2) bv += g.bias2[col];
-        float* dst = g.C + (size_t)row * g.ldc + col;
-        *dst = gemm_epilogue(g, v, bv, row, col, dst);
+    const size_t stride = (size_t)gridDim.x * 256;
+    if ((g.N & 3) == 0) {                     // rows hold whole float4s: a vector never straddles two rows
+        const float4* slab4 = reinterpret_cast<const float4*>(g.slab);
+        const size_t mn4 = mn / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += stride) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int z = 0;
+            for (; z + 3 < nsplit; z += 4) {
+                a0 = f4add(a0, slab4[(size_t)z * mn4 + i]);
+                a1 = f4add(a1, slab4[(size_t)(z + 1) * mn4 + i]);
+                a2 = f4add(a2, slab4[(size_t)(z + 2) * mn4 + i]);
+                a3 = f4add(a3, slab4[(size_t)(z + 3) * mn4 + i]);
+            }
+            for (; z < nsplit; ++z) a0 = f4add(a0, slab4[(size_t)z * mn4 + i]);
+            const float4 v4 = f4add(f4add(a0, a1), f4add(a2, a3));
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const int row = (int)((4 * i) / g.N), col0 = (int)(4 * i - (size_t)row * g.N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = col0 + e;
+                float bv = 0.f;
+                if (g.bias) bv += g.bias[col];
+                if (g.bias2) bv += g.bias2[col];
+                float* dst = g.C + (size_t)row * g.ldc + col;
+                *dst = gemm_epilogue(g, v[e], bv, row, col, dst);
+            }
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += stride) {
+            float v = 0.f;
+            for (int z = 0; z < nsplit; ++z) v += g.slab[(size_t)z * mn + i];
+            const int row = (int)(i / g.N), col = (int)(i - (size_t)row * g.N);
+            float bv = 0.f;
+            if (g.bias) bv += g.bias[col];
+            if (g.bias2) bv += g.bias2[col];
+            float* dst = g.C + (size_t)row * g.ldc + col;
+            *dst = gemm_epilogue(g, v, bv, row, col, dst);
+        }
     }
     if (g.cs_slab)
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)g.M; i += (size_t)gridDim.x * 256) {
-            float v = 0.f;
-            for (int z = 0; z < nsplit; ++z) v += g.cs_slab[(size_t)z * g.M + i];
-            g.colsum[i] = v;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)g.M; i += stride) {
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            int z = 0;
+            for (; z + 3 < nsplit; z += 4) {
+                c0 += g.cs_slab[(size_t)z * g.M + i];
+                c1 += g.cs_slab[(size_t)(z + 1) * g.M + i];
+                c2 += g.cs_slab[(size_t)(z + 2) * g.M + i];
+                c3 += g.cs_slab[(size_t)(z + 3) * g.M + i];
+            }
+            for (; z < nsplit; ++z) c0 += g.cs_slab[(size_t)z * g.M + i];
+            g.colsum[i] = (c0 + c1) + (c2 + c3);
         }
 }
 
@@ -573,15 +611,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (threadIdx.x < 64 && col < N)
         partial[(size_t)blockIdx.y * N + col] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nchunk, int N,
-                                                           float* __restrict__ out, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
-    float acc = 0.f;
-    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * N + col];
-    out[col] = accumulate ? out[col] + acc : acc;
-}
-
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const float* __restrict__ X, int ldx, int R, int N,
                                                              float* __restrict__ out, int ldo, int accumulate) {
     const int g = blockIdx.x;
@@ -696,7 +725,7 @@ int rlt_colsum(const float* X, int ldx, int T, int N, float* out, int accumulate
     const int nchunk = rlt_cdiv(T, CS_ROWS_PER_WG);
     hipStream_t st = rlt_stream(stream);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(rlt_cdiv(N, 64), nchunk), dim3(256), 0, st, X, ldx, T, N, (float*)ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(rlt_cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, nchunk, N, out, accumulate);
+    hipLaunchKernelGGL(rlt_rows_reduce_kernel, dim3(rlt_cdiv(N, 16)), dim3(256), 0, st, (const float*)ws, nchunk, N, N, N, out, out, accumulate);
     return RLT_LAUNCH_RESULT();
 }
 

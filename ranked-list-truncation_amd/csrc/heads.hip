@@ -182,15 +182,6 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     if (threadIdx.x < nh) prow[nhe + threadIdx.x] = dbs[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void heads_final_kernel(const float* __restrict__ partial, int B, int pw, int nhe,
-                                                          int nh, float* __restrict__ dw, float* __restrict__ db) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= nhe + nh) return;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += partial[(size_t)b * pw + col];
-    if (col < nhe) dw[col] = acc; else db[col - nhe] = acc;
-}
-
 __global__ __launch_bounds__(256) void to_pm_kernel(const float* __restrict__ in, int B, int S, int F,
                                                     float* __restrict__ out, int reverse) {
     const size_t n = (size_t)B * S * F;
@@ -265,8 +256,8 @@ int rlt_heads_bwd(const float* x, const float* w, const int* kinds, int n_heads,
     if (V == 4) hipLaunchKernelGGL(heads_bwd_kernel<4>, grid, block, shm, st, x, w, hk, n_heads, out, dout, S, B, E, dx, accumulate_dx, part, pw);
     else if (V == 2) hipLaunchKernelGGL(heads_bwd_kernel<2>, grid, block, shm, st, x, w, hk, n_heads, out, dout, S, B, E, dx, accumulate_dx, part, pw);
     else hipLaunchKernelGGL(heads_bwd_kernel<1>, grid, block, shm, st, x, w, hk, n_heads, out, dout, S, B, E, dx, accumulate_dx, part, pw);
-    hipLaunchKernelGGL(heads_final_kernel, dim3(rlt_cdiv(pw, 256)), dim3(256), 0, st, (const float*)part, B, pw,
-                       n_heads * E, n_heads, dw, db);
+    hipLaunchKernelGGL(rlt_rows_reduce_kernel, dim3(rlt_cdiv(n_heads * E + n_heads, 16)), dim3(256), 0, st, (const float*)part, B, pw,
+                       n_heads * E + n_heads, n_heads * E, dw, db, 0);
     return RLT_LAUNCH_RESULT();
 }
 

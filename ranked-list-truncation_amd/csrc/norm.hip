@@ -175,17 +175,6 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         partial[(size_t)blockIdx.x * 2 * E + col] = sm[col] + sm[2 * E + col] + sm[4 * E + col] + sm[6 * E + col];
 }
 
-__global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ partial, int nblk, int E,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= 2 * E) return;
-    float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += partial[(size_t)b * 2 * E + col];
-    float* dst = col < E ? dgamma + col : dbeta + (col - E);
-    *dst = accumulate ? *dst + acc : acc;
-}
-
 int ln_grid(int T) { const int g = rlt_cdiv(T, 4); return g > 2048 ? 2048 : g; }
 int pick_v(int E) { return (E % 256 == 0) ? 4 : ((E % 128 == 0) ? 2 : 1); }
 
@@ -235,8 +224,8 @@ int rlt_add_layernorm_bwd(const float* x, const float* r, const float* gamma, co
     if (V == 4) hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
     else if (V == 2) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
     else hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, block, shm, st, x, r, gamma, stats, dy, T, E, dz, part, dr, drop_p, seed);
-    hipLaunchKernelGGL(ln_param_final_kernel, dim3(rlt_cdiv(2 * E, 256)), dim3(256), 0, st, (const float*)part, nblk, E,
-                       dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(rlt_rows_reduce_kernel, dim3(rlt_cdiv(2 * E, 16)), dim3(256), 0, st, (const float*)part, nblk, 2 * E,
+                       2 * E, E, dgamma, dbeta, accumulate);
     return RLT_LAUNCH_RESULT();
 }
 
