@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+
+On the GPU box:
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+then
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv \
+         attn3_bwd_dkv_kernel "attncut b4096 s300 bf16x3" > profiles/r01_pmc_traffic.json
+
+Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KB; on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact."""
+import collections
+import csv
+import json
+import re
+import sys
+
+KERNEL_RE = re.compile(r"(attn3?_\w+|gemm3?_kernel<[^>]*>|bilstm3?_\w+|splitk_reduce_kernel|add_ln_\w+|heads_\w+|"
+                       r"reward_loss_kernel|adam_kernel|rlt_rows_reduce_kernel|colsum_\w+|cut_metrics_kernel)")
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            m = KERNEL_RE.search(r["Kernel_Name"])
+            acc[m.group(1) if m else "other"].append(float(r["Counter_Value"]))
+    return {k: {"launches": len(v), "mean_kb": sum(v) / len(v)} for k, v in acc.items()}
+
+
+def main():
+    fetch_csv, write_csv, dominant, workload = sys.argv[1:5]
+    fetch = per_kernel(fetch_csv, "FETCH_SIZE")
+    write = per_kernel(write_csv, "WRITE_SIZE")
+    fk = [k for k in fetch if k.startswith(dominant)]
+    wk = [k for k in write if k.startswith(dominant)]
+    if not fk or not wk:
+        sys.exit(f"kernel {dominant} not found in the counter files")
+    read_b = 2.0 * 1024.0 * sum(fetch[k]["mean_kb"] for k in fk)
+    write_b = 1024.0 * sum(write[k]["mean_kb"] for k in wk)
+    json.dump({"workload": workload, "dominant_launch": fk, "read_bytes_per_launch": read_b,
+               "write_bytes_per_launch": write_b, "traffic_bytes_per_launch": read_b + write_b,
+               "note": "FETCH_SIZE (KB) doubled per the gfx950 correction, WRITE_SIZE (KB) as is; separate --pmc passes",
+               "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
