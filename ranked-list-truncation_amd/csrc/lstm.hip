@@ -20,6 +20,7 @@
 // (deterministic).  dA is written in place over the gate stash; dW_ih, dW_hh, db and dx are then
 // plain GEMMs / column sums on it (position-major layout makes h_{t-1} a row offset of B).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -411,6 +412,118 @@ __global__ __launch_bounds__(1024) void bilstm3_bwd_kernel(float* __restrict__ g
     }
 }
 
+// 512-thread form of the split-bf16 backward recurrence: 8 wavefronts x 16 hidden units, two wavefronts per SIMD
+// and therefore a 256-VGPR budget.  The 1024-thread form above has 128 VGPRs per lane, half of them taken by the
+// W_hh^T fragments; it spills 9 fragments that are reloaded from scratch every time step (~11 GB of extra memory
+// traffic per launch, profiles/r01_i_pmc_traffic.json).  Here nothing spills, the partial dh tiles of all four
+// 32-column blocks fit LDS at once (one exchange per step instead of two) and the sum runs over 8 partials, not 16.
+constexpr int LDP8 = 132;      // floats per row of a partial dh tile (128 + 4)
+__global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                           const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
+                                                           const float* __restrict__ d_hout, int S, int B) {
+    extern __shared__ __attribute__((aligned(16))) float P[];           // [8][LISTS][LDP8]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+    const int ucol = 16 * w + 8 * hh;          // this lane's 8 hidden units
+
+    // dh = W_hh^T dA with the lane's own dA values as the B operand.  k-step (p, uh): element j <-> gate 2p + (j>>2),
+    // unit ucol + 4uh + (j&3); the A fragment (32-column block a) holds the same rows of W_hh at column 32a + l31.
+    bf16x8 wth[4][4], wtl[4][4];
+    {
+        const float* wp = dir ? w_hh_r : w_hh_f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int pgate = ks >> 1, uh = ks & 1;
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = wp[(size_t)((2 * pgate + (j >> 2)) * HID + ucol + 4 * uh + (j & 3)) * HID + a * 32 + l31];
+                split8(x, wth[a][ks], wtl[a][ks]);
+            }
+    }
+    float dc[8], dhrec[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { dc[u] = 0.f; dhrec[u] = 0.f; }
+
+    for (int t = S - 1; t >= 0; --t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        const size_t tokp = (size_t)(t > 0 ? (dir ? s + 1 : s - 1) : s) * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        bf16x8 dah[4], dal[4];
+#pragma unroll
+        for (int uh = 0; uh < 2; ++uh) {
+            float4 gv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4*>(grow + g * HID + 4 * uh);
+            const float4 ct4 = *reinterpret_cast<const float4*>(cst + (tok * 2 + dir) * HID + ucol + 4 * uh);
+            const float4 cpl = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol + 4 * uh);
+            const float4 cp4 = t > 0 ? cpl : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 dh4 = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol + 4 * uh);
+            const float* gf_ = reinterpret_cast<const float*>(&gv[0]);
+            const float* ct = reinterpret_cast<const float*>(&ct4);
+            const float* cp = reinterpret_cast<const float*>(&cp4);
+            const float* dho = reinterpret_cast<const float*>(&dh4);
+            float dA[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = gf_[u], fg = gf_[4 + u], gg = gf_[8 + u], og = gf_[12 + u];
+                const float dh = dho[u] + dhrec[4 * uh + u];
+                const float tc = ftanh(ct[u]);
+                const float dcu = dc[4 * uh + u] + dh * og * (1.f - tc * tc);
+                dA[u] = valid ? dcu * gg * ig * (1.f - ig) : 0.f;
+                dA[4 + u] = valid ? dcu * cp[u] * fg * (1.f - fg) : 0.f;
+                dA[8 + u] = valid ? dcu * ig * (1.f - gg * gg) : 0.f;
+                dA[12 + u] = valid ? dh * tc * og * (1.f - og) : 0.f;
+                dc[4 * uh + u] = dcu * fg;
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(grow + g * HID + 4 * uh) = make_float4(dA[4 * g], dA[4 * g + 1], dA[4 * g + 2], dA[4 * g + 3]);
+            }
+#pragma unroll
+            for (int pgate = 0; pgate < 2; ++pgate) {
+                const float x[8] = {dA[8 * pgate + 0], dA[8 * pgate + 1], dA[8 * pgate + 2], dA[8 * pgate + 3],
+                                    dA[8 * pgate + 4], dA[8 * pgate + 5], dA[8 * pgate + 6], dA[8 * pgate + 7]};
+                split8(x, dah[2 * pgate + uh], dal[2 * pgate + uh]);
+            }
+        }
+        if (t == 0) break;
+        float* pw = P + (size_t)(w * LISTS + l31) * LDP8 + 4 * hh;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = mfma3(wth[a][ks], wtl[a][ks], dah[ks], dal[ks], acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(pw + 32 * a + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __syncthreads();
+        {
+            const float* pr = P + (size_t)l31 * LDP8 + ucol;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float4 v0 = *reinterpret_cast<const float4*>(pr + (size_t)ww * LISTS * LDP8);
+                const float4 v1 = *reinterpret_cast<const float4*>(pr + (size_t)ww * LISTS * LDP8 + 4);
+                s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+                s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            }
+            dhrec[0] = s0.x; dhrec[1] = s0.y; dhrec[2] = s0.z; dhrec[3] = s0.w;
+            dhrec[4] = s1.x; dhrec[5] = s1.y; dhrec[6] = s1.z; dhrec[7] = s1.w;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -435,10 +548,16 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
     if (!(rlt_aligned16(gates) && rlt_aligned16(c) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(d_hout)))
         return RLT_E_ALIGN;
     const size_t shm = (size_t)16 * LISTS * LDP * sizeof(float);
+    const size_t shm8 = (size_t)8 * LISTS * LDP8 * sizeof(float);
     int rc = rlt_allow_lds(bilstm_bwd_kernel, shm);
     if (!rc) rc = rlt_allow_lds(bilstm3_bwd_kernel, shm);
+    if (!rc) rc = rlt_allow_lds(bilstm3_bwd8_kernel, shm8);
     if (rc) return rc;
-    if (rlt_precision() == RLT_PRECISION_BF16X3)
+    static const bool wide = getenv("RLT_LSTM_BWD_1024") != nullptr;     // experiment switch: the 1024-thread form
+    if (rlt_precision() == RLT_PRECISION_BF16X3 && !wide)
+        hipLaunchKernelGGL(bilstm3_bwd8_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(512), shm8, rlt_stream(stream),
+                           gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
+    else if (rlt_precision() == RLT_PRECISION_BF16X3)
         hipLaunchKernelGGL(bilstm3_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
                            gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
     else
