@@ -32,7 +32,30 @@ struct GemmArgs {
     float drop_p; uint32_t drop_thr, seed;   // epilogue dropout on the output (after ReLU), keep -> /(1-p)
     float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
     int nt_store;        // write C with non-temporal stores (streamed output: keep the operands in L2)
+    int slab_xcd;        // split-K launched as a 1-D grid with K slabs pinned to XCDs (see decode_block)
 };
+
+// (tile, K slab) of this workgroup.
+//  * no split-K, or a split count that is not a multiple of 8: XCD-aware bijective remap of the flat tile id (the
+//    tiles an XCD runs are contiguous and share operand panels in that XCD's L2); slab = blockIdx.z.
+//  * split-K with nsplit % 8 == 0, launched as a 1-D grid of tiles x nsplit: under round-robin dispatch XCD c gets the
+//    ids = c (mod 8); it is given the K slabs z = c (mod 8) and runs ALL tiles of a slab together, so every slab of A
+//    and B is fetched from HBM by exactly one XCD and shared by that slab's tiles through its L2.  (With tiles spread
+//    over XCDs instead, each XCD streams the whole small operand: 8x its bytes - measured 20 GB instead of 11 GB on
+//    the FFN weight gradients.)
+__device__ __forceinline__ void decode_block(const GemmArgs& g, int& bid, int& z) {
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int id = blockIdx.x;
+    if (g.slab_xcd) {
+        const int xcd = id & 7, j = id >> 3, grp = j / nwg;
+        z = grp * 8 + xcd;
+        bid = j - grp * nwg;
+    } else {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        z = blockIdx.z;
+    }
+}
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float bv, int row, int col, const float* dst) {
     v += bv;
@@ -129,9 +152,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
 
 // ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
 __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0,
-                                             int wm, int wn, int l31, int hh) {
+                                             int wm, int wn, int l31, int hh, int z) {
     const bool to_slab = g.slab != nullptr;
-    float* out = to_slab ? g.slab + (size_t)blockIdx.z * g.M * g.N : g.C;
+    float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
     const int ldo = to_slab ? g.N : g.ldc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -158,7 +181,7 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
 }
 
 // 8 threads (tid>>5) hold partial sums of the same 4 columns m = 4*(tid&31)..+3: reduce through LDS
-__device__ __forceinline__ void finish_colsum(const GemmArgs& g, float4 csum, float* lds, int tid, int m0) {
+__device__ __forceinline__ void finish_colsum(const GemmArgs& g, float4 csum, float* lds, int tid, int m0, int z) {
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(lds);
     red[tid] = csum;
@@ -167,7 +190,7 @@ __device__ __forceinline__ void finish_colsum(const GemmArgs& g, float4 csum, fl
         float4 t = red[tid];
 #pragma unroll
         for (int j = 1; j < 8; ++j) { const float4 o = red[tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-        float* dst = (g.cs_slab ? g.cs_slab + (size_t)blockIdx.z * g.M : g.colsum) + m0 + 4 * tid;
+        float* dst = (g.cs_slab ? g.cs_slab + (size_t)z * g.M : g.colsum) + m0 + 4 * tid;
         const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -184,16 +207,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
 
-    // XCD-aware, bijective remap of the flat block id (8 XCDs, round-robin dispatch)
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
+    int bid, zslab;
+    decode_block(g, bid, zslab);
     const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int kbeg = zslab * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     f32x16 acc[2][2];
@@ -253,8 +271,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
         buf ^= 1;
     }
 
-    write_output(g, acc, m0, n0, wm, wn, l31, hh);
-    if (want_cs) finish_colsum(g, csum, gsm, tid, m0);
+    write_output(g, acc, m0, n0, wm, wn, l31, hh, zslab);
+    if (want_cs) finish_colsum(g, csum, gsm, tid, m0, zslab);
 }
 
 // ======================================================================================================
@@ -377,15 +395,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
+    int bid, zslab;
+    decode_block(g, bid, zslab);
     const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int kbeg = zslab * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     f32x16 acc[2][2];
@@ -467,8 +481,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         if (t + 4 < nt) fetch(t + 4, a1, b1);
         __syncthreads();
     }
-    write_output(g, acc, m0, n0, wm, wn, l31, hh);
-    if (want_cs) finish_colsum(g, csum, gsm, tid, m0);
+    write_output(g, acc, m0, n0, wm, wn, l31, hh, zslab);
+    if (want_cs) finish_colsum(g, csum, gsm, tid, m0, zslab);
 }
 
 template <bool TA, bool TB, bool FAST>
@@ -591,6 +605,7 @@ int choose_split(int M, int N, int K) {
     const long long maxs = K / 512 > 0 ? K / 512 : 1;        // keep >= 512 of K per slice
     if (want > maxs) want = maxs;
     if (want > 256) want = 256;
+    if (want >= 8) want = want / 8 * 8;       // whole groups of 8 slabs: one slab per XCD and round (decode_block)
     return (int)(want < 1 ? 1 : want);
 }
 
@@ -691,10 +706,12 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     int kchunk = rlt_cdiv(rlt_cdiv(K, ns), 32) * 32;
     ns = rlt_cdiv(K, kchunk);
     g.kchunk = kchunk;
+    static const bool no_slab_xcd = getenv("RLT_GEMM_NO_SLAB_XCD") != nullptr;
+    g.slab_xcd = (ns > 1 && ns % 8 == 0 && !no_slab_xcd) ? 1 : 0;
     g.slab = ns > 1 ? (float*)ws : nullptr;
     g.cs_slab = (ns > 1 && colsum_a) ? (float*)ws + (size_t)ns * M * N : nullptr;
     hipStream_t st = rlt_stream(stream);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, ns);
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     int rc = 0;
     if (gemm_mode() == 1) {
         if (!ta && tb) rc = launch_gemm3<false, true>(g, grid, st);
