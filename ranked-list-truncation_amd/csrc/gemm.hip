@@ -180,16 +180,19 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
     }
 }
 
-// 8 threads (tid>>5) hold partial sums of the same 4 columns m = 4*(tid&31)..+3: reduce through LDS
+// 8 threads hold partial sums of the same 4 columns m: reduce through LDS.  KLOW = false: the 8 threads are
+// tid, tid+32, ... (columns 4*(tid&31), the fp32 kernel's staging map); KLOW = true: tid = 8*mb + kb (columns 4*mb,
+// the split-bf16 kernel's map, which keeps the k index in the low lane bits for conflict-free LDS stores)
+template <bool KLOW>
 __device__ __forceinline__ void finish_colsum(const GemmArgs& g, float4 csum, float* lds, int tid, int m0, int z) {
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(lds);
     red[tid] = csum;
     __syncthreads();
     if (tid < 32) {
-        float4 t = red[tid];
+        float4 t = red[KLOW ? 8 * tid : tid];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) { const float4 o = red[tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        for (int j = 1; j < 8; ++j) { const float4 o = red[KLOW ? 8 * tid + j : tid + 32 * j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
         float* dst = (g.cs_slab ? g.cs_slab + (size_t)z * g.M : g.colsum) + m0 + 4 * tid;
         const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     }
 
     write_output(g, acc, m0, n0, wm, wn, l31, hh, zslab);
-    if (want_cs) finish_colsum(g, csum, gsm, tid, m0, zslab);
+    if (want_cs) finish_colsum<false>(g, csum, gsm, tid, m0, zslab);
 }
 
 // ======================================================================================================
@@ -316,7 +319,7 @@ __device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int m
             int r, c;
             bool ok;
             if (KC) { const int idx = tid + 256 * i; r = mn0 + (idx >> 3); c = k0 + 4 * (idx & 7); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
-            else { r = k0 + 4 * (tid >> 5) + i; c = mn0 + 4 * (tid & 31); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
+            else { r = k0 + 4 * (tid & 7) + i; c = mn0 + 4 * (tid >> 3); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
             (void)ok;          // the zero-select is applied by mask3 just before the registers are consumed
             v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
         } else if (KC) {       // [MN][K]: idx -> (row, 4 consecutive k)
@@ -332,8 +335,10 @@ __device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int m
                     if (kk + 3 < Kend) v.w = src[3];
                 }
             }
-        } else {        // [K][MN]: thread owns a 4(k) x 4(mn) block, i = k row within the block
-            const int kk = k0 + 4 * (tid >> 5) + i, col = mn0 + 4 * (tid & 31);
+        } else {        // [K][MN]: thread owns a 4(k) x 4(mn) block, i = k row within the block; the k block is the LOW part
+                        // of tid so that the 16 lanes of a ds_write_b64 group cover 8 k blocks x 2 rows = 32 distinct
+                        // banks (with mn in the low bits the 16 rows are 80 dwords apart: an 8-way bank conflict)
+            const int kk = k0 + 4 * (tid & 7) + i, col = mn0 + 4 * (tid >> 3);
             if (kk < Kend) {
                 const float* src = P + (size_t)kk * ld + col;
                 if (vec && col + 3 < MN) v = *reinterpret_cast<const float4*>(src);
@@ -355,7 +360,7 @@ __device__ __forceinline__ void mask3(Stage3& st, int tid, int mn0, int k0, int 
     for (int i = 0; i < 4; ++i) {
         bool ok;
         if (KC) { const int idx = tid + 256 * i; ok = mn0 + (idx >> 3) < MN && k0 + 4 * (idx & 7) < Kend; }
-        else ok = k0 + 4 * (tid >> 5) + i < Kend && mn0 + 4 * (tid & 31) < MN;
+        else ok = k0 + 4 * (tid & 7) + i < Kend && mn0 + 4 * (tid >> 3) < MN;
         st.v[i] = make_float4(ok ? st.v[i].x : 0.f, ok ? st.v[i].y : 0.f, ok ? st.v[i].z : 0.f, ok ? st.v[i].w : 0.f);
     }
 }
@@ -373,7 +378,7 @@ __device__ __forceinline__ void store3(uint16_t* __restrict__ Thi, uint16_t* __r
             *reinterpret_cast<uint2*>(Tlo + mn * LDK3 + k) = lo;
         }
     } else {
-        const int k = 4 * (tid >> 5), mn = 4 * (tid & 31);
+        const int k = 4 * (tid & 7), mn = 4 * (tid >> 3);
         const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
         const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
         const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         __syncthreads();
     }
     write_output(g, acc, m0, n0, wm, wn, l31, hh, zslab);
-    if (want_cs) finish_colsum(g, csum, gsm, tid, m0, zslab);
+    if (want_cs) finish_colsum<true>(g, csum, gsm, tid, m0, zslab);
 }
 
 template <bool TA, bool TB, bool FAST>
