@@ -220,6 +220,15 @@ int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, floa
  */
 int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
                        float* h_out, float* c_out, void* stream);
+
+/* The same recurrence with the input projection fused in, for narrow inputs (1 <= I <= 3: layer 0 of the
+ * reference's encoders, input_size = 3, models/AttnCut.py:6,8): pre-activations x W_ih^T + b_ih + b_hh are formed
+ * inside the kernel from x (S*B, I) and never touch HBM; `gates` (S*B, 1024) is output only (activated gates for
+ * rlt_bilstm_rec_bwd).  RLT_E_SHAPE for I > 3: use rlt_gemm + rlt_bilstm_rec_fwd. */
+int rlt_bilstm_rec_fwd_x(const float* x, int I, const float* w_ih_fwd, const float* b_ih_fwd, const float* b_hh_fwd,
+                         const float* w_ih_rev, const float* b_ih_rev, const float* b_hh_rev,
+                         const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
+                         float* gates, float* h_out, float* c_out, void* stream);
 int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
                        const float* d_hout, int S, int B, void* stream);
 

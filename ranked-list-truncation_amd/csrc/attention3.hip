@@ -443,158 +443,10 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
 }
 
-// ------------------------------------------------------------------------------------------ dV
-// workgroup = 256 keys, loops over 64-query tiles: dV^T[d][key] += dO^T P with P recomputed from the LSE
-template <int HD, bool DROP>
-__global__ __launch_bounds__(512, 2) void attn3_bwd_dv_kernel(Attn3Args g) {
-    const AttnArgs& a = g.a;
-    constexpr int DT = (HD + 31) / 32;
-    constexpr int DPART = Rec<HD>::TP + Rec<HD>::AUX;                       // dO transposed pair | aux
-    constexpr int STAGE = Rec<HD>::RP + DPART;                              // Q rows pair | ...
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
-    const size_t ld = (size_t)3 * E;
-    const int nt = rlt_cdiv_dev(B, KT);
-    const int ntile = rlt_cdiv_dev(B, QT3);
-    int pair, ktile;
-    map_block(blockIdx.x, npair, ntile, pair, ktile);
-    const int s = pair / H, h = pair % H;
-    const int key = ktile * QT3 + wv * 32 + l31;
-    const bool wave_live = ktile * QT3 + wv * 32 < B;
-    const uint32_t ps = pair_seed(a.seed, pair);
-    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-
-    bf16x8 kh[HD / 16], kl[HD / 16];
-    image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, min(key >> 6, nt - 1)), key & 63, hh, kh, kl);
-    f32x16 dv[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dv[dt][r] = 0.f;
-
-    auto issue = [&](int t, int buf) {
-        dma_copy<Rec<HD>::RP>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<DPART>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.dimg, 0, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
-    };
-    issue(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
-        if (wave_live) {
-            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
-            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
-            const uint16_t* dt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
-            const uint16_t* dt_lo = dt_hi + T_elems<HD>();
-            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + Rec<HD>::RP + Rec<HD>::TP);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 sc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] (Q carries scale*log2e)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    // queries beyond B need no mask: their columns of the transposed dO image are zero, p is finite
-                    float p = rlt_exp2(sc[r] - Ls[ql]);
-                    if (DROP)
-                        p = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? p * inv_keep : 0.f;
-                    sc[r] = p;
-                }
-                mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
-            }
-        }
-        __syncthreads();
-    }
-    if (!wave_live || key >= B) return;
-    store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + 2 * E, hh, dv, 1.f);
-}
-
-// ------------------------------------------------------------------------------------------ dK
-template <int HD, bool DROP>
-__global__ __launch_bounds__(512, 2) void attn3_bwd_dk_kernel(Attn3Args g) {
-    const AttnArgs& a = g.a;
-    constexpr int DT = (HD + 31) / 32;
-    constexpr int QREC = Rec<HD>::RP + Rec<HD>::TP;                         // Q rows pair | Q transposed pair
-    constexpr int STAGE = QREC + Rec<HD>::RP + Rec<HD>::AUX;                // ... | dO rows pair | aux
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
-    const size_t ld = (size_t)3 * E;
-    const int nt = rlt_cdiv_dev(B, KT);
-    const int ntile = rlt_cdiv_dev(B, QT3);
-    int pair, ktile;
-    map_block(blockIdx.x, npair, ntile, pair, ktile);
-    const int s = pair / H, h = pair % H;
-    const int key = ktile * QT3 + wv * 32 + l31;
-    const bool wave_live = ktile * QT3 + wv * 32 < B;
-    const uint32_t ps = pair_seed(a.seed, pair);
-    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-
-    bf16x8 kh[HD / 16], kl[HD / 16], vh[HD / 16], vl[HD / 16];
-    const int ktl = min(key >> 6, nt - 1);
-    image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, ktl), key & 63, hh, kh, kl);
-    image_row_frags<HD>(record<HD>(g.img, 2, npair, nt, pair, ktl), key & 63, hh, vh, vl);
-    f32x16 dk[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[dt][r] = 0.f;
-
-    auto issue = [&](int t, int buf) {
-        const uint8_t* drec = record<HD>(g.dimg, 0, npair, nt, pair, t);
-        dma_copy<QREC>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::RP>(lds + buf * STAGE + QREC, drec, wv, lane);
-        dma_copy<Rec<HD>::AUX>(lds + buf * STAGE + QREC + Rec<HD>::RP, drec + Rec<HD>::RP + Rec<HD>::TP, wv, lane);
-    };
-    issue(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
-        if (wave_live) {
-            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
-            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
-            const uint16_t* qt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
-            const uint16_t* qt_lo = qt_hi + T_elems<HD>();
-            const uint16_t* dr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC);
-            const uint16_t* dr_lo = dr_hi + rows_elems<HD>();
-            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + QREC + Rec<HD>::RP);
-            const float* Es = Ls + KT;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key]
-                dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    // queries beyond B need no mask: their columns of the transposed Q image are zero, p is finite
-                    const float p = rlt_exp2(sc[r] - Ls[ql]);
-                    float dpr = dp[r];
-                    if (DROP)
-                        dpr = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr) ? dpr * inv_keep : 0.f;
-                    dp[r] = p * (dpr - Es[ql]);                                    // dS
-                }
-                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
-            }
-        }
-        __syncthreads();
-    }
-    if (!wave_live || key >= B) return;
-    // the Q image carries c = scale*log2e, so dK = scale * dS^T Q = ln2 * dS^T (cQ)
-    store_acc_T<HD>(a.dqkv + ((size_t)s * B + key) * ld + h * HD + E, hh, dk, LN2);
-}
-
 // ------------------------------------------------------------------------------------------ dK + dV fused
-// One pass over the query tiles computes S and P once for both gradients (4 products per tile instead of the 5 of
-// the separate dV and dK kernels); ~200 unified VGPRs, one 512-thread workgroup per CU.
+// workgroup = 256 keys, loops over 64-query tiles.  One pass computes S and P (recomputed from the LSE) once for both
+// gradients: dV^T[d][key] += dO^T P and dK^T[d][key] += (cQ)^T dS - 4 products per tile (separate dV and dK kernels
+// need 5); ~210 unified VGPRs, one 512-thread workgroup per CU.
 template <int HD, bool DROP>
 __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
@@ -683,9 +535,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 
 template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP); }
 template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP); }
-template <int HD> size_t dv3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
 template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX); }
-template <int HD> size_t dk3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP + Rec<HD>::AUX); }
 
 template <int HD>
 int prepare3(const PrepArgs& p, hipStream_t st) {
@@ -705,16 +555,8 @@ int launch3(int which, const Attn3Args& g, hipStream_t st) {
         if ((rc = rlt_allow_lds(attn3_fwd_kernel<HD, DROP>, fwd3_smem<HD>()))) return rc;
         hipLaunchKernelGGL((attn3_fwd_kernel<HD, DROP>), dim3(grid), dim3(512), fwd3_smem<HD>(), st, g);
     } else if (which == 1) {
-        static const bool split = getenv("RLT_ATTN_SPLIT_DKV") != nullptr;      // experiment switch: separate dV and dK kernels
-        if (split) {
-            if ((rc = rlt_allow_lds(attn3_bwd_dv_kernel<HD, DROP>, dv3_smem<HD>()))) return rc;
-            if ((rc = rlt_allow_lds(attn3_bwd_dk_kernel<HD, DROP>, dk3_smem<HD>()))) return rc;
-            hipLaunchKernelGGL((attn3_bwd_dv_kernel<HD, DROP>), dim3(grid), dim3(512), dv3_smem<HD>(), st, g);
-            hipLaunchKernelGGL((attn3_bwd_dk_kernel<HD, DROP>), dim3(grid), dim3(512), dk3_smem<HD>(), st, g);
-        } else {
-            if ((rc = rlt_allow_lds(attn3_bwd_dkv_kernel<HD, DROP>, dkv3_smem<HD>()))) return rc;
-            hipLaunchKernelGGL((attn3_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(512), dkv3_smem<HD>(), st, g);
-        }
+        if ((rc = rlt_allow_lds(attn3_bwd_dkv_kernel<HD, DROP>, dkv3_smem<HD>()))) return rc;
+        hipLaunchKernelGGL((attn3_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(512), dkv3_smem<HD>(), st, g);
     } else {
         if ((rc = rlt_allow_lds(attn3_bwd_dq_kernel<HD, DROP>, dq3_smem<HD>()))) return rc;
         hipLaunchKernelGGL((attn3_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(512), dq3_smem<HD>(), st, g);

@@ -306,6 +306,14 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
     lo.y = pack_bf16x2(c - ch, d - dh);
 }
 
+// K-contiguous operand ([MN][K]): element idx of the 1024 float4 of a 128 x 32 tile -> (row, 16-byte k chunk).
+// Bits: idx = [row>>3][kq>>1 (2 bits)][row&7 (3 bits)][kq&1]: a wavefront still covers 8 rows x 128 contiguous bytes
+// of global memory, but the 16 lanes of a ds_write_b64 group hold 8 rows x 2 chunks, whose 4-dword windows at
+// 20-dword row stride tile the 32 banks exactly (rows-major lanes, 2 rows x 8 chunks, overlap on 4 banks: a third of
+// the LDS cycles of the NT kernel were bank conflicts)
+__device__ __forceinline__ int kc_row(int idx) { return ((idx >> 1) & 7) | ((idx >> 6) << 3); }
+__device__ __forceinline__ int kc_kq(int idx) { return (idx & 1) | (((idx >> 4) & 3) << 1); }
+
 // registers of one staged operand tile: 4 float4 per thread
 struct Stage3 { float4 v[4]; };
 
@@ -318,13 +326,13 @@ __device__ __forceinline__ void load3(const float* __restrict__ P, int ld, int m
         if (FAST) {     // branch-free: clamp, load, select (see load_tile)
             int r, c;
             bool ok;
-            if (KC) { const int idx = tid + 256 * i; r = mn0 + (idx >> 3); c = k0 + 4 * (idx & 7); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
+            if (KC) { const int idx = tid + 256 * i; r = mn0 + kc_row(idx); c = k0 + 4 * kc_kq(idx); ok = r < MN && c < Kend; r = min(r, MN - 1); c = min(c, Kend - 4); }
             else { r = k0 + 4 * (tid & 7) + i; c = mn0 + 4 * (tid >> 3); ok = r < Kend && c < MN; r = min(r, Kend - 1); c = min(c, MN - 4); }
             (void)ok;          // the zero-select is applied by mask3 just before the registers are consumed
             v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + c);
         } else if (KC) {       // [MN][K]: idx -> (row, 4 consecutive k)
             const int idx = tid + 256 * i;
-            const int row = mn0 + (idx >> 3), kk = k0 + 4 * (idx & 7);
+            const int row = mn0 + kc_row(idx), kk = k0 + 4 * kc_kq(idx);
             if (row < MN) {
                 const float* src = P + (size_t)row * ld + kk;
                 if (vec && kk + 3 < Kend) v = *reinterpret_cast<const float4*>(src);
@@ -359,7 +367,7 @@ __device__ __forceinline__ void mask3(Stage3& st, int tid, int mn0, int k0, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         bool ok;
-        if (KC) { const int idx = tid + 256 * i; ok = mn0 + (idx >> 3) < MN && k0 + 4 * (idx & 7) < Kend; }
+        if (KC) { const int idx = tid + 256 * i; ok = mn0 + kc_row(idx) < MN && k0 + 4 * kc_kq(idx) < Kend; }
         else ok = k0 + 4 * (tid & 7) + i < Kend && mn0 + 4 * (tid >> 3) < MN;
         st.v[i] = make_float4(ok ? st.v[i].x : 0.f, ok ? st.v[i].y : 0.f, ok ? st.v[i].z : 0.f, ok ? st.v[i].w : 0.f);
     }
@@ -371,7 +379,7 @@ __device__ __forceinline__ void store3(uint16_t* __restrict__ Thi, uint16_t* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
-            const int mn = idx >> 3, k = 4 * (idx & 7);
+            const int mn = kc_row(idx), k = 4 * kc_kq(idx);
             uint2 hi, lo;
             split4(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, hi, lo);
             *reinterpret_cast<uint2*>(Thi + mn * LDK3 + k) = hi;

@@ -31,10 +31,50 @@ constexpr int LDP = 68;       // LDS row stride of the partial dh tiles (floats)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Fused input projection for narrow inputs (I <= 3, the reference's score / tf-idf / doc2vec features): instead of a
+// separate GEMM writing x W_ih^T + b_ih + b_hh to HBM (4 KB per token) and the recurrence reading it back, the
+// recurrence computes the 16 pre-activations of a lane from the I input values of its list and a per-direction table
+// (row -> W_ih[row][0..2], b_ih[row] + b_hh[row]) kept in LDS (8 KB; all lanes of a wavefront read the same two
+// addresses, a broadcast).
+struct XIn {
+    const float* x;            // (S*B, I) position-major, or null: `gates` holds the pre-activations
+    const float* w_ih[2];      // (512, I) per direction
+    const float* b_ih[2];
+    const float* b_hh[2];
+    int I;
+};
+__device__ __forceinline__ void xin_table(const XIn& xi, int dir, int tid, int nthreads, float4* tab) {
+    for (int row = tid; row < 4 * 128; row += nthreads) {
+        const float* wr = xi.w_ih[dir] + (size_t)row * xi.I;
+        float4 t;
+        t.x = wr[0];
+        t.y = xi.I > 1 ? wr[1] : 0.f;
+        t.z = xi.I > 2 ? wr[2] : 0.f;
+        t.w = xi.b_ih[dir][row] + xi.b_hh[dir][row];
+        tab[row] = t;
+    }
+}
+__device__ __forceinline__ void xin_gates(const XIn& xi, const float4* tab, size_t tok, int ucol, float4 (&gin)[4]) {
+    const float* xr = xi.x + tok * xi.I;
+    const float x0 = xr[0], x1 = xi.I > 1 ? xr[1] : 0.f, x2 = xi.I > 2 ? xr[2] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 t = tab[g * 128 + ucol + u];
+            v[u] = ((t.x * x0 + t.y * x1) + t.z * x2) + t.w;
+        }
+        gin[g] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <bool XIN>
 __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                           const float* __restrict__ w_hh_r, int S, int B, float* __restrict__ h_out,
-                                                          float* __restrict__ c_out) {
+                                                          float* __restrict__ c_out, XIn xi) {
     __shared__ __attribute__((aligned(16))) float hs[2][LISTS * LDH];
+    __shared__ float4 xtab[XIN ? 4 * HID : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
     const int b = blockIdx.x * LISTS + l31;
@@ -51,6 +91,7 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
         }
     }
     for (int i = tid; i < LISTS * LDH; i += 1024) hs[0][i] = 0.f;      // h_0 = 0
+    if (XIN) xin_table(xi, blockIdx.y, tid, 1024, xtab);
     float c[4] = {0.f, 0.f, 0.f, 0.f};                                  // c_0 = 0
     const int ucol = 8 * w + 4 * hh;                                    // first of this lane's 4 units
     __syncthreads();
@@ -61,9 +102,12 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
         const size_t tok = (size_t)s * B + (valid ? b : 0);
         float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
         float4 gin[4];
+        if (XIN) xin_gates(xi, xtab, tok, ucol, gin);
+        else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)        // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
-            gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+            for (int g = 0; g < 4; ++g)    // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
+                gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+        }
 
         f32x16 acc;
 #pragma unroll
@@ -233,10 +277,12 @@ __device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 
 __device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + rlt_exp2(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.f * fsigmoid(2.f * x) - 1.f; }
 
+template <bool XIN>
 __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                            const float* __restrict__ w_hh_r, int S, int B,
-                                                           float* __restrict__ h_out, float* __restrict__ c_out) {
+                                                           float* __restrict__ h_out, float* __restrict__ c_out, XIn xi) {
     __shared__ __attribute__((aligned(16))) uint16_t hs[2][2][LISTS * LDH3];        // [buffer][hi|lo]
+    __shared__ float4 xtab[XIN ? 4 * HID : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
     const int b = blockIdx.x * LISTS + l31;
@@ -255,6 +301,7 @@ __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ g
         }
     }
     for (int i = tid; i < 2 * LISTS * LDH3; i += 1024) (&hs[0][0][0])[i] = 0;       // h_0 = 0 (hi and lo images)
+    if (XIN) xin_table(xi, blockIdx.y, tid, 1024, xtab);
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     const int ucol = 8 * w + 4 * hh;
     __syncthreads();
@@ -265,9 +312,12 @@ __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ g
         const size_t tok = (size_t)s * B + (valid ? b : 0);
         float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
         float4 gin[4];
+        if (XIN) xin_gates(xi, xtab, tok, ucol, gin);
+        else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)        // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
-            gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+            for (int g = 0; g < 4; ++g)    // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
+                gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -307,116 +357,11 @@ __global__ __launch_bounds__(1024) void bilstm3_fwd_kernel(float* __restrict__ g
     }
 }
 
-__global__ __launch_bounds__(1024) void bilstm3_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
-                                                           const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
-                                                           const float* __restrict__ d_hout, int S, int B) {
-    extern __shared__ __attribute__((aligned(16))) float P[];           // [16][LISTS][LDP]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int dir = blockIdx.y;
-    const int b = blockIdx.x * LISTS + l31;
-    const bool valid = b < B;
-    const int ucol = 8 * w + 4 * hh;
-
-    // dh = W_hh^T dA.  B operand = this lane's dA registers: k-step s2 <- registers 8*s2..8*s2+7, i.e. element j is the
-    // gate row (2*s2 + (j>>2))*128 + 8w + 4hh + (j&3).  A fragment (tile a, step s2) must hold the same rows of W_hh at
-    // column a*32 + l31.
-    bf16x8 wth[4][2], wtl[4][2];
-    {
-        const float* wp = dir ? w_hh_r : w_hh_f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    x[j] = wp[(size_t)((2 * s2 + (j >> 2)) * HID + ucol + (j & 3)) * HID + a * 32 + l31];
-                split8(x, wth[a][s2], wtl[a][s2]);
-            }
-    }
-    float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhrec[4] = {0.f, 0.f, 0.f, 0.f};
-
-    for (int t = S - 1; t >= 0; --t) {
-        const int s = dir ? S - 1 - t : t;
-        const size_t tok = (size_t)s * B + (valid ? b : 0);
-        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
-        float dA[16];
-        {
-            float4 gv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4*>(grow + g * HID);
-            const float4 ct4 = *reinterpret_cast<const float4*>(cst + (tok * 2 + dir) * HID + ucol);
-            const size_t tokp = (size_t)(t > 0 ? (dir ? s + 1 : s - 1) : s) * B + (valid ? b : 0);
-            const float4 cpl = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol);
-            const float4 cp4 = t > 0 ? cpl : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 dh4 = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol);
-            const float* gf_ = reinterpret_cast<const float*>(&gv[0]);
-            const float* ct = reinterpret_cast<const float*>(&ct4);
-            const float* cp = reinterpret_cast<const float*>(&cp4);
-            const float* dho = reinterpret_cast<const float*>(&dh4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float ig = gf_[u], fg = gf_[4 + u], gg = gf_[8 + u], og = gf_[12 + u];
-                const float dh = dho[u] + dhrec[u];
-                const float tc = ftanh(ct[u]);
-                const float dcu = dc[u] + dh * og * (1.f - tc * tc);
-                dA[u] = valid ? dcu * gg * ig * (1.f - ig) : 0.f;
-                dA[4 + u] = valid ? dcu * cp[u] * fg * (1.f - fg) : 0.f;
-                dA[8 + u] = valid ? dcu * ig * (1.f - gg * gg) : 0.f;
-                dA[12 + u] = valid ? dh * tc * og * (1.f - og) : 0.f;
-                dc[u] = dcu * fg;
-            }
-            if (valid) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(grow + g * HID) = make_float4(dA[4 * g], dA[4 * g + 1], dA[4 * g + 2], dA[4 * g + 3]);
-            }
-        }
-        if (t == 0) break;
-        bf16x8 dah[2], dal[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const float x[8] = {dA[8 * s2 + 0], dA[8 * s2 + 1], dA[8 * s2 + 2], dA[8 * s2 + 3],
-                                dA[8 * s2 + 4], dA[8 * s2 + 5], dA[8 * s2 + 6], dA[8 * s2 + 7]};
-            split8(x, dah[s2], dal[s2]);
-        }
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                acc0 = mfma3(wth[2 * rd][s2], wtl[2 * rd][s2], dah[s2], dal[s2], acc0);
-                acc1 = mfma3(wth[2 * rd + 1][s2], wtl[2 * rd + 1][s2], dah[s2], dal[s2], acc1);
-            }
-            float* pw = P + (size_t)(w * LISTS + l31) * LDP + 4 * hh;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(pw + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
-                *reinterpret_cast<float4*>(pw + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
-            }
-            __syncthreads();
-            if ((w >> 3) == rd) {
-                const float* pr = P + (size_t)l31 * LDP + 8 * (w & 7) + 4 * hh;
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int ww = 0; ww < 16; ++ww) {
-                    const float4 v = *reinterpret_cast<const float4*>(pr + (size_t)ww * LISTS * LDP);
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-                }
-                dhrec[0] = sum.x; dhrec[1] = sum.y; dhrec[2] = sum.z; dhrec[3] = sum.w;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// 512-thread form of the split-bf16 backward recurrence: 8 wavefronts x 16 hidden units, two wavefronts per SIMD
-// and therefore a 256-VGPR budget.  The 1024-thread form above has 128 VGPRs per lane, half of them taken by the
-// W_hh^T fragments; it spills 9 fragments that are reloaded from scratch every time step (~11 GB of extra memory
-// traffic per launch, profiles/r01_i_pmc_traffic.json).  Here nothing spills, the partial dh tiles of all four
-// 32-column blocks fit LDS at once (one exchange per step instead of two) and the sum runs over 8 partials, not 16.
+// Split-bf16 backward recurrence, 512 threads: 8 wavefronts x 16 hidden units, two wavefronts per SIMD and therefore a
+// 256-VGPR budget.  (A 1024-thread form like the forward kernel's has 128 VGPRs per lane, half of them taken by the
+// W_hh^T fragments; it spilled 9 fragments that were reloaded from scratch every time step: ~11 GB of extra memory
+// traffic per launch, profiles/r01_i_pmc_traffic.json.)  Nothing spills, the partial dh tiles of all four 32-column
+// blocks fit LDS at once (one exchange per step) and the sum runs over 8 partials.
 constexpr int LDP8 = 132;      // floats per row of a partial dh tile (128 + 4)
 __global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                            const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
@@ -528,18 +473,44 @@ __global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ g
 
 extern "C" {
 
+static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
+                             float* h_out, float* c_out, const XIn& xi, void* stream) {
+    const dim3 grid(rlt_cdiv(B, LISTS), 2), block(1024);
+    hipStream_t st = rlt_stream(stream);
+    if (rlt_precision() == RLT_PRECISION_BF16X3) {
+        if (xi.x) hipLaunchKernelGGL(bilstm3_fwd_kernel<true>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+        else hipLaunchKernelGGL(bilstm3_fwd_kernel<false>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+    } else {
+        if (xi.x) hipLaunchKernelGGL(bilstm_fwd_kernel<true>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+        else hipLaunchKernelGGL(bilstm_fwd_kernel<false>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+    }
+    return RLT_LAUNCH_RESULT();
+}
+
 int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
                        float* h_out, float* c_out, void* stream) {
     RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
     if (!(rlt_aligned16(gates) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(h_out) && rlt_aligned16(c_out)))
         return RLT_E_ALIGN;
-    if (rlt_precision() == RLT_PRECISION_BF16X3)
-        hipLaunchKernelGGL(bilstm3_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
-                           gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
-    else
-        hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), 0, rlt_stream(stream),
-                           gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out);
-    return RLT_LAUNCH_RESULT();
+    XIn xi{};
+    return launch_bilstm_fwd(gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi, stream);
+}
+
+int rlt_bilstm_rec_fwd_x(const float* x, int I, const float* w_ih_fwd, const float* b_ih_fwd, const float* b_hh_fwd,
+                         const float* w_ih_rev, const float* b_ih_rev, const float* b_hh_rev,
+                         const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
+                         float* gates, float* h_out, float* c_out, void* stream) {
+    RLT_CHECK_ARG(x && w_ih_fwd && b_ih_fwd && b_hh_fwd && w_ih_rev && b_ih_rev && b_hh_rev);
+    RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
+    RLT_CHECK_SHAPE(I >= 1 && I <= 3);
+    if (!(rlt_aligned16(gates) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(h_out) && rlt_aligned16(c_out)))
+        return RLT_E_ALIGN;
+    XIn xi{};
+    xi.x = x; xi.I = I;
+    xi.w_ih[0] = w_ih_fwd; xi.w_ih[1] = w_ih_rev;
+    xi.b_ih[0] = b_ih_fwd; xi.b_ih[1] = b_ih_rev;
+    xi.b_hh[0] = b_hh_fwd; xi.b_hh[1] = b_hh_rev;
+    return launch_bilstm_fwd(gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi, stream);
 }
 
 int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
@@ -550,15 +521,10 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
     const size_t shm = (size_t)16 * LISTS * LDP * sizeof(float);
     const size_t shm8 = (size_t)8 * LISTS * LDP8 * sizeof(float);
     int rc = rlt_allow_lds(bilstm_bwd_kernel, shm);
-    if (!rc) rc = rlt_allow_lds(bilstm3_bwd_kernel, shm);
     if (!rc) rc = rlt_allow_lds(bilstm3_bwd8_kernel, shm8);
     if (rc) return rc;
-    static const bool wide = getenv("RLT_LSTM_BWD_1024") != nullptr;     // experiment switch: the 1024-thread form
-    if (rlt_precision() == RLT_PRECISION_BF16X3 && !wide)
+    if (rlt_precision() == RLT_PRECISION_BF16X3)
         hipLaunchKernelGGL(bilstm3_bwd8_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(512), shm8, rlt_stream(stream),
-                           gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
-    else if (rlt_precision() == RLT_PRECISION_BF16X3)
-        hipLaunchKernelGGL(bilstm3_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),
                            gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
     else
         hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(1024), shm, rlt_stream(stream),

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
+    "rlt_bilstm_rec_fwd_x": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),
     "rlt_from_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -250,12 +250,17 @@ class BiLSTMLayerFn(Function):
         if H4 != 512 or w_hh_f.shape != (512, 128):
             raise RuntimeError("the HIP BiLSTM kernel is specialised for hidden_size=128 (as the reference hard-codes)")
         gates = _empty((T, 2 * H4), x)
-        # input projections of both directions, biases b_ih + b_hh folded in
-        gemm(0, 1, T, H4, I, x, I, w_ih_f, I, gates, 2 * H4, bias=b_ih_f, bias2=b_hh_f)
-        gemm(0, 1, T, H4, I, x, I, w_ih_r, I, gates, 2 * H4, bias=b_ih_r, bias2=b_hh_r, c_off=H4)
         h = _empty((T, 256), x)
         c = _empty((T, 256), x)
-        call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(h), ptr(c), stream())
+        if I <= 3:
+            # narrow input (layer 0): the projection is formed inside the recurrence, no pre-activation round trip
+            call("rlt_bilstm_rec_fwd_x", ptr(x), I, ptr(w_ih_f), ptr(b_ih_f), ptr(b_hh_f), ptr(w_ih_r), ptr(b_ih_r),
+                 ptr(b_hh_r), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(gates), ptr(h), ptr(c), stream())
+        else:
+            # input projections of both directions, biases b_ih + b_hh folded in
+            gemm(0, 1, T, H4, I, x, I, w_ih_f, I, gates, 2 * H4, bias=b_ih_f, bias2=b_hh_f)
+            gemm(0, 1, T, H4, I, x, I, w_ih_r, I, gates, 2 * H4, bias=b_ih_r, bias2=b_hh_r, c_off=H4)
+            call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(h), ptr(c), stream())
         ctx.dims = (S, B, I)
         ctx.save_for_backward(x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h)
         ctx.used = False
