@@ -73,13 +73,7 @@ def encoder(x_pm, params, n_head, S, B, drop_p=0.0):
     the FFN hidden dropout and dropout2 (FFN branch)."""
     h = x_pm
     for layer in params.layers.children():
-        att = layer.self_attn
-        qkv = ops.linear(h, att.in_proj_weight, att.in_proj_bias)
-        ctx_ = ops.list_attention(qkv, S, B, n_head, drop_p)
-        proj = ops.linear(ctx_, att.out_proj.weight, att.out_proj.bias)
-        h1 = ops.add_layernorm(h, proj, layer.norm1.weight, layer.norm1.bias, drop_p=drop_p)
-        ff = ops.ffn(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, drop_p)
-        h = ops.add_layernorm(h1, ff, layer.norm2.weight, layer.norm2.bias, drop_p=drop_p)
+        h = ops.encoder_layer(h, layer, S, B, n_head, drop_p)
     return h
 
 
