@@ -144,6 +144,14 @@ int rlt_colsum(const float* X, int ldx, int T, int N, float* out, int accumulate
 /* out[g][n] (+)= sum_{r<R} X[(g*R + r)*ldx + n] for g < G: per-position sums (Choopy dPE) */
 int rlt_segment_colsum(const float* X, int ldx, int G, int R, int N, float* out, int ldo,
                        int accumulate, void* stream);
+
+/* Narrow weight gradient of an input projection: dW[M][I] = A^T X and db[M] = column sums of A, for 1 <= I <= 3
+ * (the LSTM layer-0 input weights, input_size = 3, models/AttnCut.py:8; replaces the N = 3 case of the dW GEMM and
+ * its bias-gradient side sum with ONE streaming pass over A for both directions).  A (T, lda >= M, M % 4 == 0),
+ * X (T, ldx >= I); db may be NULL. */
+size_t rlt_narrow_dw_workspace(int T, int M);
+int rlt_narrow_dw(const float* A, int lda, const float* X, int ldx, int I, int T, int M,
+                  float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 /* y = max(x,0) backward etc. are fused in the kernels; dX *= (Y > 0) in place (FFN backward) */
 int rlt_relu_bwd(float* dX, const float* Y, size_t n, void* stream);
 /* x[i] *= *scale (device scalar) */

@@ -669,6 +669,44 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= f;
 }
 
+// ---- narrow weight gradient: dW[M][I] = A^T X, db[M] = column sums of A, for I <= 3 ------------------------
+// The LSTM layer-0 input weights (I = 3 features): as a GEMM this is a 128x128-tile product with N = 3, one pass
+// over A (the 5 GB gate-gradient stash) per direction at ~2 TB/s.  Here one streaming pass covers all M columns of
+// both directions: a 256-thread workgroup owns whole rows (thread = 4 consecutive columns, 16-byte loads), a chunk of
+// rows, and 16 register accumulators; fixed-order two-level reduction (bitwise reproducible).
+constexpr int NDW_CHUNKS = 2048;
+__global__ __launch_bounds__(256) void narrow_dw_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X,
+                                                                int ldx, int I, int T, int M, int rows_per_wg,
+                                                                float* __restrict__ partial) {
+    const int m4 = blockIdx.y * 256 + threadIdx.x;          // float4 column index
+    const int t0 = blockIdx.x * rows_per_wg, t1 = min(T, t0 + rows_per_wg);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, ab = a0;
+    if (4 * m4 < M) {
+        const float* ap = A + 4 * m4;
+        for (int t = t0; t < t1; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(ap + (size_t)t * lda);
+            const float* xr = X + (size_t)t * ldx;
+            const float x0 = xr[0], x1 = I > 1 ? xr[1] : 0.f, x2 = I > 2 ? xr[2] : 0.f;
+            a0.x += v.x * x0; a0.y += v.y * x0; a0.z += v.z * x0; a0.w += v.w * x0;
+            a1.x += v.x * x1; a1.y += v.y * x1; a1.z += v.z * x1; a1.w += v.w * x1;
+            a2.x += v.x * x2; a2.y += v.y * x2; a2.z += v.z * x2; a2.w += v.w * x2;
+            ab.x += v.x; ab.y += v.y; ab.z += v.z; ab.w += v.w;
+        }
+        float* pr = partial + (size_t)blockIdx.x * 4 * M + 4 * m4;   // [chunk][f][m], f = 3 holds the column sums
+        *reinterpret_cast<float4*>(pr) = a0;
+        *reinterpret_cast<float4*>(pr + M) = a1;
+        *reinterpret_cast<float4*>(pr + 2 * M) = a2;
+        *reinterpret_cast<float4*>(pr + 3 * M) = ab;
+    }
+}
+__global__ __launch_bounds__(256) void narrow_dw_scatter_kernel(const float* __restrict__ sums, int M, int I,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    for (int f = 0; f < I; ++f) dW[(size_t)m * I + f] = sums[(size_t)f * M + m];
+    if (db) db[m] = sums[(size_t)3 * M + m];
+}
+
 int ew_grid(size_t n) { size_t g = (n + 1023) / 1024; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace
@@ -763,6 +801,31 @@ int rlt_segment_colsum(const float* X, int ldx, int G, int R, int N, float* out,
                        int accumulate, void* stream) {
     RLT_CHECK_ARG(X && out && G > 0 && R > 0 && N > 0 && ldx >= N && ldo >= N);
     hipLaunchKernelGGL(segment_colsum_kernel, dim3(G), dim3(256), 0, rlt_stream(stream), X, ldx, R, N, out, ldo, accumulate);
+    return RLT_LAUNCH_RESULT();
+}
+
+size_t rlt_narrow_dw_workspace(int T, int M) {
+    if (T <= 0 || M <= 0) return 0;
+    const int rows = rlt_cdiv(T, NDW_CHUNKS);
+    const int nchunk = rlt_cdiv(T, rows);
+    return ((size_t)nchunk * 4 * M + (size_t)4 * M) * sizeof(float);
+}
+
+int rlt_narrow_dw(const float* A, int lda, const float* X, int ldx, int I, int T, int M,
+                  float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(A && X && dW && ws && T > 0 && M > 0 && lda >= M && ldx >= I);
+    RLT_CHECK_SHAPE(I >= 1 && I <= 3 && M % 4 == 0 && lda % 4 == 0);
+    if (!rlt_aligned16(A)) return RLT_E_ALIGN;
+    if (ws_bytes < rlt_narrow_dw_workspace(T, M)) return RLT_E_WORKSPACE;
+    const int rows = rlt_cdiv(T, NDW_CHUNKS);
+    const int nchunk = rlt_cdiv(T, rows);
+    float* partial = (float*)ws;
+    float* sums = partial + (size_t)nchunk * 4 * M;
+    hipStream_t st = rlt_stream(stream);
+    hipLaunchKernelGGL(narrow_dw_partial_kernel, dim3(nchunk, rlt_cdiv(M, 1024)), dim3(256), 0, st, A, lda, X, ldx, I, T, M, rows, partial);
+    hipLaunchKernelGGL(rlt_rows_reduce_kernel, dim3(rlt_cdiv(4 * M, 16)), dim3(256), 0, st, (const float*)partial, nchunk, 4 * M,
+                       4 * M, 4 * M, sums, sums, 0);
+    hipLaunchKernelGGL(narrow_dw_scatter_kernel, dim3(rlt_cdiv(M, 256)), dim3(256), 0, st, (const float*)sums, M, I, dW, db);
     return RLT_LAUNCH_RESULT();
 }
 

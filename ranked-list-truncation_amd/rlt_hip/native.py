@@ -42,6 +42,8 @@ _SIGNATURES = {
     "rlt_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rlt_colsum": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rlt_segment_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "rlt_narrow_dw_workspace": (c_size_t, [c_int, c_int]),
+    "rlt_narrow_dw": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "rlt_relu_bwd": (c_int, [P, P, c_size_t, P]),
     "rlt_scale": (c_int, [P, P, c_size_t, P]),
     "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_uint32, P, P, P]),

@@ -384,10 +384,20 @@ class BiLSTMLayerFn(Function):
         dA = gates
         db = _empty((1024,), x)
         grads_w = []
+        dw_ih_both = None
+        if I <= 3:
+            # narrow input: dW_ih of both directions and the bias gradients in ONE streaming pass over dA
+            dw_ih_both = _empty((1024, I), x)
+            ws_bytes = query("rlt_narrow_dw_workspace", T, 1024)
+            ws = workspace(ws_bytes, x.device)
+            call("rlt_narrow_dw", ptr(dA), 1024, ptr(x), I, I, T, 1024, ptr(dw_ih_both), ptr(db), ptr(ws), ws_bytes, stream())
         for d, (w_ih, _w_hh) in enumerate(((w_ih_f, w_hh_f), (w_ih_r, w_hh_r))):
-            dw_ih = _empty((512, I), x)
-            # bias gradient (column sums of dA) rides on the dW_ih product
-            gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d, colsum_a=db[512 * d:512 * (d + 1)])
+            if dw_ih_both is not None:
+                dw_ih = dw_ih_both[512 * d:512 * (d + 1)]
+            else:
+                dw_ih = _empty((512, I), x)
+                # bias gradient (column sums of dA) rides on the dW_ih product
+                gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d, colsum_a=db[512 * d:512 * (d + 1)])
             dw_hh = _empty((512, 128), x) if S > 1 else torch.zeros((512, 128), dtype=torch.float32, device=x.device)
             if S > 1:
                 K = T - B
