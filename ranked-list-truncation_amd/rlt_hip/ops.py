@@ -361,9 +361,10 @@ class BiLSTMLayerFn(Function):
             call("rlt_bilstm_rec_fwd_x", ptr(x), I, ptr(w_ih_f), ptr(b_ih_f), ptr(b_hh_f), ptr(w_ih_r), ptr(b_ih_r),
                  ptr(b_hh_r), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(gates), ptr(h), ptr(c), stream())
         else:
-            # input projections of both directions, biases b_ih + b_hh folded in
-            gemm(0, 1, T, H4, I, x, I, w_ih_f, I, gates, 2 * H4, bias=b_ih_f, bias2=b_hh_f)
-            gemm(0, 1, T, H4, I, x, I, w_ih_r, I, gates, 2 * H4, bias=b_ih_r, bias2=b_hh_r, c_off=H4)
+            # input projections of both directions as one product (x is read once), biases b_ih + b_hh folded in
+            w_cat = torch.cat((w_ih_f, w_ih_r), 0)
+            gemm(0, 1, T, 2 * H4, I, x, I, w_cat, I, gates, 2 * H4,
+                 bias=torch.cat((b_ih_f, b_ih_r)), bias2=torch.cat((b_hh_f, b_hh_r)))
             call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(h), ptr(c), stream())
         ctx.dims = (S, B, I)
         ctx.save_for_backward(x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h)
@@ -391,13 +392,12 @@ class BiLSTMLayerFn(Function):
             ws_bytes = query("rlt_narrow_dw_workspace", T, 1024)
             ws = workspace(ws_bytes, x.device)
             call("rlt_narrow_dw", ptr(dA), 1024, ptr(x), I, I, T, 1024, ptr(dw_ih_both), ptr(db), ptr(ws), ws_bytes, stream())
+        else:
+            # both directions in one product; the bias gradient (column sums of dA) rides on it
+            dw_ih_both = _empty((1024, I), x)
+            gemm(1, 0, 1024, I, T, dA, 1024, x, I, dw_ih_both, I, colsum_a=db)
         for d, (w_ih, _w_hh) in enumerate(((w_ih_f, w_hh_f), (w_ih_r, w_hh_r))):
-            if dw_ih_both is not None:
-                dw_ih = dw_ih_both[512 * d:512 * (d + 1)]
-            else:
-                dw_ih = _empty((512, I), x)
-                # bias gradient (column sums of dA) rides on the dW_ih product
-                gemm(1, 0, 512, I, T, dA, 1024, x, I, dw_ih, I, a_off=512 * d, colsum_a=db[512 * d:512 * (d + 1)])
+            dw_ih = dw_ih_both[512 * d:512 * (d + 1)]
             dw_hh = _empty((512, 128), x) if S > 1 else torch.zeros((512, 128), dtype=torch.float32, device=x.device)
             if S > 1:
                 K = T - B
@@ -409,8 +409,7 @@ class BiLSTMLayerFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty((T, I), x)
-            gemm(0, 0, T, I, 512, dA, 1024, w_ih_f, I, dx, I)
-            gemm(0, 0, T, I, 512, dA, 1024, w_ih_r, I, dx, I, flags=N.GEMM_ACCUMULATE, a_off=512)
+            gemm(0, 0, T, I, 1024, dA, 1024, torch.cat((w_ih_f, w_ih_r), 0), I, dx, I)     # one product over both directions
         db_f, db_r = db[:512], db[512:]
         (dwi_f, dwh_f), (dwi_r, dwh_r) = grads_w
         return dx, dwi_f, dwh_f, db_f, db_f, dwi_r, dwh_r, db_r, db_r, None, None
