@@ -156,6 +156,40 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
     const int ldo = to_slab ? g.N : g.ldc;
+    // interior tiles with one of the common epilogues: the bounds and mode tests are hoisted out of the per-element
+    // loop (tested per element they cost >1 ms of a K = 256 product that writes 10 GB)
+    if (m0 + BM <= g.M && n0 + BN <= g.N && !g.nt_store && g.drop_p <= 0.f) {
+        auto tile = [&](auto f) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                float bv = 0.f;
+                if (!to_slab) {
+                    if (g.bias) bv += g.bias[col];
+                    if (g.bias2) bv += g.bias2[col];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row0 = m0 + wm * 64 + i * 32 + 4 * hh;
+                    float* dst = out + (size_t)row0 * ldo + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        dst[(size_t)dr * ldo] = f(acc[i][j][r] + bv, row0 + dr, col, dst + (size_t)dr * ldo);
+                    }
+                }
+            }
+        };
+        const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
+        if (to_slab || (!relu && !accum && !g.mask)) { tile([](float v, int, int, const float*) { return v; }); return; }
+        if (relu && !accum && !g.mask) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
+        if (accum && !relu && !g.mask) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
+        if (g.mask && !relu && !accum) {
+            const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
+            tile([=](float v, int row, int col, const float*) { return mk[(size_t)row * ldm + col] > 0.f ? v * sc : 0.f; });
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -427,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // in flight, i.e. two K tiles of global loads are outstanding per thread (the kernel is bound by
     // bytes-in-flight x latency, not by the MFMA pipe)
     Stage3 a0, b0, a1, b1;
+    const bool edge = m0 + BM > g.M || n0 + BN > g.N || ((kend - kbeg) & (BK3 - 1)) != 0;      // workgroup-uniform
     const bool want_cs = TA && g.colsum != nullptr && tn == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int t, Stage3& sa, Stage3& sb) {
@@ -441,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         // above the MFMA block that is meant to hide the load latency
         __builtin_amdgcn_sched_barrier(0);
         const int k0 = kbeg + t * BK3;
-        if (FAST) {
+        if (FAST && edge) {            // interior workgroups with whole K tiles load nothing out of range
             mask3<!TA>(sa, tid, m0, k0, g.M, kend);
             mask3<TB>(sb, tid, n0, k0, g.N, kend);
         }
