@@ -216,15 +216,17 @@ def main():
         step_flop = step_algorithmic_flops(args.model, B, S) if args.model == "attncut" else None
         step_bytes = 16.0e6 * B if args.model == "attncut" else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/r01_i_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
+        # same command (tools/pmc_traffic.py -> profiles/r01_m_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
         # applied); only quoted for the exact workload and kernel it was measured on
         traffic = None
+        step_traffic = None
         try:
-            with open(os.path.join(REPO, "profiles", "r01_i_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_m_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if (args.model == "attncut" and B == 4096 and S == 300 and precision == "bf16x3"
                     and all(kern.startswith(k) for k in pmc["dominant_launch"])):
                 traffic = pmc["traffic_bytes_per_launch"]
+                step_traffic = pmc.get("step_traffic_bytes")
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -249,7 +251,11 @@ def main():
                              "frac_of_f32_mfma_peak": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
                              "algorithmic_GB": round(step_bytes / 1e9, 1),
                              "hbm_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                             "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 8.0e12, 4)}},
+                             "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 8.0e12, 4),
+                             # all kernels' FETCH_SIZE/WRITE_SIZE of one step (same PMC passes as `traffic`) / this run's time
+                             "measured_traffic_GB": None if step_traffic is None else round(step_traffic / 1e9, 1),
+                             "measured_hbm_GBps": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9, 1),
+                             "measured_frac_of_hbm_peak": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 8.0e12, 4)}},
             "train_state": {"loss": round(float(loss.detach()), 6), "f1": round(float(f1), 6), "dcg": round(float(dcg), 6)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,6 +34,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, dominant, workload = sys.argv[1:5]
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3          # bench steps + warm-ups in the profiled command
     fetch = per_kernel(fetch_csv, "FETCH_SIZE")
     write = per_kernel(write_csv, "WRITE_SIZE")
     fk = [k for k in fetch if k.startswith(dominant)]
@@ -42,7 +43,10 @@ def main():
         sys.exit(f"kernel {dominant} not found in the counter files")
     read_b = 2.0 * 1024.0 * sum(fetch[k]["mean_kb"] for k in fk)
     write_b = 1024.0 * sum(write[k]["mean_kb"] for k in wk)
-    json.dump({"workload": workload, "dominant_launch": fk, "read_bytes_per_launch": read_b,
+    step_b = (sum(2.0 * 1024.0 * v["mean_kb"] * v["launches"] for v in fetch.values())
+              + sum(1024.0 * v["mean_kb"] * v["launches"] for v in write.values())) / steps
+    json.dump({"workload": workload, "dominant_launch": fk, "step_traffic_bytes": step_b, "steps_profiled": steps,
+               "read_bytes_per_launch": read_b,
                "write_bytes_per_launch": write_b, "traffic_bytes_per_launch": read_b + write_b,
                "note": "FETCH_SIZE (KB) doubled per the gfx950 correction, WRITE_SIZE (KB) as is; separate --pmc passes",
                "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}, sys.stdout, indent=1)
