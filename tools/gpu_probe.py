@@ -247,7 +247,8 @@ def attention():
 @section
 def lstm():
     import models as hm
-    for (B, S, I) in [(5, 12, 3), (40, 30, 3), (70, 9, 256), (33, 300, 3)]:
+    # I <= 3 takes the fused input projection (rlt_bilstm_rec_fwd_x) and rlt_narrow_dw; wider inputs the GEMM path
+    for (B, S, I) in [(5, 12, 3), (40, 30, 3), (70, 9, 256), (33, 300, 3), (6, 7, 1), (6, 7, 2), (6, 7, 4)]:
         ref = torch.nn.LSTM(I, 128, num_layers=2, batch_first=True, bidirectional=True)
         x = torch.randn(B, S, I)
         dh = torch.randn(B, S, 256)
