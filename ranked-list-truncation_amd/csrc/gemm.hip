@@ -33,6 +33,9 @@ struct GemmArgs {
     float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
     int nt_store;        // write C with non-temporal stores (streamed output: keep the operands in L2)
     int slab_xcd;        // split-K launched as a 1-D grid with K slabs pinned to XCDs (see decode_block)
+    uint32_t* bits_out;  // with RLT_GEMM_RELU: 1 bit per output element (C > 0), row-major, ldbits words per row
+    const uint32_t* bits_in;   // epilogue mask from such bits: C = bit ? C * mask_scale : 0
+    int ldbits;
 };
 
 // (tile, K slab) of this workgroup.
@@ -181,10 +184,27 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
             }
         };
         const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
-        if (to_slab || (!relu && !accum && !g.mask)) { tile([](float v, int, int, const float*) { return v; }); return; }
-        if (relu && !accum && !g.mask) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
-        if (accum && !relu && !g.mask) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
-        if (g.mask && !relu && !accum) {
+        if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) { tile([](float v, int, int, const float*) { return v; }); return; }
+        if (relu && !accum && !g.mask && !g.bits_out && !g.bits_in) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
+        if (accum && !relu && !g.mask && !g.bits_in) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
+        if (g.bits_out && relu && !accum && !g.mask && !to_slab) {
+            uint32_t* bo = g.bits_out; const int ldw = g.ldbits;
+            tile([=](float v, int row, int col, const float*) {
+                v = fmaxf(v, 0.f);
+                const unsigned long long bal = __ballot(v > 0.f);
+                if (l31 == 0) bo[(size_t)row * ldw + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
+                return v;
+            });
+            return;
+        }
+        if (g.bits_in && !relu && !accum && !g.mask && !to_slab) {
+            const uint32_t* bi = g.bits_in; const int ldw = g.ldbits; const float sc = g.mask_scale;
+            tile([=](float v, int row, int col, const float*) {
+                return ((bi[(size_t)row * ldw + (col >> 5)] >> (col & 31)) & 1u) ? v * sc : 0.f;
+            });
+            return;
+        }
+        if (g.mask && !relu && !accum && !g.bits_in && !g.bits_out) {
             const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
             tile([=](float v, int row, int col, const float*) { return mk[(size_t)row * ldm + col] > 0.f ? v * sc : 0.f; });
             return;
@@ -208,6 +228,11 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
                 float v = acc[i][j][r];
                 float* dst = out + (size_t)row * ldo + col;
                 if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
+                if (!to_slab && g.bits_in) v = ((g.bits_in[(size_t)row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? v * g.mask_scale : 0.f;
+                if (!to_slab && g.bits_out) {
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
+                }
                 if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
             }
         }
@@ -763,12 +788,12 @@ int rlt_gemm(int ta, int tb, int M, int N, int K,
                        0.0f, 0u, ws, ws_bytes, stream);
 }
 
-int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
-                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                const float* bias, const float* bias2, int flags,
-                const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
-                float drop_p, uint32_t seed,
-                void* ws, size_t ws_bytes, void* stream) {
+static int gemm_run(int ta, int tb, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, const float* bias2, int flags,
+                    const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
+                    float drop_p, uint32_t seed, uint32_t* bits_out, const uint32_t* bits_in,
+                    void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
     RLT_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N);
     RLT_CHECK_ARG(!relu_mask || ldmask >= N);
@@ -776,6 +801,7 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
+    g.bits_out = bits_out; g.bits_in = bits_in; g.ldbits = N / 32;
     static const int nt = [] { const char* e = getenv("RLT_GEMM_NT"); return e ? atoi(e) : 0; }();
     g.nt_store = nt;
     g.mask_scale = mask_scale; g.drop_p = drop_p; g.drop_thr = rlt_drop_threshold(drop_p); g.seed = seed;
@@ -785,7 +811,7 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     g.vecB = (ldb % 4 == 0) && rlt_aligned16(B);
     g.flags = flags;
     g.tiles_m = rlt_cdiv(M, BM); g.tiles_n = rlt_cdiv(N, BN);
-    int ns = choose_split(M, N, K);
+    int ns = (bits_out || bits_in) ? 1 : choose_split(M, N, K);       // the bit epilogues live in the GEMM kernel proper
     if (ns > 1 && (!ws || ws_bytes < ((size_t)ns * M * N + (size_t)ns * M) * sizeof(float))) {
         if (ws == nullptr && ws_bytes == 0) ns = 1; else return RLT_E_WORKSPACE;
     }
@@ -814,6 +840,27 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     if (ns > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_grid((size_t)M * N)), dim3(256), 0, st, g, ns);
     return RLT_LAUNCH_RESULT();
+}
+
+int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
+                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* bias2, int flags,
+                const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
+                float drop_p, uint32_t seed,
+                void* ws, size_t ws_bytes, void* stream) {
+    return gemm_run(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, relu_mask, ldmask, mask_scale, colsum_a,
+                    drop_p, seed, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int rlt_gemm_bits(int ta, int tb, int M, int N, int K,
+                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, int flags, uint32_t* relu_bits_out, const uint32_t* mask_bits_in, float mask_scale,
+                  void* stream) {
+    RLT_CHECK_ARG((relu_bits_out != nullptr) != (mask_bits_in != nullptr));
+    RLT_CHECK_ARG(!relu_bits_out || (flags & RLT_GEMM_RELU));
+    RLT_CHECK_SHAPE(N % 32 == 0);
+    return gemm_run(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, flags, nullptr, 0, mask_scale, nullptr,
+                    0.f, 0u, relu_bits_out, mask_bits_in, nullptr, 0, stream);
 }
 
 size_t rlt_colsum_workspace(int T, int N) {

@@ -75,6 +75,13 @@ def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=
          ptr(relu_mask), ldmask, mask_scale, ptr(colsum_a), drop_p, seed, ptr(ws), ws_bytes, stream())
 
 
+def gemm_bits(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, bits_out=None, bits_in=None, mask_scale=1.0):
+    """rlt_gemm_bits: ReLU forward that also emits a 1-bit mask (bits_out, int32 (M, N/32)), or the masked backward
+    product that consumes it (bits_in)."""
+    call("rlt_gemm_bits", ta, tb, M, Nn, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), flags,
+         ptr(bits_out), ptr(bits_in), mask_scale, stream())
+
+
 def colsum(X, ldx, T, Nn, out, accumulate=0, x_off=0):
     ws_bytes = query("rlt_colsum_workspace", T, Nn)
     ws = workspace(ws_bytes, X.device)
@@ -269,7 +276,13 @@ class EncoderLayerFn(Function):
         st1 = _empty((T, 2), x)
         call("rlt_add_layernorm_fwd", ptr(x), ptr(proj), ptr(n1_w), ptr(n1_b), T, E, eps, drop_p, s_ln1, ptr(h1), ptr(st1), stream())
         hid = _empty((T, Fh), x)
-        gemm(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=s_ffn)
+        relu_bits = None
+        if drop_p == 0 and Fh % 32 == 0:
+            # 1-bit ReLU mask for the backward dH product (reads T*Fh/8 bytes instead of the 4*T*Fh of `hid`)
+            relu_bits = torch.empty((T, Fh // 32), dtype=torch.int32, device=x.device)
+            gemm_bits(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, bits_out=relu_bits)
+        else:
+            gemm(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=s_ffn)
         ff = _empty((T, E), x)
         gemm(0, 1, T, E, Fh, hid, Fh, w2, Fh, ff, E, bias=b2)
         y = _empty((T, E), x)
@@ -277,6 +290,7 @@ class EncoderLayerFn(Function):
         call("rlt_add_layernorm_fwd", ptr(h1), ptr(ff), ptr(n2_w), ptr(n2_b), T, E, eps, drop_p, s_ln2, ptr(y), ptr(st2), stream())
         ctx.cfg = (S, B, H, HD, eps, drop_p, seeds)
         ctx.images = images
+        ctx.relu_bits = relu_bits
         ctx.save_for_backward(x, in_w, out_w, n1_w, w1, w2, n2_w, qkv, att, lse, proj, st1, h1, hid, ff, st2)
         return y
 
@@ -303,7 +317,11 @@ class EncoderLayerFn(Function):
         dw2, db2 = _empty((E, Fh), x), _empty((E,), x)
         gemm(1, 0, E, Fh, T, dr2, E, hid, Fh, dw2, Fh, colsum_a=db2)
         dhid = _empty((T, Fh), x)
-        gemm(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, relu_mask=hid, ldmask=Fh, mask_scale=1.0 / (1.0 - drop_p))
+        if ctx.relu_bits is not None:
+            gemm_bits(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, bits_in=ctx.relu_bits)
+            ctx.relu_bits = None
+        else:
+            gemm(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, relu_mask=hid, ldmask=Fh, mask_scale=1.0 / (1.0 - drop_p))
         dw1, db1 = _empty((Fh, E), x), _empty((Fh,), x)
         gemm(1, 0, Fh, E, T, dhid, Fh, h1, E, dw1, E, colsum_a=db1)
         gemm(0, 0, T, E, Fh, dhid, Fh, w1, E, dz2, E, flags=N.GEMM_ACCUMULATE)       # dh1 = dz2 + dhid W1, in place

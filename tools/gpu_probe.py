@@ -78,6 +78,21 @@ def gemm():
         ref = (A.t().double() @ B.double()) * (mask > 0)
         report(f"gemm_ex mask {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
         report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
+    # 1-bit ReLU mask pair (rlt_gemm_bits): interior and edge tiles
+    for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256)]:
+        A, W, bias = torch.randn(M, K), torch.randn(Nn, K), torch.randn(Nn)
+        H = torch.empty(M, Nn, device=dev)
+        bits = torch.zeros(M, Nn // 32, dtype=torch.int32, device=dev)
+        ops.gemm_bits(0, 1, M, Nn, K, A.to(dev), K, W.to(dev), K, H, Nn, bias=bias.to(dev), flags=N.GEMM_RELU, bits_out=bits)
+        ref = torch.relu(A.double() @ W.double().t() + bias.double())
+        report(f"gemm_bits relu fwd {M}x{Nn}x{K}", rel(H, ref), mfma_tol(1e-5))
+        unpacked = ((bits.cpu().unsqueeze(2) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(M, Nn).bool()
+        report(f"gemm_bits mask bits {M}x{Nn}x{K}", float((unpacked != (H.cpu() > 0)).sum()), 0)
+        dY, W2 = torch.randn(M, K), torch.randn(K, Nn)
+        dH = torch.empty(M, Nn, device=dev)
+        ops.gemm_bits(0, 0, M, Nn, K, dY.to(dev), K, W2.to(dev), Nn, dH, Nn, bits_in=bits, mask_scale=1.25)
+        refd = (dY.double() @ W2.double()) * (H.cpu() > 0) * 1.25
+        report(f"gemm_bits masked bwd {M}x{Nn}x{K}", rel(dH, refd), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
     X = torch.randn(5000, 300)
     out = torch.empty(300, device=dev)
     ops.colsum(X.to(dev), 300, 5000, 300, out)
