@@ -154,18 +154,21 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
 }
 
 // ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
-__device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0,
-                                             int wm, int wn, int l31, int hh, int z) {
+// wavefront tile = 64 rows (2 MFMA blocks) x 32*NJ columns at (rbase, cbase); `interior`: the whole workgroup tile is
+// inside C
+template <int NJ>
+__device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (&acc)[2][NJ], int rbase, int cbase,
+                                               bool interior, int l31, int hh, int z) {
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
     const int ldo = to_slab ? g.N : g.ldc;
     // interior tiles with one of the common epilogues: the bounds and mode tests are hoisted out of the per-element
     // loop (tested per element they cost >1 ms of a K = 256 product that writes 10 GB)
-    if (m0 + BM <= g.M && n0 + BN <= g.N && !g.nt_store && g.drop_p <= 0.f) {
+    if (interior && !g.nt_store && g.drop_p <= 0.f) {
         auto tile = [&](auto f) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l31;
+            for (int j = 0; j < NJ; ++j) {
+                const int col = cbase + j * 32 + l31;
                 float bv = 0.f;
                 if (!to_slab) {
                     if (g.bias) bv += g.bias[col];
@@ -173,7 +176,7 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int row0 = m0 + wm * 64 + i * 32 + 4 * hh;
+                    const int row0 = rbase + i * 32 + 4 * hh;
                     float* dst = out + (size_t)row0 * ldo + col;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -211,8 +214,8 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = cbase + j * 32 + l31;
         if (col >= g.N) continue;
         float bv = 0.f;
         if (!to_slab) {
@@ -223,7 +226,7 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, hh);
+                const int row = rbase + i * 32 + acc_row(r, hh);
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 float* dst = out + (size_t)row * ldo + col;
@@ -237,6 +240,11 @@ __device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&a
             }
         }
     }
+}
+
+__device__ __forceinline__ void write_output(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0,
+                                             int wm, int wn, int l31, int hh, int z) {
+    write_output_t<2>(g, acc, m0 + wm * 64, n0 + wn * 64, m0 + BM <= g.M && n0 + BN <= g.N, l31, hh, z);
 }
 
 // 8 threads hold partial sums of the same 4 columns m: reduce through LDS.  KLOW = false: the 8 threads are
@@ -558,6 +566,190 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     if (want_cs) finish_colsum<true>(g, csum, gsm, tid, m0, zslab);
 }
 
+// ======================================================================================================
+// 256 x 256 tile, 8 wavefronts (4 x 2, each 64 x 128: 128 accumulator VGPRs), one workgroup per CU.
+// The 128 x 128 kernel above moves (128 + 128) * K * 4 bytes from L2 per 128 * 128 * K MACs; measured, every large
+// product here drives the L2 at 9-10.7 TB/s of request bandwidth (TCC_REQ, profiles/r01_h_ablation_notes.md) - that,
+// not the matrix pipe or HBM, is what the 128-wide tiles saturate.  A 256 x 256 tile halves the L2 bytes per MAC
+// and cuts the LDS fragment reads per MFMA from 0.67 to 0.5.  Interior tiles and whole K tiles only (the host falls
+// back to gemm3_kernel otherwise).  LDS: [buf][A_hi | A_lo | B_hi | B_lo], planes of 256 rows x 64 bytes (32 bf16),
+// no padding: the four 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128
+// fragment reads conflict-free for the instruction's lane groups; 2 x 64 KB.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int PL2 = 256 * 32;
+__device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <bool KC>
+__device__ __forceinline__ void load3b(const float* __restrict__ P, int ld, int mn0, int k0, int tid, Stage3& st) {
+    if (KC) {           // [MN][K]: element idx of the 2048 float4 of a 256 x 32 tile -> (row, 16-byte k group)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(mn0 + (idx >> 3)) * ld + k0 + 4 * (idx & 7));
+        }
+    } else {            // [K][MN]: thread owns a 4(k) x 4(mn) block, k block in the low lane bits
+        const int kb = tid & 7, mb = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(k0 + 4 * kb + i) * ld + mn0 + 4 * mb);
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void store3b(uint16_t* __restrict__ Thi, uint16_t* __restrict__ Tlo, int tid, const Stage3& st) {
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            const int row = idx >> 3, kq = idx & 7;
+            const int off = row * 32 + 8 * swz2(row, kq >> 1) + 4 * (kq & 1);
+            uint2 hi, lo;
+            split4(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, hi, lo);
+            *reinterpret_cast<uint2*>(Thi + off) = hi;
+            *reinterpret_cast<uint2*>(Tlo + off) = lo;
+        }
+    } else {
+        const int kb = tid & 7, mb = tid >> 3;
+        const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
+        const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
+        const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
+        const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * mb + c;
+            const int off = row * 32 + 8 * swz2(row, kb >> 1) + 4 * (kb & 1);
+            uint2 hi, lo;
+            split4(f0[c], f1[c], f2[c], f3[c], hi, lo);
+            *reinterpret_cast<uint2*>(Thi + off) = hi;
+            *reinterpret_cast<uint2*>(Tlo + off) = lo;
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    int bid, zslab;
+    decode_block(g, bid, zslab);                     // g.tiles_* count 256-wide tiles here
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int kbeg = zslab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stage3 sa, sb;
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int t) {
+        const int k0 = kbeg + t * BK3;
+        load3b<!TA>(g.A, g.lda, m0, k0, tid, sa);
+        load3b<TB>(g.B, g.ldb, n0, k0, tid, sb);
+    };
+    auto stash = [&](int buf) {
+        if (want_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+        }
+        uint16_t* nb = lds + buf * 4 * PL2;
+        store3b<!TA>(nb, nb + PL2, tid, sa);
+        store3b<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb);
+    };
+    // fragment offsets: (row >> 2) & 3 of every row this lane reads equals (l31 >> 2) & 3 (row bases are multiples of 32)
+    const int sw = (l31 >> 2) & 3;
+    // 8 steps (k-step ks, 32-column block j) of 6 MFMAs; the B fragments of the next step (and the A fragments of the
+    // next k-step) are read while the current step multiplies.  The scheduling fences keep the compiler from hoisting
+    // all 24 fragment reads to the top (96 more live VGPRs than the 256 available: 158 spills).
+    auto multiply = [&](int buf) {
+        const uint16_t* pa = lds + buf * 4 * PL2 + (wm * 64 + l31) * 32;
+        const uint16_t* pb = lds + buf * 4 * PL2 + 2 * PL2 + (wn * 128 + l31) * 32;
+        bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
+        auto load_a = [&](int ks, int slot) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[slot][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * 32 + co);
+                al[slot][i] = *reinterpret_cast<const bf16x8*>(pa + PL2 + i * 32 * 32 + co);
+            }
+        };
+        auto load_b = [&](int ks, int j, int slot) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+            bh[slot] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * 32 + co);
+            bl[slot] = *reinterpret_cast<const bf16x8*>(pb + PL2 + j * 32 * 32 + co);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int ks = step >> 2, j = step & 3;
+            if (step + 1 < 8) load_b((step + 1) >> 2, (step + 1) & 3, (step + 1) & 1);
+            if (step == 2) load_a(1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[step & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int nt = (kend - kbeg) / BK3;
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(1);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        multiply(buf);                                 // tile t; the registers hold tile t+1
+        if (t + 1 < nt) stash(buf ^ 1);
+        if (t + 2 < nt) fetch(t + 2);
+        __syncthreads();
+    }
+    write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
+    if (want_cs) {                                     // 8 threads (tid = 8*mb + kb) hold partial sums of columns 4*mb..+3
+        float4* red = reinterpret_cast<float4*>(gsm);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[8 * tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 o = red[8 * tid + j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)zslab * g.M : g.colsum) + m0 + 4 * tid;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+
+// the 256-wide tile needs: split-bf16 mode, M % 256 == 0, N % 256 == 0, whole 32-wide K tiles per slab, the branch-free
+// loader preconditions (16-byte aligned operands, leading dimensions multiples of 4)
+bool gemm_big_ok(const GemmArgs& g, bool ta, bool tb) {
+    static const int off = [] { const char* e = getenv("RLT_GEMM_NO_BIG"); return e ? atoi(e) : 0; }();
+    if (off) return false;
+    if (!g.vecA || !g.vecB) return false;
+    if ((g.M % BM2) || (g.N % BN2) || (g.K % BK3) || (g.kchunk % BK3)) return false;
+    (void)ta; (void)tb;
+    return true;
+}
+template <bool TA, bool TB>
+int launch_gemm3b(GemmArgs g, int ns, hipStream_t st) {
+    const size_t shm = (size_t)2 * 4 * PL2 * sizeof(uint16_t);
+    int rc = rlt_allow_lds(gemm3b_kernel<TA, TB>, shm);
+    if (rc) return rc;
+    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
+    hipLaunchKernelGGL((gemm3b_kernel<TA, TB>), grid, dim3(512), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+
 template <bool TA, bool TB, bool FAST>
 int launch_gemm3_v(const GemmArgs& g, dim3 grid, hipStream_t st) {
     const size_t shm = (size_t)2 * 4 * TILE3 * sizeof(uint16_t);
@@ -825,7 +1017,12 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     hipStream_t st = rlt_stream(stream);
     dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     int rc = 0;
-    if (gemm_mode() == 1) {
+    if (gemm_mode() == 1 && gemm_big_ok(g, ta, tb)) {
+        if (!ta && tb) rc = launch_gemm3b<false, true>(g, ns, st);
+        else if (!ta && !tb) rc = launch_gemm3b<false, false>(g, ns, st);
+        else if (ta && !tb) rc = launch_gemm3b<true, false>(g, ns, st);
+        else rc = launch_gemm3b<true, true>(g, ns, st);
+    } else if (gemm_mode() == 1) {
         if (!ta && tb) rc = launch_gemm3<false, true>(g, grid, st);
         else if (!ta && !tb) rc = launch_gemm3<false, false>(g, grid, st);
         else if (ta && !tb) rc = launch_gemm3<true, false>(g, grid, st);
