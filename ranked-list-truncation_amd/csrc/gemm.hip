@@ -577,7 +577,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 // fragment reads conflict-free for the instruction's lane groups; 2 x 64 KB.
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int PL2 = 256 * 32;
-__device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+// physical LDS row of a logical tile row: bits 0 and 2 swapped, so that logical rows 4 apart (the two rows a 16-lane
+// ds_write_b64 group covers, in both staging maps below) land in different 16-dword halves of the 32 store banks
+__device__ __forceinline__ int prow2(int row) { return (row & ~5) | ((row & 1) << 2) | ((row >> 2) & 1); }
+// byte-16 chunk swizzle on the PHYSICAL row: makes the ds_read_b128 fragment reads conflict-free
+__device__ __forceinline__ int swz2(int prow, int chunk) { return chunk ^ ((prow >> 2) & 3); }
+// K-contiguous staging map: element idx -> (row, 16-byte k group); 16 consecutive lanes = 8 k groups x rows {r, r+4}
+__device__ __forceinline__ int kcb_row(int idx) { return (((idx >> 3) & 1) << 2) | ((idx >> 4) & 3) | ((idx >> 6) << 3); }
 
 template <bool KC>
 __device__ __forceinline__ void load3b(const float* __restrict__ P, int ld, int mn0, int k0, int tid, Stage3& st) {
@@ -585,7 +591,7 @@ __device__ __forceinline__ void load3b(const float* __restrict__ P, int ld, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 512 * i;
-            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(mn0 + (idx >> 3)) * ld + k0 + 4 * (idx & 7));
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(mn0 + kcb_row(idx)) * ld + k0 + 4 * (idx & 7));
         }
     } else {            // [K][MN]: thread owns a 4(k) x 4(mn) block, k block in the low lane bits
         const int kb = tid & 7, mb = tid >> 3;
@@ -594,35 +600,35 @@ __device__ __forceinline__ void load3b(const float* __restrict__ P, int ld, int 
             st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(k0 + 4 * kb + i) * ld + mn0 + 4 * mb);
     }
 }
+// one quarter (`part` = 0..3) of the split + LDS store of a staged operand tile
 template <bool KC>
-__device__ __forceinline__ void store3b(uint16_t* __restrict__ Thi, uint16_t* __restrict__ Tlo, int tid, const Stage3& st) {
+__device__ __forceinline__ void store3b_part(uint16_t* __restrict__ Thi, uint16_t* __restrict__ Tlo, int tid, const Stage3& st, int part) {
     if (KC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 512 * i;
-            const int row = idx >> 3, kq = idx & 7;
-            const int off = row * 32 + 8 * swz2(row, kq >> 1) + 4 * (kq & 1);
-            uint2 hi, lo;
-            split4(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, hi, lo);
-            *reinterpret_cast<uint2*>(Thi + off) = hi;
-            *reinterpret_cast<uint2*>(Tlo + off) = lo;
-        }
+        const int idx = tid + 512 * part;
+        const int row = prow2(kcb_row(idx)), kq = idx & 7;
+        const int off = row * 32 + 8 * swz2(row, kq >> 1) + 4 * (kq & 1);
+        uint2 hi, lo;
+        split4(st.v[part].x, st.v[part].y, st.v[part].z, st.v[part].w, hi, lo);
+        *reinterpret_cast<uint2*>(Thi + off) = hi;
+        *reinterpret_cast<uint2*>(Tlo + off) = lo;
     } else {
         const int kb = tid & 7, mb = tid >> 3;
         const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
         const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
         const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
         const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int row = 4 * mb + c;
-            const int off = row * 32 + 8 * swz2(row, kb >> 1) + 4 * (kb & 1);
-            uint2 hi, lo;
-            split4(f0[c], f1[c], f2[c], f3[c], hi, lo);
-            *reinterpret_cast<uint2*>(Thi + off) = hi;
-            *reinterpret_cast<uint2*>(Tlo + off) = lo;
-        }
+        const int row = prow2(4 * mb + part);
+        const int off = row * 32 + 8 * swz2(row, kb >> 1) + 4 * (kb & 1);
+        uint2 hi, lo;
+        split4(f0[part], f1[part], f2[part], f3[part], hi, lo);
+        *reinterpret_cast<uint2*>(Thi + off) = hi;
+        *reinterpret_cast<uint2*>(Tlo + off) = lo;
     }
+}
+template <bool KC>
+__device__ __forceinline__ void store3b(uint16_t* __restrict__ Thi, uint16_t* __restrict__ Tlo, int tid, const Stage3& st) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) store3b_part<KC>(Thi, Tlo, tid, st, part);
 }
 
 template <bool TA, bool TB>
@@ -664,14 +670,22 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
         store3b<!TA>(nb, nb + PL2, tid, sa);
         store3b<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb);
     };
-    // fragment offsets: (row >> 2) & 3 of every row this lane reads equals (l31 >> 2) & 3 (row bases are multiples of 32)
-    const int sw = (l31 >> 2) & 3;
+    // fragment rows: row bases are multiples of 32, so the physical row is base + prow2(l31) and its swizzle key is fixed
+    const int pl = prow2(l31);
+    const int sw = (pl >> 2) & 3;
     // 8 steps (k-step ks, 32-column block j) of 6 MFMAs; the B fragments of the next step (and the A fragments of the
     // next k-step) are read while the current step multiplies.  The scheduling fences keep the compiler from hoisting
-    // all 24 fragment reads to the top (96 more live VGPRs than the 256 available: 158 spills).
-    auto multiply = [&](int buf) {
-        const uint16_t* pa = lds + buf * 4 * PL2 + (wm * 64 + l31) * 32;
-        const uint16_t* pb = lds + buf * 4 * PL2 + 2 * PL2 + (wn * 128 + l31) * 32;
+    // all 24 fragment reads to the top (96 more live VGPRs than the 256 available).
+    // The split + LDS store of the NEXT tile (registers sa, sb) is spread over steps 4..7, two quarters per step, right
+    // behind that step's MFMAs: the wavefront issues the VALU work while its MFMAs execute.  With the stash after the
+    // whole multiply, the two wavefronts of a SIMD (same workgroup, in lock-step between the barriers) both sit in their
+    // MFMA phase, then both in their VALU phase, and the two pipes take turns.  The global loads of tile t+2 follow the
+    // last use of each staging register (A after step 5, B after step 7): a full iteration of latency cover.
+    auto multiply = [&](int buf, int t, int nt_) {
+        const uint16_t* pa = lds + buf * 4 * PL2 + (wm * 64 + pl) * 32;
+        const uint16_t* pb = lds + buf * 4 * PL2 + 2 * PL2 + (wn * 128 + pl) * 32;
+        uint16_t* nb = lds + (buf ^ 1) * 4 * PL2;
+        const bool do_stash = t + 1 < nt_, do_fetch = t + 2 < nt_;
         bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
         auto load_a = [&](int ks, int slot) {
             const int co = 8 * ((2 * ks + hh) ^ sw);
@@ -699,6 +713,21 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[step & 1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
             }
+            if (step >= 4 && do_stash) {
+                if (step == 4 && want_cs) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+                }
+                if (step < 6) {
+                    store3b_part<!TA>(nb, nb + PL2, tid, sa, 2 * (step - 4));
+                    store3b_part<!TA>(nb, nb + PL2, tid, sa, 2 * (step - 4) + 1);
+                    if (step == 5 && do_fetch) load3b<!TA>(g.A, g.lda, m0, kbeg + (t + 2) * BK3, tid, sa);
+                } else {
+                    store3b_part<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb, 2 * (step - 6));
+                    store3b_part<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb, 2 * (step - 6) + 1);
+                    if (step == 7 && do_fetch) load3b<TB>(g.B, g.ldb, n0, kbeg + (t + 2) * BK3, tid, sb);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -708,10 +737,7 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
     if (nt > 1) fetch(1);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        multiply(buf);                                 // tile t; the registers hold tile t+1
-        if (t + 1 < nt) stash(buf ^ 1);
-        if (t + 2 < nt) fetch(t + 2);
+        multiply(t & 1, t, nt);                        // tile t; stashes tile t+1 (in registers), fetches tile t+2
         __syncthreads();
     }
     write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
