@@ -216,12 +216,12 @@ def main():
         step_flop = step_algorithmic_flops(args.model, B, S) if args.model == "attncut" else None
         step_bytes = 16.0e6 * B if args.model == "attncut" else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/r01_n_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
+        # same command (tools/pmc_traffic.py -> profiles/r01_o_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
         # applied); only quoted for the exact workload and kernel it was measured on
         traffic = None
         step_traffic = None
         try:
-            with open(os.path.join(REPO, "profiles", "r01_n_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_o_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if (args.model == "attncut" and B == 4096 and S == 300 and precision == "bf16x3"
                     and all(kern.startswith(k) for k in pmc["dominant_launch"])):
