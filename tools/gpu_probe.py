@@ -62,6 +62,23 @@ def gemm():
         Ad, Bd, bd = A.to(dev), B.to(dev), bias.to(dev)
         ops.gemm(ta, tb, M, Nn, K, Ad, A.shape[1], Bd, B.shape[1], C, Nn, bias=bd)
         report(f"gemm ta={ta} tb={tb} {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
+    # 256-aligned shapes take the 256x256-tile kernel in split-bf16 mode (all four layouts, split-K, fused side sums)
+    for (ta, tb, M, Nn, K) in [(0, 1, 512, 256, 64), (0, 0, 256, 512, 96), (1, 0, 512, 256, 16384), (1, 1, 256, 256, 8192),
+                               (0, 1, 1024, 768, 256)]:
+        A = torch.randn((K, M) if ta else (M, K))
+        B = torch.randn((Nn, K) if tb else (K, Nn))
+        bias = torch.randn(Nn)
+        ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
+        C = torch.empty(M, Nn, device=dev)
+        cs = torch.empty(M, device=dev) if ta else None
+        ops.gemm(ta, tb, M, Nn, K, A.to(dev), A.shape[1], B.to(dev), B.shape[1], C, Nn, bias=bias.to(dev), colsum_a=cs)
+        report(f"gemm256 ta={ta} tb={tb} {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
+        if ta:
+            report(f"gemm256 colsum ta={ta} tb={tb} {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
+    A, B, C0 = torch.randn(512, 64), torch.randn(64, 256), torch.randn(512, 256)
+    C = C0.clone().to(dev)
+    ops.gemm(0, 0, 512, 256, 64, A.to(dev), 64, B.to(dev), 256, C, 256, flags=N.GEMM_ACCUMULATE)
+    report("gemm256 accumulate", rel(C, A.double() @ B.double() + C0.double()), mfma_tol(1e-5))
     # relu + accumulate
     A, B = torch.randn(200, 64), torch.randn(96, 64)
     C0 = torch.randn(200, 96)
@@ -79,7 +96,7 @@ def gemm():
         report(f"gemm_ex mask {M}x{Nn}x{K}", rel(C, ref), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
         report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
     # 1-bit ReLU mask pair (rlt_gemm_bits): interior and edge tiles
-    for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256)]:
+    for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256), (512, 512, 128)]:
         A, W, bias = torch.randn(M, K), torch.randn(Nn, K), torch.randn(Nn)
         H = torch.empty(M, Nn, device=dev)
         bits = torch.zeros(M, Nn // 32, dtype=torch.int32, device=dev)
