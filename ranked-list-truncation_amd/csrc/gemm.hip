@@ -31,7 +31,6 @@ struct GemmArgs {
     float* cs_slab;      // split-K partials of colsum [z][M] or null
     float drop_p; uint32_t drop_thr, seed;   // epilogue dropout on the output (after ReLU), keep -> /(1-p)
     float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
-    int nt_store;        // write C with non-temporal stores (streamed output: keep the operands in L2)
     int slab_xcd;        // split-K launched as a 1-D grid with K slabs pinned to XCDs (see decode_block)
     uint32_t* bits_out;  // with RLT_GEMM_RELU: 1 bit per output element (C > 0), row-major, ldbits words per row
     const uint32_t* bits_in;   // epilogue mask from such bits: C = bit ? C * mask_scale : 0
@@ -164,7 +163,7 @@ __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (
     const int ldo = to_slab ? g.N : g.ldc;
     // interior tiles with one of the common epilogues: the bounds and mode tests are hoisted out of the per-element
     // loop (tested per element they cost >1 ms of a K = 256 product that writes 10 GB)
-    if (interior && !g.nt_store && g.drop_p <= 0.f) {
+    if (interior && g.drop_p <= 0.f) {
         auto tile = [&](auto f) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -236,7 +235,7 @@ __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (
                     const unsigned long long bal = __ballot(v > 0.f);
                     if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
                 }
-                if (g.nt_store) __builtin_nontemporal_store(v, dst); else *dst = v;
+                *dst = v;
             }
         }
     }
@@ -883,8 +882,7 @@ int gemm_mode() {
     return forced >= 0 ? forced : rlt_precision();
 }
 
-int gemm_bk() {
-    static const int bk = [] { const char* e = getenv("RLT_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+);
     return bk;
 }
 
@@ -1020,8 +1018,6 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
     g.bits_out = bits_out; g.bits_in = bits_in; g.ldbits = N / 32;
-    static const int nt = [] { const char* e = getenv("RLT_GEMM_NT"); return e ? atoi(e) : 0; }();
-    g.nt_store = nt;
     g.mask_scale = mask_scale; g.drop_p = drop_p; g.drop_thr = rlt_drop_threshold(drop_p); g.seed = seed;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
