@@ -882,10 +882,6 @@ int gemm_mode() {
     return forced >= 0 ? forced : rlt_precision();
 }
 
-);
-    return bk;
-}
-
 int choose_split(int M, int N, int K) {
     const long long tiles = (long long)rlt_cdiv(M, BM) * rlt_cdiv(N, BN);
     if (tiles >= 256 || K < 4096) return 1;
