@@ -41,6 +41,11 @@ def test_argument_errors_are_reported_not_crashed(native):
     assert lib.rlt_gemm(0, 1, 0, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, None) == -1
     assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None, 0, None) == -1
     assert lib.rlt_heads_fwd(None, None, None, None, 1, 1, 1, 64, None, None) == -1
+    # entry points added for the narrow (input_size <= 3) LSTM layer and the 1-bit ReLU mask
+    assert lib.rlt_bilstm_rec_fwd_x(None, 3, None, None, None, None, None, None, None, None, 1, 1, None, None, None, None) == -1
+    assert lib.rlt_narrow_dw(None, 4, None, 3, 3, 1, 4, None, None, None, 0, None) == -1
+    assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, None, None, 1.0, None) == -1
+    assert native.query("rlt_narrow_dw_workspace", 1228800, 1024) > 0
 
 
 def test_models_mirror_reference_state_dict():
