@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Developer probe: odd batch / length combinations of the five models against the CPU oracle (outputs and gradients)."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "ranked-list-truncation_amd"))
+import torch
+
+import models as hm
+from oracle import models as om
+from oracle.weights import fill_state_dict, synthetic_lists
+from rlt_hip import native as N
+
+dev = torch.device("cuda")
+bad = 0
+for prec in ("bf16x3", "fp32"):
+    N.set_precision(prec)
+    for name, kw, B, S, F in [("AttnCut", {}, 2, 5, 3), ("AttnCut", {}, 33, 64, 3), ("AttnCut", {"input_size": 2}, 7, 11, 2),
+                              ("AttnCut", {"input_size": 5}, 4, 9, 5), ("Choopy", {"seq_len": 7}, 3, 7, 1),
+                              ("MtAttnCut", {"num_tasks": 2.1}, 9, 33, 3), ("MMOECut", {"seq_len": 12, "num_experts": 2}, 6, 12, 3),
+                              ("MtChoopy", {"seq_len": 20, "num_tasks": 2.2}, 5, 20, 1)]:
+        ref = getattr(om, name)(dropout=0.0, **kw)
+        fill_state_dict(ref, 7)
+        mod = getattr(hm, name)(dropout=0.0, **kw)
+        mod.load_state_dict(ref.state_dict())
+        mod = mod.to(dev)
+        x, _ = synthetic_lists(B, S, F, 3)
+        outs_r = ref(x)
+        outs_d = mod(x.to(dev))
+        outs_r = outs_r if isinstance(outs_r, (list, tuple)) else [outs_r]
+        outs_d = outs_d if isinstance(outs_d, (list, tuple)) else [outs_d]
+        g = [torch.randn_like(o) for o in outs_r]
+        sum((o * gi).sum() for o, gi in zip(outs_r, g)).backward()
+        sum((o * gi.to(dev)).sum() for o, gi in zip(outs_d, g)).backward()
+        eo = max(float((a.detach().cpu() - b.detach()).abs().max()) for a, b in zip(outs_d, outs_r))
+        eg = 0.0
+        worst = []
+        for (n1, p1), (n2, p2) in zip(mod.named_parameters(), ref.named_parameters()):
+            if p2.grad is None:
+                continue
+            # relative L2 error per parameter: a ReLU whose pre-activation is within rounding distance of zero may take
+            # either branch (tools/gpu_probe.py, dropout section).  One flipped unit moves one row of linear1's gradient -
+            # and, through dX, everything upstream - by ~1/sqrt(tokens) of the gradient's size: percent-level at these
+            # token counts.  bf16x3 pre-activations carry ~1e-5 relative error, so a few units per ~1e6 flip; in fp32
+            # mode ~1e-7, i.e. rarely any.  A wrong kernel is O(1) in this metric.
+            scale = max(float(p2.grad.norm()), 1e-3 * p2.grad.numel() ** 0.5)
+            e = float((p1.grad.cpu() - p2.grad).norm()) / scale
+            worst.append((e, n1))
+            eg = max(eg, e)
+        if os.environ.get("EDGE_VERBOSE") and eg >= 1e-3:
+            print("     worst:", [(f"{e:.1e}", n) for e, n in sorted(worst, reverse=True)[:6]])
+        ok = eo < 1e-5 and eg < (2e-2 if prec == "bf16x3" else 1e-3)      # see the comment at the metric
+        bad += not ok
+        print(f"{'OK  ' if ok else 'FAIL'} {prec:6s} {name:10s} {kw} B{B} S{S}: out err {eo:.2e} grad err {eg:.2e}", flush=True)
+sys.exit(1 if bad else 0)
