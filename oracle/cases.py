@@ -40,6 +40,13 @@ MODEL_CASES = [
           "mtcut_f1", gate_scale=1.0, w_r=0.4, w_c=0.6),
     _case("mmoecut_e3_t3_b6_s40", "MMOECut", {"num_experts": 3, "num_tasks": 3, "seq_len": 40}, 6, 40, 3, 145, MT,
           "mtcut_f1", w_r=0.4, w_c=0.6),
+    # "next" row N4: the other two mixture-of-experts models of the reference
+    _case("moecut_e3_t3_b5_s300", "MOECut", {"num_experts": 3, "num_tasks": 3}, 5, 300, 3, 151, MT,
+          "mtcut_f1", w_r=0.4, w_c=0.6),
+    _case("moecut_e4_t21_b6_s40", "MOECut", {"num_experts": 4, "num_tasks": 2.1, "seq_len": 40}, 6, 40, 3, 152, MT,
+          "mtcut_dcg", w_r=0.4, w_c=0.6),
+    _case("plecut_b5_s300", "PLECut", {}, 5, 300, 3, 161, MT, "mtcut_f1", w_r=0.4, w_c=0.6),
+    _case("plecut_b6_s40", "PLECut", {"seq_len": 40}, 6, 40, 3, 162, MT, "mtcut_dcg", w_r=0.4, w_c=0.6),
 ]
 CASE_BY_TAG = {c["tag"]: c for c in MODEL_CASES}
 
@@ -56,5 +63,5 @@ def make_criterion(losses_mod, name, case=None):
         return losses_mod.AttnCutLoss(metric=parts[1])
     if parts[0] == "mtcut":
         return losses_mod.MtCutLoss(metric=parts[1], rerank_weight=case["w_r"], classi_weight=case["w_c"],
-                                    num_tasks=case["kwargs"]["num_tasks"])
+                                    num_tasks=case["kwargs"].get("num_tasks", 3))
     raise KeyError(name)

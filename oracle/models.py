@@ -9,6 +9,8 @@ reference classes, built from stock torch-CPU modules.  Reference lines followed
     MtChoopy   models/MtChoopy.py:5-32
     MMOECut    models/MMOECut.py:56-110  (Expert :6-14, TowerCut :17-27,
                                           TowerClass :30-40, TowerRerank :43-53)
+    MOECut     models/MOECut.py:55-108   (one shared gate)
+    PLECut     models/PLECut.py:55-103   (3 experts; gates over experts {0,1}, {1,2}, {0,1,2})
 
 The one behaviour that is easy to miss: every encoder layer is a
 `nn.TransformerEncoderLayer` with `batch_first=False` that is fed a (B, S, E) tensor, so
@@ -191,7 +193,67 @@ class MMOECut(nn.Module):
         return outs
 
 
+class MOECut(nn.Module):
+    """models/MOECut.py:55-108: MMOECut with ONE gate matrix shared by all towers."""
+
+    def __init__(self, seq_len: int = 300, num_experts=3, num_tasks=3, input_size=3,
+                 encoding_size=128, d_model=256, n_head=4, num_layers=1, dropout=0.2):
+        super().__init__()
+        self.seq_len = seq_len
+        self.expert_hidden = d_model
+        self.pre_encoding = _bilstm(input_size, encoding_size)
+        self.softmax = nn.Softmax(dim=1)
+        self.experts = nn.ModuleList(
+            [Expert(d_model, n_head, num_layers, dropout) for _ in range(num_experts)])
+        self.w_gates = nn.Parameter(torch.randn(encoding_size * seq_len * 2, num_experts), requires_grad=True)
+        if num_tasks == 3:
+            towers = [TowerClass(d_model), TowerRerank(d_model), TowerCut(d_model)]
+        elif num_tasks == 2.1:
+            towers = [TowerClass(d_model), TowerCut(d_model)]
+        elif num_tasks == 2.2:
+            towers = [TowerRerank(d_model), TowerCut(d_model)]
+        else:
+            raise ValueError("num_tasks must be 3, 2.1 or 2.2")
+        self.towers = nn.ModuleList(towers)
+
+    def forward(self, x):
+        h = self.pre_encoding(x)[0]
+        expert_out = torch.stack([e(h) for e in self.experts])
+        gate = self.softmax(h.reshape(h.shape[0], -1) @ self.w_gates)              # models/MOECut.py:92
+        mixed = (gate.t()[:, :, None, None] * expert_out).sum(dim=0)               # :98-99
+        return [tower(mixed) for tower in self.towers]
+
+
+class PLECut(nn.Module):
+    """models/PLECut.py:55-103: three experts; the class tower mixes experts {0,1}, the rerank tower {1,2}, the cut
+    tower all three (gate matrices of 2, 2 and 3 columns)."""
+
+    def __init__(self, seq_len: int = 300, num_experts=3, input_size=3, encoding_size=128,
+                 d_model=256, n_head=2, num_layers=1, dropout=0.1):
+        super().__init__()
+        self.seq_len = seq_len
+        self.expert_hidden = d_model
+        self.pre_encoding = _bilstm(input_size, encoding_size)
+        self.softmax = nn.Softmax(dim=1)
+        self.experts = nn.ModuleList(
+            [Expert(d_model, n_head, num_layers, dropout) for _ in range(num_experts)])
+        self.w_gates = nn.ParameterList(
+            [nn.Parameter(torch.randn(encoding_size * seq_len * 2, n), requires_grad=True) for n in (2, 2, 3)])
+        self.towers = nn.ModuleList([TowerClass(d_model), TowerRerank(d_model), TowerCut(d_model)])
+
+    def forward(self, x):
+        h = self.pre_encoding(x)[0]
+        eo = [e(h) for e in self.experts]
+        groups = [torch.stack(eo[:2]), torch.stack(eo[1:]), torch.stack(eo)]        # models/PLECut.py:80-82
+        flat = h.reshape(h.shape[0], -1)
+        outs = []
+        for w_gate, grp, tower in zip(self.w_gates, groups, self.towers):
+            gate = self.softmax(flat @ w_gate)
+            outs.append(tower((gate.t()[:, :, None, None] * grp).sum(dim=0)))
+        return outs
+
+
 MODEL_TABLE = {
     "attncut": AttnCut, "choopy": Choopy, "mtattncut": MtAttnCut,
-    "mtchoopy": MtChoopy, "mmoecut": MMOECut,
+    "mtchoopy": MtChoopy, "mmoecut": MMOECut, "moecut": MOECut, "plecut": PLECut,
 }

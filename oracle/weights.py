@@ -26,7 +26,7 @@ def fill_state_dict(model: torch.nn.Module, seed: int, gate_scale: float = None)
         shape = tuple(ten.shape)
         if key.endswith("position_encoding"):
             val = rs.standard_normal(shape)
-        elif ".w_gates." in "." + key or key.startswith("w_gates."):
+        elif ".w_gates." in "." + key or key.startswith("w_gates.") or key == "w_gates":
             scale = gate_scale if gate_scale is not None else 1.0 / math.sqrt(shape[0])
             val = rs.standard_normal(shape) * scale
         elif "norm" in key and key.endswith("weight"):

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
         const int s = (int)(t / B), b = (int)(t % B);
         for (int h = 0; h < H; ++h) {
             float v = 0.f;
-            if (lane < HD) v = o[t * E + h * HD + lane] * dout[t * E + h * HD + lane];
+            for (int d = lane; d < HD; d += 64) v += o[t * E + h * HD + d] * dout[t * E + h * HD + d];
             v = wave_sum(v);
             if (lane == 0) delta[((size_t)s * H + h) * B + b] = v;
         }
@@ -428,7 +428,7 @@ template <int HD>
 int launch_dkv(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
     static const int occ = [] { const char* e = getenv("RLT_DKV_OCC"); return (e && atoi(e) == 1) ? 1 : 2; }();
-    if (occ == 2) {
+    if (occ == 2 && HD <= 64) {          // head dim 128 needs the 512-register form
         int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 2>, dkv_smem<HD>());
         if (rc) return rc;
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, i
 }  // namespace
 
 // 0 = exact fp32 MFMA kernels (parity mode), 1 = split-bf16 kernels of attention3.hip
-static int attn_mode() {
+static int attn_mode_any() {
     static const int forced = [] {
         const char* e = getenv("RLT_ATTN_MODE");
         if (!e) return -1;
@@ -485,6 +485,10 @@ static int attn_mode() {
     }();
     return forced >= 0 ? forced : rlt_precision();
 }
+// head dims 16 / 32 / 64 have split-bf16 kernels; 128 (PLECut: d_model 256, 2 heads, models/PLECut.py:56) runs on the
+// exact-fp32 kernels in either mode (a correct, unhurried instantiation: it is not on a benchmarked configuration)
+static int attn_mode(int HD) { return HD <= 64 ? attn_mode_any() : 0; }
+static bool hd_ok(int HD) { return HD == 16 || HD == 32 || HD == 64 || HD == 128; }
 
 extern "C" {
 
@@ -505,25 +509,26 @@ static size_t delta_bytes(int S, int B, int H) { return ((size_t)S * H * B * siz
 
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD) {
     if (S <= 0 || B <= 0 || H <= 0) return 0;
-    if (!(HD == 16 || HD == 32 || HD == 64)) return 0;
-    return attn_mode() == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 3) : 0;
+    if (!hd_ok(HD)) return 0;
+    return attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 3) : 0;
 }
 
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* images, size_t images_bytes, void* stream) {
     RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
-    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    RLT_CHECK_SHAPE(hd_ok(HD));
     if (!(rlt_aligned16(qkv) && rlt_aligned16(out))) return RLT_E_ALIGN;
     AttnArgs a{};
     a.qkv = qkv; a.o = out; a.lse_o = lse; a.S = S; a.B = B; a.H = H;
     a.scale = 1.0f / sqrtf((float)HD);
     a.drop_p = drop_p; a.drop_thr = rlt_drop_threshold(drop_p); a.seed = seed;
     hipStream_t st = rlt_stream(stream);
-    if (attn_mode() == 1 && images) {      // split-bf16: needs room for the Q/K/V tile records
+    if (attn_mode(HD) == 1 && images) {      // split-bf16: needs room for the Q/K/V tile records
         if (images_bytes < rlt_attn3_images_bytes(S, B, H, HD, 3)) return RLT_E_WORKSPACE;
         if (!rlt_aligned16(images)) return RLT_E_ALIGN;
         return rlt_attn3_run(0, a, HD, images, nullptr, st);
     }
+    if (HD == 128) return launch_fwd<128>(a, st);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
     return launch_fwd<16>(a, st);
@@ -531,15 +536,15 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
 
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
     if (S <= 0 || B <= 0 || H <= 0) return 0;
-    if (!(HD == 16 || HD == 32 || HD == 64)) return 0;
-    return delta_bytes(S, B, H) + (attn_mode() == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0);
+    if (!hd_ok(HD)) return 0;
+    return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0);
 }
 
 int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
                                    const void* images, void* ws, size_t ws_bytes, void* stream) {
     RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0);
-    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
-    const bool split = attn_mode() == 1 && images;
+    RLT_CHECK_SHAPE(hd_ok(HD));
+    const bool split = attn_mode(HD) == 1 && images;
     if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0)) return RLT_E_WORKSPACE;
     hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
@@ -554,17 +559,19 @@ int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const fl
 static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
                     int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
     RLT_CHECK_ARG(qkv && dout && lse && ws && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
-    RLT_CHECK_SHAPE(HD == 16 || HD == 32 || HD == 64);
+    RLT_CHECK_SHAPE(hd_ok(HD));
     if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
     const AttnArgs a = bwd_args(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
-    if (attn_mode() == 1 && images)
+    if (attn_mode(HD) == 1 && images)
         return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
     if (which == 1) {
+        if (HD == 128) return launch_dkv<128>(a, st);
         if (HD == 64) return launch_dkv<64>(a, st);
         if (HD == 32) return launch_dkv<32>(a, st);
         return launch_dkv<16>(a, st);
     }
+    if (HD == 128) return launch_dq<128>(a, st);
     if (HD == 64) return launch_dq<64>(a, st);
     if (HD == 32) return launch_dq<32>(a, st);
     return launch_dq<16>(a, st);

@@ -1,9 +1,12 @@
 """Plug-in surface of the hot path: the same names the reference exports from models/__init__.py:2-6
-for the five in-scope model families."""
+for the five in-scope model families, plus MOECut / PLECut from the "next" row N4
+(section 8f; models/__init__.py:7-8)."""
 from .Choopy import Choopy
 from .AttnCut import AttnCut
 from .MtChoopy import MtChoopy
 from .MtAttnCut import MtAttnCut
 from .MMOECut import MMOECut
+from .MOECut import MOECut
+from .PLECut import PLECut
 
-__all__ = ["Choopy", "AttnCut", "MtChoopy", "MtAttnCut", "MMOECut"]
+__all__ = ["Choopy", "AttnCut", "MtChoopy", "MtAttnCut", "MMOECut", "MOECut", "PLECut"]

@@ -27,7 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 logging.basicConfig(level=logging.INFO)
 
 from dataloader import at_dataloader, cp_dataloader, write_synthetic_robust04  # noqa: E402
-from models import AttnCut, Choopy, MMOECut, MtAttnCut, MtChoopy  # noqa: E402
+from models import AttnCut, Choopy, MMOECut, MOECut, MtAttnCut, MtChoopy, PLECut  # noqa: E402
 from utils import losses  # noqa: E402
 from utils.metrics import Metric  # noqa: E402
 from rlt_hip.parallel import FlatModel, FusedAdam, shard_batch  # noqa: E402
@@ -73,9 +73,16 @@ class Trainer:
             self.model = MMOECut(seq_len=self.seq_len, num_tasks=args.num_tasks, input_size=feat,
                                  dropout=args.dropout, num_experts=args.num_experts)
             self.criterion = losses.MtCutLoss(metric=args.criterion, num_tasks=args.num_tasks)
+        elif name == 'moecut':                                                 # run.py:91-96
+            self.model = MOECut(seq_len=self.seq_len, num_tasks=args.num_tasks, input_size=feat, dropout=args.dropout)
+            self.criterion = losses.MtCutLoss(metric=args.criterion, num_tasks=args.num_tasks)
+        elif name == 'mtple':                                                  # run.py:97-102
+            self.model = PLECut(seq_len=self.seq_len, input_size=feat, dropout=args.dropout, num_experts=3)
+            self.criterion = losses.MtCutLoss(metric=args.criterion, num_tasks=args.num_tasks)
         else:
-            raise ValueError(f"model {name!r} is outside the HIP hot path (choopy, attncut, mtchoopy, mtattncut, mmoecut)")
-        self.multi_task = name in ('mtchoopy', 'mtattncut', 'mmoecut')        # reference: `'m' in model_name`
+            raise ValueError(f"model {name!r} is outside the HIP hot path "
+                             "(choopy, attncut, mtchoopy, mtattncut, mmoecut, moecut, mtple)")
+        self.multi_task = name in ('mtchoopy', 'mtattncut', 'mmoecut', 'moecut', 'mtple')   # reference: `'m' in model_name`
         self.model = self.model.to(self.device)
         if args.ft and self.model_path and os.path.exists(self.model_path):
             self.load_model()

@@ -52,7 +52,8 @@ def test_models_mirror_reference_state_dict():
     import models as hm
     from oracle import models as om
     cfgs = [("AttnCut", {}), ("Choopy", {}), ("MtAttnCut", {}), ("MtChoopy", {"num_tasks": 2.1}),
-            ("MMOECut", {}), ("MMOECut", {"num_experts": 4, "num_tasks": 2.2})]
+            ("MMOECut", {}), ("MMOECut", {"num_experts": 4, "num_tasks": 2.2}),
+            ("MOECut", {}), ("MOECut", {"num_experts": 4, "num_tasks": 2.1, "seq_len": 40}), ("PLECut", {}), ("PLECut", {"seq_len": 40})]
     for name, kw in cfgs:
         a, b = getattr(hm, name)(**kw), getattr(om, name)(**kw)
         ka = [(k, tuple(v.shape)) for k, v in a.state_dict().items()]

@@ -253,7 +253,7 @@ def _attn_ref(qkv, H):          # qkv (B,S,3E) double; attention over axis 0
 @section
 def attention():
     for (B, S, H, HD) in [(5, 7, 4, 64), (63, 5, 4, 64), (130, 3, 2, 64), (200, 2, 4, 64), (5, 9, 8, 16), (70, 4, 8, 16),
-                          (33, 3, 2, 32), (300, 2, 4, 64)]:
+                          (33, 3, 2, 32), (300, 2, 4, 64), (6, 3, 2, 128), (70, 2, 2, 128), (130, 2, 1, 128)]:
         E = H * HD
         qkv = torch.randn(B, S, 3 * E)
         dout = torch.randn(B, S, E)
