@@ -301,6 +301,18 @@ int rlt_mmoe_mix_bwd(const float* const* experts, const float* gates, const floa
                      int n_tasks, int n_e, int S, int B, int E,
                      float* const* dexperts, float* dgates, void* stream);
 
+/* ------------------------------------------------------------------ BiCut (section 8f row N4)
+ * Two-class head of models/Bicut.py:11-16: position-major logits z (S*B, 2) -> Dropout on the logits -> softmax over
+ * the two classes {0: truncate, 1: continue}; out is (B, S, 2) in the reference's layout.  bwd: dz (S*B, 2). */
+int rlt_pair_softmax_fwd(const float* z, int B, int S, float drop_p, uint32_t seed, float* out, void* stream);
+int rlt_pair_softmax_bwd(const float* out, const float* dout, int B, int S, float drop_p, uint32_t seed, float* dz, void* stream);
+/* BiCutLoss (utils/losses.py:11-45) and its gradient in one pass.  out (B,S,2), labels (B,S) in {0,1}.
+ * mask = positions up to and including the last one whose argmax is class 0 (all positions when none is);
+ * metric_nci != 0: reward (0, -1/log2(j+2)) for label 1, (0, (j+1)/alpha) for label 0; otherwise ((1-alpha)/r, 0) and
+ * (0, alpha/(1-r)).  loss = sum(out * mask * reward) / B; dout = mask * reward / B; per_list (B) unnormalised. */
+int rlt_bicut_loss(const float* out, const float* labels, int B, int S, int metric_nci, float alpha, float r,
+                   float* per_list, float* loss, float* dout, void* stream);
+
 /* ------------------------------------------------------------------ optimizer (N2, run.py:104,129)
  * torch.optim.Adam with coupled L2 (grad += wd * p), bias correction, eps outside the sqrt,
  * on a flat fp32 bucket.  step: 1-based step count. */

@@ -65,3 +65,10 @@ def make_criterion(losses_mod, name, case=None):
         return losses_mod.MtCutLoss(metric=parts[1], rerank_weight=case["w_r"], classi_weight=case["w_c"],
                                     num_tasks=case["kwargs"].get("num_tasks", 3))
     raise KeyError(name)
+
+
+# BiCut: outputs are (B,S,2); criteria are BiCutLoss metrics
+BICUT_CASES = [
+    dict(tag="bicut_b5_s300", kwargs={"input_size": 3}, batch=5, seq_len=300, n_feat=3, seed=171, criteria=["nci", "f1"], grad_crit="nci"),
+    dict(tag="bicut_b8_s40_in5", kwargs={"input_size": 5}, batch=8, seq_len=40, n_feat=5, seed=172, criteria=["nci", "f1"], grad_crit="f1"),
+]

@@ -171,3 +171,42 @@ class MtCutLoss(nn.Module):
         if y_class is not None:
             loss = loss + self.classiloss(y_class.squeeze(2), labels) * self.classi_weight
         return loss
+
+
+def bicut_last_truncate(output: torch.Tensor) -> torch.Tensor:
+    """utils/losses.py:21-30 (BiCutLoss.slice_index) for a batch: index of the LAST position whose argmax over the
+    two classes is 0 (truncate), or S when every position says 1 (continue).  argmax ties go to class 0."""
+    temp = (output[..., 1] > output[..., 0])                     # True <=> argmax == 1
+    S = temp.shape[1]
+    pos = torch.arange(S).expand_as(temp)
+    last0 = torch.where(~temp, pos, torch.full_like(pos, -1)).max(dim=1).values
+    return torch.where(last0 < 0, torch.full_like(last0, S), last0)
+
+
+class BiCutLoss(nn.Module):
+    """utils/losses.py:11-45.  mask = positions up to and including the last truncate decision; r from the labels:
+    'nci': label 1 -> (0, -1/log2(j+2)), label 0 -> (0, (j+1)/alpha); any other metric: label 1 -> ((1-alpha)/r, 0),
+    label 0 -> (0, alpha/(1-r)); loss = sum(output * mask * r) / B."""
+
+    def __init__(self, alpha: float = 0.65, r: float = 0.0971134020, metric: str = 'nci'):
+        super().__init__()
+        self.metric, self.alpha, self.r = metric, alpha, r
+
+    def reward(self, labels: torch.Tensor) -> torch.Tensor:
+        B, S = labels.shape
+        pos = labels == 1
+        out = torch.zeros(B, S, 2, dtype=torch.float32)
+        j = torch.arange(S, dtype=torch.float64)
+        if self.metric == 'nci':
+            out[..., 1] = torch.where(pos, (-1.0 / torch.log2(j + 2)).float().expand(B, S),
+                                      ((j + 1) / self.alpha).float().expand(B, S))
+        else:
+            out[..., 0] = torch.where(pos, torch.tensor((1 - self.alpha) / self.r, dtype=torch.float32), torch.tensor(0.0))
+            out[..., 1] = torch.where(pos, torch.tensor(0.0), torch.tensor(self.alpha / (1 - self.r), dtype=torch.float32))
+        return out
+
+    def forward(self, output: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        idx = bicut_last_truncate(output.detach())
+        S = output.shape[1]
+        mask = (torch.arange(S).unsqueeze(0) <= idx.unsqueeze(1)).to(output.dtype).unsqueeze(2)
+        return (output * mask * self.reward(labels)).sum() / output.shape[0]

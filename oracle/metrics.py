@@ -62,3 +62,11 @@ class Metric:
     @classmethod
     def dcg(cls, labels, k_s, penalty=-1):
         return float(np.mean(dcg_per_list(labels, k_s, penalty)))
+
+
+def bicut_cut_positions(output):
+    """run.py:131-136: argmax over the two classes per position; k = S when every position says continue (1), else the
+    first truncate position + 1.  `output` numpy (B,S,2)."""
+    pred = np.argmax(output, axis=2)
+    S = pred.shape[1]
+    return np.array([S if r.sum() == S else int(np.argmin(r)) + 1 for r in pred], dtype=np.int64)

@@ -11,6 +11,8 @@ reference classes, built from stock torch-CPU modules.  Reference lines followed
                                           TowerClass :30-40, TowerRerank :43-53)
     MOECut     models/MOECut.py:55-108   (one shared gate)
     PLECut     models/PLECut.py:55-103   (3 experts; gates over experts {0,1}, {1,2}, {0,1,2})
+    BiCut      models/Bicut.py:5-21      (BiLSTM -> Linear(256,256) -> ReLU -> Linear(256,2) -> Dropout -> softmax over
+                                          the two classes {0: truncate, 1: continue} at every position)
 
 The one behaviour that is easy to miss: every encoder layer is a
 `nn.TransformerEncoderLayer` with `batch_first=False` that is fed a (B, S, E) tensor, so
@@ -253,7 +255,20 @@ class PLECut(nn.Module):
         return outs
 
 
+class BiCut(nn.Module):
+    def __init__(self, input_size=231449, lstm_hiden_size=128, lstm_layers=2, fc_dimensions=256, dropout=0.4):
+        super().__init__()
+        self.bilstm = nn.LSTM(input_size=input_size, hidden_size=lstm_hiden_size, num_layers=lstm_layers,
+                              batch_first=True, bidirectional=True)
+        self.fc = nn.Linear(in_features=lstm_hiden_size * 2, out_features=fc_dimensions)
+        self.softmax = nn.Sequential(nn.ReLU(), nn.Linear(in_features=fc_dimensions, out_features=2),
+                                     nn.Dropout(dropout), nn.Softmax(dim=2))
+
+    def forward(self, x):
+        return self.softmax(self.fc(self.bilstm(x)[0]))          # (B,S,2)
+
+
 MODEL_TABLE = {
     "attncut": AttnCut, "choopy": Choopy, "mtattncut": MtAttnCut,
-    "mtchoopy": MtChoopy, "mmoecut": MMOECut, "moecut": MOECut, "plecut": PLECut,
+    "mtchoopy": MtChoopy, "mmoecut": MMOECut, "moecut": MOECut, "plecut": PLECut, "bicut": BiCut,
 }

@@ -625,6 +625,52 @@ class RewardLossFn(Function):
         return g.view(ctx.pshape), None, None, None, None
 
 
+class PairSoftmaxFn(Function):
+    """BiCut's two-class head: position-major logits (S*B, 2) -> dropout -> softmax over the classes -> (B,S,2)."""
+
+    @staticmethod
+    def forward(ctx, z, S, B, drop_p=0.0, seed=0):
+        out = _empty((B, S, 2), z)
+        call("rlt_pair_softmax_fwd", ptr(z), B, S, drop_p, seed, ptr(out), stream())
+        ctx.cfg = (S, B, drop_p, seed)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        S, B, drop_p, seed = ctx.cfg
+        dz = _empty((S * B, 2), out)
+        call("rlt_pair_softmax_bwd", ptr(out), ptr(N.f32c(dout)), B, S, drop_p, seed, ptr(dz), stream())
+        return dz, None, None, None, None
+
+
+def pair_softmax(z, S, B, drop_p=0.0):
+    return PairSoftmaxFn.apply(z, S, B, drop_p, next_seed() if drop_p > 0 else 0)
+
+
+class BiCutLossFn(Function):
+    """utils/losses.py:11-45 with its gradient, one launch."""
+
+    @staticmethod
+    def forward(ctx, out, labels, nci, alpha, r):
+        B, S = labels.shape
+        per_list = _empty((B,), out)
+        loss = _empty((1,), out)
+        dout = _empty((B, S, 2), out)
+        call("rlt_bicut_loss", ptr(out), ptr(labels), B, S, int(nci), alpha, r, ptr(per_list), ptr(loss), ptr(dout), stream())
+        ctx.save_for_backward(dout)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (dout,) = ctx.saved_tensors
+        g = dout.clone()
+        go = N.f32c(go).reshape(1)
+        call("rlt_scale", ptr(g), ptr(go), g.numel(), stream())
+        return g, None, None, None, None
+
+
 class MtCutLossFn(Function):
     """cut JS loss + w_r * rerank hinge + w_c * BCE, one tape node (utils/losses.py:180-191)."""
 

@@ -27,7 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 logging.basicConfig(level=logging.INFO)
 
 from dataloader import at_dataloader, cp_dataloader, write_synthetic_robust04  # noqa: E402
-from models import AttnCut, Choopy, MMOECut, MOECut, MtAttnCut, MtChoopy, PLECut  # noqa: E402
+from models import AttnCut, BiCut, Choopy, MMOECut, MOECut, MtAttnCut, MtChoopy, PLECut  # noqa: E402
 from utils import losses  # noqa: E402
 from utils.metrics import Metric  # noqa: E402
 from rlt_hip.parallel import FlatModel, FusedAdam, shard_batch  # noqa: E402
@@ -54,7 +54,10 @@ class Trainer:
         loader = cp_dataloader if name in ('choopy', 'mtchoopy') else at_dataloader
         self.train_loader, self.test_loader, _ = loader(args.retrieve_data, args.dataset_name, args.batch_size,
                                                         device=self.device, base=args.dataset_base, seed=args.seed)
-        if name == 'choopy':                                                   # run.py:65-68
+        if name == 'bicut':                                                    # run.py:59-64
+            self.model = BiCut(input_size=feat, dropout=args.dropout)
+            self.criterion = losses.BiCutLoss(metric=args.criterion)
+        elif name == 'choopy':                                                 # run.py:65-68
             self.model = Choopy(seq_len=self.seq_len, dropout=args.dropout)
             self.criterion = losses.ChoopyLoss(metric=args.criterion)
         elif name == 'attncut':                                                # run.py:69-75
@@ -81,7 +84,7 @@ class Trainer:
             self.criterion = losses.MtCutLoss(metric=args.criterion, num_tasks=args.num_tasks)
         else:
             raise ValueError(f"model {name!r} is outside the HIP hot path "
-                             "(choopy, attncut, mtchoopy, mtattncut, mmoecut, moecut, mtple)")
+                             "(bicut, choopy, attncut, mtchoopy, mtattncut, mmoecut, moecut, mtple)")
         self.multi_task = name in ('mtchoopy', 'mtattncut', 'mmoecut', 'moecut', 'mtple')   # reference: `'m' in model_name`
         self.model = self.model.to(self.device)
         if args.ft and self.model_path and os.path.exists(self.model_path):
@@ -105,7 +108,7 @@ class Trainer:
             loss.backward()
             self.flat.all_reduce_grads()
             self.optimizer.step()
-        cut = output[-1] if self.multi_task else output        # run.py:137-142
+        cut = output[-1] if self.multi_task else output        # run.py:131-142 (Metric.evaluate applies BiCut's rule to (B,S,2))
         _k, f1, dcg = Metric.evaluate(cut, y)
         stats = torch.stack([loss.detach().double(), f1, dcg])
         if self.world > 1:

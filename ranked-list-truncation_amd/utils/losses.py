@@ -1,6 +1,6 @@
 """Reward losses on the HIP hot path - drop-in for the criteria of the reference's utils/losses.py
 that are on the hot path: ChoopyLoss :48-68, AttnCutLoss :71-96, RerankLoss :99-141,
-MtCutLoss :164-191, DivLoss :194-233.  Same constructor signatures; `criterion(output, labels)`
+MtCutLoss :164-191, DivLoss :194-233, and BiCutLoss :11-45 (section 8f row N4).  Same constructor signatures; `criterion(output, labels)`
 returns a 0-d tensor supporting .backward() and .item().
 
 The reference builds its (B,S) reward matrix with B*S python calls of O(S) tensor ops; here the
@@ -98,3 +98,18 @@ class MtCutLoss(nn.Module):
         return ops.MtCutLossFn.apply(p, rr, cl, y, _metric_code(self.metric), float(self.cutloss.tau),
                                      float(self.rerank_weight), float(self.classi_weight),
                                      float(self.rerankloss.margin))
+
+
+class BiCutLoss(nn.Module):
+    """utils/losses.py:11-45 on the (B,S,2) output of BiCut; the position mask, the label-dependent reward pairs, the sum
+    and d(loss)/d(output) come out of one kernel pass (`rlt_bicut_loss`)."""
+
+    def __init__(self, alpha: float = 0.65, r: float = 0.0971134020, metric: str = 'nci'):
+        super().__init__()
+        self.metric, self.alpha, self.r = metric, alpha, r
+
+    def forward(self, output, labels):
+        N.require_cuda(output, labels)
+        if output.dim() != 3 or output.shape[2] != 2:
+            raise ValueError(f"expected the (B,S,2) output of BiCut, got {tuple(output.shape)}")
+        return ops.BiCutLossFn.apply(N.f32c(output), N.f32c(labels), self.metric == 'nci', float(self.alpha), float(self.r))

@@ -52,7 +52,15 @@ class Metric:
         mean F1, mean DCG as 0-d float64 tensors) without leaving the device (run.py:137-145)."""
         p = N.f32c(output.detach())
         y = N.f32c(labels)
-        k, _f1, _dcg, sums = ops.cut_metrics(p, y)
+        if p.dim() == 3 and p.shape[2] == 2:
+            # BiCut (run.py:131-136): k = S when every position says continue, else the first truncate position + 1
+            cont = p[..., 1] > p[..., 0]                       # argmax == 1 (ties -> class 0)
+            S = cont.shape[1]
+            first0 = torch.where(~cont, torch.arange(S, device=p.device).expand_as(cont), torch.full_like(cont, S, dtype=torch.long)).min(dim=1).values
+            k_in = torch.where(first0 >= S, torch.full_like(first0, S), first0 + 1).to(torch.int32).contiguous()
+            k, _f1, _dcg, sums = ops.cut_metrics(None, y, k_in=k_in)
+        else:
+            k, _f1, _dcg, sums = ops.cut_metrics(p, y)
         mean = sums / y.shape[0]
         return k, mean[0], mean[1]
 

@@ -45,6 +45,8 @@ def test_argument_errors_are_reported_not_crashed(native):
     assert lib.rlt_bilstm_rec_fwd_x(None, 3, None, None, None, None, None, None, None, None, 1, 1, None, None, None, None) == -1
     assert lib.rlt_narrow_dw(None, 4, None, 3, 3, 1, 4, None, None, None, 0, None) == -1
     assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, None, None, 1.0, None) == -1
+    assert lib.rlt_pair_softmax_fwd(None, 1, 1, 0.0, 0, None, None) == -1
+    assert lib.rlt_bicut_loss(None, None, 1, 1, 1, 0.65, 0.1, None, None, None, None) == -1
     assert native.query("rlt_narrow_dw_workspace", 1228800, 1024) > 0
 
 
@@ -53,7 +55,7 @@ def test_models_mirror_reference_state_dict():
     from oracle import models as om
     cfgs = [("AttnCut", {}), ("Choopy", {}), ("MtAttnCut", {}), ("MtChoopy", {"num_tasks": 2.1}),
             ("MMOECut", {}), ("MMOECut", {"num_experts": 4, "num_tasks": 2.2}),
-            ("MOECut", {}), ("MOECut", {"num_experts": 4, "num_tasks": 2.1, "seq_len": 40}), ("PLECut", {}), ("PLECut", {"seq_len": 40})]
+            ("MOECut", {}), ("MOECut", {"num_experts": 4, "num_tasks": 2.1, "seq_len": 40}), ("PLECut", {}), ("PLECut", {"seq_len": 40}), ("BiCut", {"input_size": 3}), ("BiCut", {"input_size": 5, "fc_dimensions": 128})]
     for name, kw in cfgs:
         a, b = getattr(hm, name)(**kw), getattr(om, name)(**kw)
         ka = [(k, tuple(v.shape)) for k, v in a.state_dict().items()]

@@ -42,7 +42,7 @@ def probe():
     return mod
 
 
-MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models"]
+MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
 
 

@@ -143,3 +143,48 @@ def test_explicit_restatement_matches_stock_modules(tag):
     p64 = fwd(x.double(), sd).squeeze(2).numpy()
     assert np.abs(p32 - gold["out0"]).max() < 1e-6
     assert np.abs(p64 - gold["out0"]).max() < 1e-6
+
+
+# ---- BiCut / BiCutLoss ------------------------------------------------
+from oracle.cases import BICUT_CASES  # noqa: E402
+from oracle.weights import fill_state_dict, synthetic_lists  # noqa: E402
+
+
+@pytest.mark.parametrize("case", BICUT_CASES, ids=lambda c: c["tag"])
+def test_bicut_model_loss_and_cut_rule(case):
+    gold = gu.load(case["tag"])
+    model = omodels.BiCut(dropout=0.0, **case["kwargs"])
+    fill_state_dict(model, case["seed"])
+    x, y = synthetic_lists(case["batch"], case["seq_len"], case["n_feat"], case["seed"] + 1)
+    np.testing.assert_array_equal(x.numpy(), gold["x"])
+    model.train()
+    out = model(x)
+    np.testing.assert_allclose(out.detach().numpy(), gold["out0"], rtol=0, atol=1e-6)
+    k_s = ometrics.bicut_cut_positions(out.detach().numpy())
+    np.testing.assert_array_equal(k_s, gold["k_s"])
+    assert abs(ometrics.Metric.f1(y.numpy(), k_s) - float(gold["f1"])) < 1e-6
+    for metric in case["criteria"]:
+        o = model(x)
+        o.retain_grad()
+        loss = olosses.BiCutLoss(metric=metric)(o, y)
+        model.zero_grad()
+        loss.backward()
+        ref = float(gold["loss/" + metric])
+        assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref)), (metric, loss.item(), ref)
+        np.testing.assert_allclose(o.grad.numpy(), gold["dout/" + metric], rtol=1e-6, atol=1e-7)
+        if metric == case["grad_crit"]:
+            gu.check_grads(model, gold, rtol=1e-4, atol_frac=1e-4)
+
+
+def test_bicutloss_edge_rows():
+    gold = gu.load("bicutloss_edge_s50")
+    y = torch.from_numpy(gold["y"])
+    for metric in ("nci", "f1"):
+        o = torch.softmax(torch.from_numpy(gold["logits"]), dim=2).requires_grad_(True)
+        loss = olosses.BiCutLoss(metric=metric)(o, y)
+        loss.backward()
+        ref = float(gold["loss/" + metric])
+        assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref))
+        np.testing.assert_allclose(o.grad.numpy(), gold["dout/" + metric], rtol=1e-6, atol=1e-7)
+    k_s = ometrics.bicut_cut_positions(torch.softmax(torch.from_numpy(gold["logits"]), dim=2).numpy())
+    np.testing.assert_array_equal(k_s, gold["k_s"])

@@ -503,6 +503,82 @@ def dropout():
 
 
 @section
+def bicut():
+    """BiCut + BiCutLoss + the cut rule of run.py:131-136 against the reference goldens and the oracle."""
+    import golden_util as gu
+    import models as hm
+    from oracle.cases import BICUT_CASES
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from oracle import models as om
+    from utils import losses as hl
+    from utils.metrics import Metric
+    for case in BICUT_CASES:
+        gold = gu.load(case["tag"])
+        model = hm.BiCut(dropout=0.0, **case["kwargs"])
+        ref = om.BiCut(dropout=0.0, **case["kwargs"])
+        fill_state_dict(ref, case["seed"])
+        model.load_state_dict(ref.state_dict())
+        model = model.to(dev)
+        x, y = synthetic_lists(case["batch"], case["seq_len"], case["n_feat"], case["seed"] + 1)
+        model.train()
+        out = model(x.to(dev))
+        report(f"{case['tag']} out", float(np.abs(out.detach().cpu().numpy() - gold["out0"]).max()), 1e-5)
+        k, f1, _dcg = Metric.evaluate(out, y.to(dev))
+        report(f"{case['tag']} k mismatches", float((k.cpu().numpy() != gold["k_s"]).sum()), 0)
+        report(f"{case['tag']} f1", abs(float(f1) - float(gold["f1"])), 1e-4)
+        for metric in case["criteria"]:
+            o = model(x.to(dev))
+            o.retain_grad()
+            loss = hl.BiCutLoss(metric=metric)(o, y.to(dev))
+            model.zero_grad()
+            loss.backward()
+            refl = float(gold["loss/" + metric])
+            report(f"{case['tag']} loss {metric}", abs(loss.item() - refl) / max(1.0, abs(refl)), 1e-5)
+            report(f"{case['tag']} dout {metric}", float(np.abs(o.grad.cpu().numpy() - gold["dout/" + metric]).max()
+                                                         / max(1e-30, np.abs(gold["dout/" + metric]).max())), 1e-6)
+            if metric == case["grad_crit"]:
+                gu.check_grads_report(model, gold, report, case["tag"]) if hasattr(gu, "check_grads_report") else \
+                    report(f"{case['tag']} grads", _grad_err(model, gold), 1e-3)
+    gold = gu.load("bicutloss_edge_s50")
+    y = torch.from_numpy(gold["y"]).to(dev)
+    for metric in ("nci", "f1"):
+        o = torch.softmax(torch.from_numpy(gold["logits"]), dim=2).to(dev).requires_grad_(True)
+        loss = hl.BiCutLoss(metric=metric)(o, y)
+        loss.backward()
+        refl = float(gold["loss/" + metric])
+        report(f"bicutloss edge loss {metric}", abs(loss.item() - refl) / max(1.0, abs(refl)), 1e-5)
+        report(f"bicutloss edge dout {metric}", float(np.abs(o.grad.cpu().numpy() - gold["dout/" + metric]).max()), 1e-6)
+    k, _f1, _dcg = Metric.evaluate(torch.softmax(torch.from_numpy(gold["logits"]), dim=2).to(dev), y)
+    report("bicut cut rule edge rows", float((k.cpu().numpy() != gold["k_s"]).sum()), 0)
+    # two-class head with dropout: rows still sum to 1, backward matches autograd on the same masks
+    z = torch.randn(6 * 9, 2)
+    zd = z.clone().to(dev).requires_grad_(True)
+    od = ops.PairSoftmaxFn.apply(zd, 9, 6, 0.0, 0)
+    g = torch.randn(6, 9, 2)
+    od.backward(g.to(dev))
+    zr = z.clone().double().requires_grad_(True)
+    orf = torch.softmax(zr, 1).reshape(9, 6, 2).permute(1, 0, 2)
+    orf.backward(g.double())
+    report("pair_softmax fwd", rel(od, orf), 1e-6)
+    report("pair_softmax bwd", rel(zd.grad, zr.grad), 1e-5)
+    od = ops.PairSoftmaxFn.apply(zd, 9, 6, 0.3, 1234)
+    report("pair_softmax dropout rows sum to 1", float((od.sum(2) - 1).abs().max()), 1e-6)
+
+
+def _grad_err(model, gold):
+    """max over parameters of |grad summary - golden| relative to the golden scale (norm / sum / probes)."""
+    import golden_util as gu
+    worst = 0.0
+    for name, prm in model.named_parameters():
+        flat = prm.grad.detach().reshape(-1).double().cpu()
+        scale = max(float(gold["gnorm/" + name]), 1e-3)
+        worst = max(worst, abs(float(flat.norm()) - float(gold["gnorm/" + name])) / scale)
+        idx = torch.from_numpy(gu.probe_index(flat.numel(), name))
+        worst = max(worst, float((flat[idx].numpy() - gold["gprobe/" + name]).__abs__().max()) / scale)
+    return worst
+
+
+@section
 def models():
     import golden_util as gu
     import models as hm

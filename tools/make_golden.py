@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 sys.path.insert(0, REPO)
 from oracle.weights import fill_state_dict, synthetic_lists  # noqa: E402
-from oracle.cases import MODEL_CASES, SINGLE_CRITERIA, make_criterion  # noqa: E402
+from oracle.cases import BICUT_CASES, MODEL_CASES, SINGLE_CRITERIA, make_criterion  # noqa: E402
 
 # ---- import the reference (models/, utils/) -------------------------------------------------
 _stub = types.ModuleType("numpy.lib.financial")
@@ -194,6 +194,65 @@ def loss_cases():
     print("losses_edge_s300: kat_f1=%.16f kat_dcg=%.16f" % (rec["kat_f1"], rec["kat_dcg"]), flush=True)
 
 
+
+def bicut_cases():
+    """BiCut + BiCutLoss (models/Bicut.py, utils/losses.py:11-45) and the cut rule of run.py:131-136, all run by the
+    reference; outputs are (B,S,2)."""
+    for case in BICUT_CASES:
+        model = ref_models.BiCut(dropout=0.0, **case["kwargs"])
+        fill_state_dict(model, case["seed"])
+        x, y = synthetic_lists(case["batch"], case["seq_len"], case["n_feat"], case["seed"] + 1)
+        rec = {"x": x.numpy(), "y": y.numpy(), "seed": np.int64(case["seed"])}
+        model.train()
+        out = model(x)
+        rec["out0"] = out.detach().numpy()
+        pred = np.argmax(out.detach().numpy(), axis=2)                      # run.py:131-136
+        S = case["seq_len"]
+        k_s = np.array([S if r.sum() == S else np.argmin(r) + 1 for r in pred], dtype=np.int64)
+        rec["k_s"] = k_s
+        rec["f1"] = np.float64(RefMetric.f1(y.numpy(), k_s))
+        rec["dcg"] = np.float64(RefMetric.dcg(y.numpy(), k_s))
+        for metric in case["criteria"]:
+            crit = ref_losses.BiCutLoss(metric=metric)
+            o = model(x)
+            o.retain_grad()
+            loss = crit(o, y)
+            rec["loss/" + metric] = np.float64(loss.item())
+            model.zero_grad()
+            loss.backward()
+            rec["dout/" + metric] = o.grad.numpy()
+            if metric == case["grad_crit"]:
+                rec.update(grad_summary(model))
+        np.savez_compressed(os.path.join(OUT, case["tag"] + ".npz"), **rec)
+        print(f"{case['tag']}: k_s={k_s.tolist()} f1={rec['f1']:.6f} "
+              + " ".join(f"{m}={float(rec['loss/' + m]):.6f}" for m in case["criteria"]), flush=True)
+    # loss-only edge rows: every position continue / every position truncate / exact ties / random
+    rs = np.random.RandomState(173)
+    B, S = 7, 50
+    lg = rs.standard_normal((B, S, 2)).astype(np.float32)
+    lg[0, :, 1] = lg[0, :, 0] + 1.0          # all continue -> nothing masked
+    lg[1, :, 0] = lg[1, :, 1] + 1.0          # all truncate
+    lg[2, :, 1] = lg[2, :, 0]                # ties -> argmax picks class 0
+    lg[3, :-1, 1] = lg[3, :-1, 0] + 1.0      # only the last position truncates
+    lg[3, -1, 0] = lg[3, -1, 1] + 1.0
+    lg[4, 1:, 1] = lg[4, 1:, 0] + 1.0        # only the first position truncates
+    lg[4, 0, 0] = lg[4, 0, 1] + 1.0
+    y = (rs.uniform(0, 1, (B, S)) < 0.2).astype(np.float32)
+    y[5] = 0.0
+    y[6] = 1.0
+    rec = {"logits": lg, "y": y}
+    for metric in ("nci", "f1"):
+        o = torch.softmax(torch.from_numpy(lg), dim=2).requires_grad_(True)
+        loss = ref_losses.BiCutLoss(metric=metric)(o, torch.from_numpy(y))
+        loss.backward()
+        rec["loss/" + metric] = np.float64(loss.item())
+        rec["dout/" + metric] = o.grad.numpy()
+    pred = np.argmax(torch.softmax(torch.from_numpy(lg), dim=2).numpy(), axis=2)
+    rec["k_s"] = np.array([S if r.sum() == S else np.argmin(r) + 1 for r in pred], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "bicutloss_edge_s50.npz"), **rec)
+    print("bicutloss_edge_s50:", {m: float(rec["loss/" + m]) for m in ("nci", "f1")}, rec["k_s"].tolist(), flush=True)
+
+
 def data_case():
     """Run the reference's OWN loaders (dataloader/attncut_dataloader.py, choopy_dataloader.py) on a small
     synthetic robust04-format pickle set written by our generator; store the tensors they produce."""
@@ -230,3 +289,5 @@ if __name__ == "__main__":
         data_case()
     if only in ("all", "models"):
         model_cases(set(sys.argv[2:]) or None)
+    if only in ("all", "bicut"):
+        bicut_cases()
