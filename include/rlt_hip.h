@@ -108,6 +108,15 @@ int rlt_weighted_sum(const float* const* x, const float* w, int n, float* out, v
 int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
 
+/* Task metrics of utils/metrics.py:40-76 (section 8f row N4), per list in float64:
+ *   dcg_out[b] = taskr_metric's DCG of list b re-ordered by descending pred (relevant +1/log2(i+2), else -1/log2(i+2));
+ *   auc_out[b] = taskc_metric's ROC AUC of pred against labels (ties 1/2), or -1 for a list with a single class (the
+ *                reference skips those);
+ *   sums (3 doubles, may be NULL) = sum of dcg_out, sum of the valid auc_out, number of valid lists.
+ * labels, pred (B,S), S <= 1024. */
+int rlt_task_metrics(const float* labels, const float* pred, int B, int S,
+                     double* dcg_out, double* auc_out, double* sums, void* stream);
+
 /* ------------------------------------------------------------------ dense contraction (M2-M7)
  * C[M,N] (+)= op(A) * op(B) (+ bias[N] + bias2[N]), optional ReLU.  fp32 in, fp32 accumulate on
  * the f32 MFMA (exact fp32 products, v_mfma_f32_32x32x2_f32).

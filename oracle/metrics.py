@@ -70,3 +70,30 @@ def bicut_cut_positions(output):
     pred = np.argmax(output, axis=2)
     S = pred.shape[1]
     return np.array([S if r.sum() == S else int(np.argmin(r)) + 1 for r in pred], dtype=np.int64)
+
+
+def taskr_metric(labels, predictions):
+    """utils/metrics.py:40-57: per list, documents re-ordered by descending prediction; relevant documents earn
+    +1/log2(i+2) at sorted position i, the others -1/log2(i+2); mean over the batch."""
+    labels, predictions = np.asarray(labels), np.asarray(predictions)
+    out = []
+    for pred, lab in zip(predictions, labels):
+        order = np.argsort(-pred, kind="stable")
+        gain = np.where(lab[order] != 0, 1.0, -1.0) / np.log2(np.arange(len(order)) + 2.0)
+        out.append(gain.sum())
+    return float(np.mean(out))
+
+
+def taskc_metric(labels, predictions):
+    """utils/metrics.py:59-76: mean over the lists holding both classes of the ROC AUC (pairs of a positive and a
+    negative document ranked correctly, ties counting 1/2 - what sklearn's roc_auc_score computes)."""
+    labels, predictions = np.asarray(labels), np.asarray(predictions, dtype=np.float64)
+    total, count = 0.0, 0
+    for pred, lab in zip(predictions, labels):
+        pos, neg = pred[lab != 0], pred[lab == 0]
+        if len(pos) == 0 or len(neg) == 0:
+            continue
+        diff = pos[:, None] - neg[None, :]
+        total += ((diff > 0).sum() + 0.5 * (diff == 0).sum()) / (len(pos) * len(neg))
+        count += 1
+    return total / count

@@ -366,6 +366,63 @@ __global__ __launch_bounds__(256) void sum2_f64_kernel(const double* a, const do
     if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
 }
 
+// ---- task metrics (utils/metrics.py:40-76) -----------------------------------------
+// taskr_metric: DCG of the whole list re-ordered by descending prediction (+1/log2(i+2) for a relevant document at
+// sorted position i, -1/log2(i+2) otherwise).  taskc_metric: ROC AUC of the predictions against the labels per list
+// (sklearn's roc_auc_score: ties count 1/2), lists with only one class skipped.  One wavefront per list, predictions
+// and labels in LDS; rank of element j = #(pred > pred_j) + #(pred == pred_j at an earlier index) by an O(S^2) sweep
+// (S <= 1024), float64 accumulation.
+constexpr int TM_MAXS = 1024;
+__global__ __launch_bounds__(256) void task_metrics_kernel(const float* __restrict__ labels, const float* __restrict__ pred,
+                                                           int B, int S, double* __restrict__ dcg_out,
+                                                           double* __restrict__ auc_out) {
+    __shared__ float sp[4][TM_MAXS];
+    __shared__ float sy[4][TM_MAXS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    for (int j = lane; j < S; j += 64) { sp[wv][j] = pred[(size_t)b * S + j]; sy[wv][j] = labels[(size_t)b * S + j]; }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    double dcg = 0.0, pairs = 0.0, npos = 0.0;
+    for (int j = lane; j < S; j += 64) {
+        const float pj = sp[wv][j];
+        const bool rel = sy[wv][j] != 0.f;
+        int rank = 0;
+        double wins = 0.0;
+        for (int i = 0; i < S; ++i) {
+            const float pi = sp[wv][i];
+            rank += (pi > pj) || (pi == pj && i < j);
+            if (rel && sy[wv][i] == 0.f) wins += pj > pi ? 1.0 : (pj == pi ? 0.5 : 0.0);
+        }
+        dcg += (rel ? 1.0 : -1.0) / log2((double)rank + 2.0);
+        if (rel) { pairs += wins; npos += 1.0; }
+    }
+    dcg = wave_sum(dcg);
+    pairs = wave_sum(pairs);
+    npos = wave_sum(npos);
+    if (lane == 0) {
+        if (dcg_out) dcg_out[b] = dcg;
+        if (auc_out) {
+            const double nneg = (double)S - npos;
+            auc_out[b] = (npos == 0.0 || nneg == 0.0) ? -1.0 : pairs / (npos * nneg);      // -1: skipped list
+        }
+    }
+}
+__global__ __launch_bounds__(256) void task_metrics_sum_kernel(const double* __restrict__ dcg, const double* __restrict__ auc,
+                                                               int B, double* __restrict__ sums) {
+    __shared__ double sm[3][4];
+    double a = 0.0, c = 0.0, n = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        a += dcg[i];
+        if (auc[i] >= 0.0) { c += auc[i]; n += 1.0; }
+    }
+    a = wave_sum(a); c = wave_sum(c); n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = c; sm[2][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x < 3) sums[threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -448,6 +505,16 @@ int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, in
     hipLaunchKernelGGL(cut_metrics_kernel, dim3(rlt_cdiv(B, 4)), dim3(256), 0, st, p, labels, k_in, B, S,
                        k_out, f1_out, dcg_out);
     if (sums) hipLaunchKernelGGL(sum2_f64_kernel, dim3(1), dim3(256), 0, st, f1_out, dcg_out, B, sums);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_task_metrics(const float* labels, const float* pred, int B, int S,
+                     double* dcg_out, double* auc_out, double* sums, void* stream) {
+    RLT_CHECK_ARG(labels && pred && dcg_out && auc_out && B > 0 && S > 0);
+    RLT_CHECK_SHAPE(S <= TM_MAXS);
+    hipStream_t st = rlt_stream(stream);
+    hipLaunchKernelGGL(task_metrics_kernel, dim3(rlt_cdiv(B, 4)), dim3(256), 0, st, labels, pred, B, S, dcg_out, auc_out);
+    if (sums) hipLaunchKernelGGL(task_metrics_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)dcg_out, (const double*)auc_out, B, sums);
     return RLT_LAUNCH_RESULT();
 }
 

@@ -47,6 +47,30 @@ class Metric:
         return float(cls._run(labels, k_s)[1])
 
     @classmethod
+    def _task(cls, labels, predictions):
+        y = _labels(labels)
+        p = torch.as_tensor(np.asarray(predictions), dtype=torch.float32).to(y.device).contiguous() \
+            if not torch.is_tensor(predictions) else N.f32c(predictions.detach().to(y.device))
+        B, S = y.shape
+        dcg = torch.empty((B,), dtype=torch.float64, device=y.device)
+        auc = torch.empty((B,), dtype=torch.float64, device=y.device)
+        sums = torch.empty((3,), dtype=torch.float64, device=y.device)
+        N.call("rlt_task_metrics", N.ptr(y), N.ptr(p.reshape(B, S)), B, S, N.ptr(dcg), N.ptr(auc), N.ptr(sums), N.stream())
+        return sums.cpu().numpy(), B
+
+    @classmethod
+    def taskr_metric(cls, labels, predictions):
+        """utils/metrics.py:40-57: mean over the batch of the DCG of each list re-ranked by the predictions."""
+        sums, B = cls._task(labels, predictions)
+        return float(sums[0] / B)
+
+    @classmethod
+    def taskc_metric(cls, labels, predictions):
+        """utils/metrics.py:59-76: mean ROC AUC over the lists that hold both classes."""
+        sums, _ = cls._task(labels, predictions)
+        return float(sums[1] / sums[2])        # the reference divides by zero too when no list qualifies
+
+    @classmethod
     def evaluate(cls, output, labels):
         """output: cut distribution (B,S,1) or (B,S) on the GPU.  Returns (k (B,) int32 tensor,
         mean F1, mean DCG as 0-d float64 tensors) without leaving the device (run.py:137-145)."""

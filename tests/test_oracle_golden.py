@@ -188,3 +188,10 @@ def test_bicutloss_edge_rows():
         np.testing.assert_allclose(o.grad.numpy(), gold["dout/" + metric], rtol=1e-6, atol=1e-7)
     k_s = ometrics.bicut_cut_positions(torch.softmax(torch.from_numpy(gold["logits"]), dim=2).numpy())
     np.testing.assert_array_equal(k_s, gold["k_s"])
+
+
+def test_task_metrics():
+    gold = gu.load("task_metrics_s300")
+    assert abs(ometrics.taskr_metric(gold["y"], gold["pred"]) - float(gold["taskr"])) < 1e-9
+    assert abs(ometrics.taskc_metric(gold["y"], gold["pred"]) - float(gold["taskc"])) < 1e-12
+    assert abs(ometrics.taskc_metric(gold["y"], gold["pred_ties"]) - float(gold["taskc_ties"])) < 1e-12

@@ -181,6 +181,10 @@ def metrics():
     kx = np.array([[1, 0, 1], [0, 0, 1], [1, 0, 0]], dtype=np.float32)
     report("Metric.f1 KAT", abs(Metric.f1(kx, np.array([1, 2, 1])) - 0.5555555555555555), 1e-12)
     report("Metric.dcg KAT", abs(Metric.dcg(kx, np.array([1, 2, 1])) - 0.1230234154761809), 1e-12)
+    tg = gu.load("task_metrics_s300")
+    report("Metric.taskr_metric golden", abs(Metric.taskr_metric(tg["y"], tg["pred"]) - float(tg["taskr"])), 1e-9)
+    report("Metric.taskc_metric golden", abs(Metric.taskc_metric(tg["y"], tg["pred"]) - float(tg["taskc"])), 1e-12)
+    report("Metric.taskc_metric ties", abs(Metric.taskc_metric(tg["y"], tg["pred_ties"]) - float(tg["taskc_ties"])), 1e-12)
     p = torch.rand(33, 300)
     k, f1, dcg, _ = ops.cut_metrics(p.to(dev), torch.from_numpy(gold["y"][:1]).repeat(33, 1).to(dev))
     report("argmax", float((k.cpu().long() - (p.argmax(1) + 1)).abs().max()), 0)

@@ -253,6 +253,25 @@ def bicut_cases():
     print("bicutloss_edge_s50:", {m: float(rec["loss/" + m]) for m in ("nci", "f1")}, rec["k_s"].tolist(), flush=True)
 
 
+
+def task_metric_case():
+    """Metric.taskr_metric / Metric.taskc_metric (utils/metrics.py:40-76) run by the reference (sklearn's AUC)."""
+    rs = np.random.RandomState(181)
+    B, S = 9, 300
+    pred = rs.standard_normal((B, S)).astype(np.float32)
+    y = (rs.uniform(0, 1, (B, S)) < 0.15).astype(np.float32)
+    y[2] = 0.0                                   # single-class lists: skipped by taskc_metric
+    y[5] = 1.0
+    pred_ties = pred.copy()
+    pred_ties[7] = np.round(pred_ties[7], 1)     # ties inside a list: AUC counts them 1/2 (the DCG of tied documents
+    rec = {"pred": pred, "pred_ties": pred_ties, "y": y,        # depends on numpy's unstable argsort: not pinned)
+           "taskr": np.float64(RefMetric.taskr_metric(y, pred)),
+           "taskc": np.float64(RefMetric.taskc_metric(y, pred)),
+           "taskc_ties": np.float64(RefMetric.taskc_metric(y, pred_ties))}
+    np.savez_compressed(os.path.join(OUT, "task_metrics_s300.npz"), **rec)
+    print("task_metrics_s300:", float(rec["taskr"]), float(rec["taskc"]), flush=True)
+
+
 def data_case():
     """Run the reference's OWN loaders (dataloader/attncut_dataloader.py, choopy_dataloader.py) on a small
     synthetic robust04-format pickle set written by our generator; store the tensors they produce."""
@@ -291,3 +310,5 @@ if __name__ == "__main__":
         model_cases(set(sys.argv[2:]) or None)
     if only in ("all", "bicut"):
         bicut_cases()
+    if only in ("all", "taskmetrics"):
+        task_metric_case()
