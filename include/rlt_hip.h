@@ -322,6 +322,19 @@ int rlt_pair_softmax_bwd(const float* out, const float* dout, int B, int S, floa
 int rlt_bicut_loss(const float* out, const float* labels, int B, int S, int metric_nci, float alpha, float r,
                    float* per_list, float* loss, float* dout, void* stream);
 
+/* ------------------------------------------------------------------ WassDistLoss (section 8f row N4)
+ * utils/losses.py:236-311: entropic optimal transport between the B predicted distributions p (B,S) and the B label
+ * vectors (B,S) of a batch: squared-distance cost, uniform marginals, at most max_iter log-domain Sinkhorn iterations
+ * with regularisation eps, stopped after the iteration whose sum |u - u_prev| < thresh (reference: 0.1; decided on the
+ * device, no host synchronisation), loss = sum(pi * C).  fwd records the iterations in ws; bwd replays them in reverse
+ * and writes dp = gscale[0] * d(loss)/dp (gscale NULL = 1).  ws: rlt_wass_loss_workspace(B, max_iter) bytes, the
+ * same buffer for fwd and bwd. */
+size_t rlt_wass_loss_workspace(int B, int max_iter);
+int rlt_wass_loss_fwd(const float* p, const float* labels, int B, int S, float eps, int max_iter, float thresh,
+                      float* loss, void* ws, size_t ws_bytes, void* stream);
+int rlt_wass_loss_bwd(const float* p, const float* labels, const float* gscale, int B, int S, float eps, int max_iter,
+                      void* ws, size_t ws_bytes, float* dp, void* stream);
+
 /* ------------------------------------------------------------------ optimizer (N2, run.py:104,129)
  * torch.optim.Adam with coupled L2 (grad += wd * p), bias correction, eps outside the sqrt,
  * on a flat fp32 bucket.  step: 1-based step count. */

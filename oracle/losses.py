@@ -210,3 +210,36 @@ class BiCutLoss(nn.Module):
         S = output.shape[1]
         mask = (torch.arange(S).unsqueeze(0) <= idx.unsqueeze(1)).to(output.dtype).unsqueeze(2)
         return (output * mask * self.reward(labels)).sum() / output.shape[0]
+
+
+class WassDistLoss(nn.Module):
+    """utils/losses.py:236-311: entropic optimal transport between the B predicted cut
+    distributions and the B label vectors of a batch.  Cost C_ij = sum_s (p_is - y_js)^2, uniform marginals 1/B,
+    log-domain Sinkhorn with regularisation eps: per iteration
+        u <- u + eps * (log(1/B + 1e-8) - logsumexp_j((-C_ij + u_i + v_j) / eps))
+        v <- v + eps * (log(1/B + 1e-8) - logsumexp_i((-C_ij + u_i + v_j) / eps))       (with the new u)
+    at most max_iter times, stopping after the iteration in which sum_i |u_i - u_i(previous)| < 0.1;
+    loss = sum_ij exp((-C_ij + u_i + v_j) / eps) * C_ij, differentiated through the iterations."""
+
+    def __init__(self, eps: float = 1e-3, max_iter: int = 100, metric: str = 'f1', tau: float = 0.95, reduction='mean'):
+        super().__init__()
+        self.eps, self.max_iter, self.reduction = eps, max_iter, reduction
+
+    def forward(self, output: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        p = output.squeeze()
+        C = ((p.unsqueeze(-2) - labels.unsqueeze(-3)).abs() ** 2).sum(-1)             # (B,B)
+        B = p.shape[-2]
+        log_m = torch.log(torch.full((B,), 1.0 / B) + 1e-8)
+        u, v = torch.zeros(B), torch.zeros(B)
+
+        def modified(u_, v_):
+            return (-C + u_.unsqueeze(-1) + v_.unsqueeze(-2)) / self.eps
+
+        for _ in range(self.max_iter):
+            u_prev = u
+            u = (log_m - torch.logsumexp(modified(u, v), dim=-1)).mul(self.eps).add(u)
+            v = (log_m - torch.logsumexp(modified(u, v).transpose(-2, -1), dim=-1)).mul(self.eps).add(v)
+            if (u - u_prev).abs().sum(-1).mean().item() < 1e-1:
+                break
+        cost = (torch.exp(modified(u, v)) * C).sum(dim=(-2, -1))
+        return cost.mean() if self.reduction == 'mean' else cost.sum()

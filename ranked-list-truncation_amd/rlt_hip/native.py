@@ -33,6 +33,9 @@ _SIGNATURES = {
     "rlt_mt_terms_bwd": (c_int, [P, P, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "rlt_weighted_sum": (c_int, [P, P, c_int, P, P]),
     "rlt_cut_metrics": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P]),
+    "rlt_wass_loss_workspace": (c_size_t, [c_int, c_int]),
+    "rlt_wass_loss_fwd": (c_int, [P, P, c_int, c_int, c_float, c_int, c_float, P, P, c_size_t, P]),
+    "rlt_wass_loss_bwd": (c_int, [P, P, P, c_int, c_int, c_float, c_int, P, c_size_t, P, P]),
     "rlt_task_metrics": (c_int, [P, P, c_int, c_int, P, P, P, P]),
     "rlt_pair_softmax_fwd": (c_int, [P, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_pair_softmax_bwd": (c_int, [P, P, c_int, c_int, c_float, c_uint32, P, P]),

@@ -625,6 +625,32 @@ class RewardLossFn(Function):
         return g.view(ctx.pshape), None, None, None, None
 
 
+class WassDistLossFn(Function):
+    """utils/losses.py:236-311: Sinkhorn forward recorded in a workspace, explicit reverse sweep for the gradient."""
+
+    @staticmethod
+    def forward(ctx, p, labels, eps, max_iter, thresh):
+        B, S = labels.shape
+        loss = _empty((1,), p)
+        ws_bytes = query("rlt_wass_loss_workspace", B, max_iter)
+        ws = workspace(ws_bytes, p.device)
+        call("rlt_wass_loss_fwd", ptr(p), ptr(labels), B, S, eps, max_iter, thresh, ptr(loss), ptr(ws), ws_bytes, stream())
+        ctx.cfg = (B, S, eps, max_iter, ws_bytes)
+        ctx.ws = ws
+        ctx.save_for_backward(p, labels)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        p, labels = ctx.saved_tensors
+        B, S, eps, max_iter, ws_bytes = ctx.cfg
+        dp = _empty((B, S), p)
+        go = N.f32c(go).reshape(1)
+        call("rlt_wass_loss_bwd", ptr(p), ptr(labels), ptr(go), B, S, eps, max_iter, ptr(ctx.ws), ws_bytes, ptr(dp), stream())
+        ctx.ws = None
+        return dp, None, None, None, None
+
+
 class PairSoftmaxFn(Function):
     """BiCut's two-class head: position-major logits (S*B, 2) -> dropout -> softmax over the classes -> (B,S,2)."""
 

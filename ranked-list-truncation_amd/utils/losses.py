@@ -1,6 +1,6 @@
 """Reward losses on the HIP hot path - drop-in for the criteria of the reference's utils/losses.py
 that are on the hot path: ChoopyLoss :48-68, AttnCutLoss :71-96, RerankLoss :99-141,
-MtCutLoss :164-191, DivLoss :194-233, and BiCutLoss :11-45 (section 8f row N4).  Same constructor signatures; `criterion(output, labels)`
+MtCutLoss :164-191, DivLoss :194-233, BiCutLoss :11-45 and WassDistLoss :236-311 (section 8f row N4).  Same constructor signatures; `criterion(output, labels)`
 returns a 0-d tensor supporting .backward() and .item().
 
 The reference builds its (B,S) reward matrix with B*S python calls of O(S) tensor ops; here the
@@ -113,3 +113,17 @@ class BiCutLoss(nn.Module):
         if output.dim() != 3 or output.shape[2] != 2:
             raise ValueError(f"expected the (B,S,2) output of BiCut, got {tuple(output.shape)}")
         return ops.BiCutLossFn.apply(N.f32c(output), N.f32c(labels), self.metric == 'nci', float(self.alpha), float(self.r))
+
+
+class WassDistLoss(nn.Module):
+    """utils/losses.py:236-311 (Sinkhorn distance between the batch's cut distributions and its label vectors); `metric`
+    and `tau` are accepted and unused, as in the reference."""
+
+    def __init__(self, eps: float = 1e-3, max_iter: int = 100, metric: str = 'f1', tau: float = 0.95, reduction='mean'):
+        super().__init__()
+        self.eps, self.max_iter, self.reduction = eps, max_iter, reduction     # one (B,B) problem: mean == sum
+
+    def forward(self, output, labels):
+        p, y = _prep(output, labels)
+        B, S = y.shape
+        return ops.WassDistLossFn.apply(p.reshape(B, S), y, float(self.eps), int(self.max_iter), 1e-1)

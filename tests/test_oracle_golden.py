@@ -195,3 +195,15 @@ def test_task_metrics():
     assert abs(ometrics.taskr_metric(gold["y"], gold["pred"]) - float(gold["taskr"])) < 1e-9
     assert abs(ometrics.taskc_metric(gold["y"], gold["pred"]) - float(gold["taskc"])) < 1e-12
     assert abs(ometrics.taskc_metric(gold["y"], gold["pred_ties"]) - float(gold["taskc_ties"])) < 1e-12
+
+
+def test_wassdist_loss_and_gradient():
+    gold = gu.load("wassdist")
+    for tag in sorted({k.split("/")[0] for k in gold}):
+        p = torch.softmax(torch.from_numpy(gold[f"{tag}/logits"]), dim=1).unsqueeze(2).requires_grad_(True)
+        loss = olosses.WassDistLoss(eps=float(gold[f"{tag}/eps"]), max_iter=100)(p, torch.from_numpy(gold[f"{tag}/y"]))
+        loss.backward()
+        ref = float(gold[f"{tag}/loss"])
+        assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (tag, loss.item(), ref)
+        dp = gold[f"{tag}/dp"]
+        np.testing.assert_allclose(p.grad.squeeze(2).numpy(), dp, rtol=0, atol=1e-4 * np.abs(dp).max())

@@ -133,6 +133,17 @@ def losses():
         report(f"loss {cname}", abs(loss.item() - ref) / max(1, abs(ref)), 1e-5)
         scale = np.abs(gold["dp/" + cname]).max()
         report(f"dloss/dp {cname}", float(np.abs(p.grad.squeeze(2).cpu().numpy() - gold["dp/" + cname]).max() / scale), 1e-4)
+    wg = gu.load("wassdist")
+    for tag in sorted({k.split("/")[0] for k in wg}):
+        p = torch.softmax(torch.from_numpy(wg[f"{tag}/logits"]), dim=1).unsqueeze(2).to(dev).requires_grad_(True)
+        loss = hl.WassDistLoss(eps=float(wg[f"{tag}/eps"]), max_iter=100)(p, torch.from_numpy(wg[f"{tag}/y"]).to(dev))
+        loss.backward()
+        ref = float(wg[f"{tag}/loss"])
+        report(f"wassdist loss {tag}", abs(loss.item() - ref) / max(1.0, abs(ref)), 1e-4)
+        dpr = wg[f"{tag}/dp"]
+        # (-C + u + v) / eps has magnitude ~1e4 at eps = 1e-3: one fp32 ulp there is ~1e-3 in the exponent, so two fp32
+        # evaluation orders of the same Sinkhorn iterations (torch's and ours) differ by ~1e-3 in the plan and its gradient
+        report(f"wassdist dp {tag}", float(np.abs(p.grad.squeeze(2).cpu().numpy() - dpr).max() / np.abs(dpr).max()), 5e-3)
     for metric in ("f1", "dcg"):
         r = ops.reward_matrix(y.to(dev), N.METRIC_F1 if metric == "f1" else N.METRIC_DCG)
         report(f"reward matrix {metric}", float(np.abs(r.cpu().numpy() - gold["reward/" + metric]).max()), 2e-5)

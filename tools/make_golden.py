@@ -272,6 +272,26 @@ def task_metric_case():
     print("task_metrics_s300:", float(rec["taskr"]), float(rec["taskc"]), flush=True)
 
 
+
+def wass_cases():
+    """WassDistLoss (utils/losses.py:236-311) run by the reference: loss and d(loss)/d(output) for a few (B, S, eps)."""
+    rec = {}
+    for tag, B, S, eps, seed in [("b6_s40_e3", 6, 40, 1e-3, 191), ("b6_s40_e2", 6, 40, 1e-2, 192), ("b17_s300_e2", 17, 300, 1e-2, 193),
+                                 ("b33_s100_e3", 33, 100, 1e-3, 194)]:
+        rs = np.random.RandomState(seed)
+        lg = rs.standard_normal((B, S)).astype(np.float32)
+        y = (rs.uniform(0, 1, (B, S)) < 0.2).astype(np.float32)
+        p = torch.softmax(torch.from_numpy(lg), dim=1).unsqueeze(2).requires_grad_(True)
+        loss = ref_losses.WassDistLoss(eps=eps, max_iter=100)(p, torch.from_numpy(y))
+        loss.backward()
+        rec[f"{tag}/logits"], rec[f"{tag}/y"] = lg, y
+        rec[f"{tag}/eps"] = np.float64(eps)
+        rec[f"{tag}/loss"] = np.float64(loss.item())
+        rec[f"{tag}/dp"] = p.grad.squeeze(2).numpy()
+        print("wass", tag, float(loss.item()), float(np.abs(rec[f"{tag}/dp"]).max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "wassdist.npz"), **rec)
+
+
 def data_case():
     """Run the reference's OWN loaders (dataloader/attncut_dataloader.py, choopy_dataloader.py) on a small
     synthetic robust04-format pickle set written by our generator; store the tensors they produce."""
@@ -312,3 +332,5 @@ if __name__ == "__main__":
         bicut_cases()
     if only in ("all", "taskmetrics"):
         task_metric_case()
+    if only in ("all", "wass"):
+        wass_cases()
