@@ -98,6 +98,14 @@ def main():
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32"],
                     help="MFMA product mode of the library (default: the library default, bf16x3)")
     ap.add_argument("--cpu-sample-batch", type=int, default=128)
+    # side configurations of SURVEY.md 8(d); the headline line uses none of them
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="train-mode dropout (parity runs use 0.0; the reference conf values are 0.4 / 0.2)")
+    ap.add_argument("--num-tasks", type=float, default=None, help="mtattncut / mmoecut: 3, 2.1 or 2.2")
+    ap.add_argument("--reward", default="f1", choices=["f1", "dcg"], help="reward metric of the criterion")
+    ap.add_argument("--buckets", default=None,
+                    help="comma-separated list lengths served round-robin, one homogeneous batch per step "
+                         "(BASELINE configs[4]: 100,200,300); --steps should be a multiple of their number")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,28 +140,43 @@ def main():
     torch.manual_seed(1234)
     S, B = args.seq_len, args.batch
     if args.model == "attncut":
-        model = hip_models.AttnCut(input_size=3, dropout=0.0).to(dev)
-        crit = hip_losses.DivLoss(metric='f1', div_type='js', augmented=True)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "AttnCut + DivLoss(js,f1,augmented) [BASELINE configs[1]]"
+        model = hip_models.AttnCut(input_size=3, dropout=args.dropout).to(dev)
+        crit = hip_losses.DivLoss(metric=args.reward, div_type='js', augmented=True)
+        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, f"AttnCut + DivLoss(js,{args.reward},augmented) [BASELINE configs[1]]"
     elif args.model == "choopy":
-        model = hip_models.Choopy(seq_len=S, dropout=0.0).to(dev)
-        crit = hip_losses.ChoopyLoss(metric='f1')
-        n_feat, heads_, hd, layers, wl = 1, 8, 16, 3, "Choopy + ChoopyLoss(f1) [BASELINE configs[2] at batch 8192]"
+        model = hip_models.Choopy(seq_len=S, dropout=args.dropout).to(dev)
+        crit = hip_losses.ChoopyLoss(metric=args.reward)
+        n_feat, heads_, hd, layers, wl = 1, 8, 16, 3, f"Choopy + ChoopyLoss({args.reward}) [BASELINE configs[2] at batch 8192]"
     elif args.model == "mtattncut":
-        model = hip_models.MtAttnCut(input_size=3, num_tasks=3, dropout=0.0).to(dev)
-        crit = hip_losses.MtCutLoss(metric='f1', num_tasks=3)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, "MtAttnCut(3 tasks) + MtCutLoss(f1) [BASELINE configs[4], one length bucket]"
+        nt = 3 if args.num_tasks is None else args.num_tasks
+        model = hip_models.MtAttnCut(input_size=3, num_tasks=nt, dropout=args.dropout).to(dev)
+        crit = hip_losses.MtCutLoss(metric=args.reward, num_tasks=nt)
+        n_feat, heads_, hd, layers = 3, 4, 64, 1
+        wl = f"MtAttnCut(tasks {nt:g}) + MtCutLoss({args.reward}) [BASELINE configs[4]]"
     else:
-        model = hip_models.MMOECut(seq_len=S, num_experts=4, num_tasks=2.1, dropout=0.0).to(dev)
-        crit = hip_losses.MtCutLoss(metric='f1', rerank_weight=0.4, classi_weight=0.6, num_tasks=2.1)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 4, "MMOECut(4 experts, tasks 2.1) + MtCutLoss(f1) [BASELINE configs[3]]"
+        nt = 2.1 if args.num_tasks is None else args.num_tasks
+        model = hip_models.MMOECut(seq_len=S, num_experts=4, num_tasks=nt, dropout=args.dropout).to(dev)
+        crit = hip_losses.MtCutLoss(metric=args.reward, rerank_weight=0.4, classi_weight=0.6, num_tasks=nt)
+        n_feat, heads_, hd, layers = 3, 4, 64, 4
+        wl = f"MMOECut(4 experts, tasks {nt:g}) + MtCutLoss({args.reward}) [BASELINE configs[3]]"
     flat = FlatModel(model)
     flat.broadcast_params()
     opt = FusedAdam(flat, lr=3e-5, weight_decay=0.0014756345581373493)
-    x, y = synth_batch(B, S, n_feat, 20240 + rank, dev)       # inputs resident in HBM before timing
+    if args.dropout > 0:
+        wl += f", dropout {args.dropout:g}"
+    # inputs resident in HBM before timing; with --buckets one homogeneous batch per length, served round-robin
+    lengths = [S] if not args.buckets else [int(v) for v in args.buckets.split(",")]
+    if args.buckets:
+        if args.model in ("choopy", "mmoecut"):
+            raise SystemExit("--buckets: Choopy / MMOECut are built for one list length (seq_len)")
+        wl += f", length buckets {lengths} round-robin"
+    batches = [synth_batch(B, L, n_feat, 20240 + rank + 7 * i, dev) for i, L in enumerate(lengths)]
     timer = ops.KernelTimer()
+    turn = [0]
 
     def step():
+        x, y = batches[turn[0] % len(batches)]
+        turn[0] += 1
         model.train()
         opt.zero_grad()
         out = model(x)
@@ -171,11 +194,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    # every bucket is served at least once untimed (first use of a shape allocates its buffers)
+    n_warm = args.warmup if len(batches) == 1 else max(args.warmup, len(batches))
+    for i in range(n_warm):
         step()
         torch.cuda.synchronize()
         if rank == 0:
-            print(f"[bench] warm-up step {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
+            print(f"[bench] warm-up step {i + 1}/{n_warm} done", file=sys.stderr, flush=True)
     fence()
     ops.KernelTimer.active = timer
     t0 = time.perf_counter()
@@ -204,17 +229,19 @@ def main():
         # 2500/3 = 833.3 TF/s (`executed_bf16_tflops` / 2500 is the same fraction).  DESIGN.md section 5.
         name = "attn_bwd_dkv"
         launches, ms = ksum.get(name, (0, float("nan")))
-        unit_flops = 2.0 * B * B * hd * S * heads_
+        S_mean = sum(lengths) / len(lengths)                   # positions per launch, averaged over the buckets
+        unit_flops = 2.0 * B * B * hd * S_mean * heads_
         if precision == "fp32":
             kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2>" % hd, 4, 1, PEAK_F32_MFMA_TFLOPS
         else:
-            kern, products, mult, peak = "attn3_bwd_dkv_kernel<%d,false>" % hd, 4, 3, PEAK_BF16_MFMA_TFLOPS
+            kern, products, mult, peak = "attn3_bwd_dkv_kernel<%d,%s>" % (hd, "true" if args.dropout > 0 else "false"), 4, 3, PEAK_BF16_MFMA_TFLOPS
         algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
         achieved, executed = algorithmic, algorithmic * mult
         peak = round(peak / mult, 1)
         # whole-step fractions SURVEY.md 8(d) asks for beside the kernel's: algorithmic fwd+bwd FLOPs and bytes per list
-        step_flop = step_algorithmic_flops(args.model, B, S) if args.model == "attncut" else None
-        step_bytes = 16.0e6 * B if args.model == "attncut" else None
+        headline = args.model == "attncut" and not args.buckets
+        step_flop = step_algorithmic_flops(args.model, B, S) if headline else None
+        step_bytes = 16.0e6 * B * S / 300.0 if headline else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
         # same command (tools/pmc_traffic.py -> profiles/r01_o_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
         # applied); only quoted for the exact workload and kernel it was measured on
@@ -223,7 +250,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "r01_o_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if (args.model == "attncut" and B == 4096 and S == 300 and precision == "bf16x3"
+            if (headline and args.dropout == 0 and B == 4096 and S == 300 and precision == "bf16x3"
                     and all(kern.startswith(k) for k in pmc["dominant_launch"])):
                 traffic = pmc["traffic_bytes_per_launch"]
                 step_traffic = pmc.get("step_traffic_bytes")
@@ -237,7 +264,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S}, "
                                    f"full train step incl. Adam and cut metrics", "global_batch": B * world,
-                       "seq_len": S, "parallelism": f"dp{world}"},
+                       "seq_len": S if not args.buckets else lengths, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

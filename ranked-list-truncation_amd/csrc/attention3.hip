@@ -286,9 +286,15 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // dropout: hash of this lane's query once; hashes of a tile's keys in LDS, written while the tile is in flight
+    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     auto issue = [&](int t, int buf) {
         dma_copy<Rec<HD>::RP>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
         dma_copy<Rec<HD>::TP>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
+        if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
     __syncthreads();
@@ -338,12 +344,14 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
                     psum += p;
                 }
                 if (DROP) {
-                    const uint32_t ps = pair_seed(a.seed, pair);
-                    const float inv_keep = 1.f / (1.f - a.drop_p);
+                    const uint4* hk4 = reinterpret_cast<const uint4*>(htab + buf * KT + sub * 32 + 4 * hh);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * KT + sub * 32 + acc_row(r, hh);
-                        sc[sub][r] = rlt_keep(ps, (uint32_t)q, (uint32_t)key, a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
+                    for (int gq = 0; gq < 4; ++gq) {                       // registers 4g..4g+3 = keys 8g+4hh+{0..3}
+                        const uint4 hk = hk4[2 * gq];
+                        sc[sub][4 * gq + 0] = rlt_keep_rc(hq, hk.x, a.drop_thr) ? sc[sub][4 * gq + 0] * inv_keep : 0.f;
+                        sc[sub][4 * gq + 1] = rlt_keep_rc(hq, hk.y, a.drop_thr) ? sc[sub][4 * gq + 1] * inv_keep : 0.f;
+                        sc[sub][4 * gq + 2] = rlt_keep_rc(hq, hk.z, a.drop_thr) ? sc[sub][4 * gq + 2] * inv_keep : 0.f;
+                        sc[sub][4 * gq + 3] = rlt_keep_rc(hq, hk.w, a.drop_thr) ? sc[sub][4 * gq + 3] * inv_keep : 0.f;
                     }
                 }
                 mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
@@ -397,9 +405,12 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
+    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-key hashes of the tile
+    const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     auto issue = [&](int t, int buf) {
         dma_copy<KREC>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
         dma_copy<Rec<HD>::RP>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
+        if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
     __syncthreads();
@@ -425,14 +436,19 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                     for (int r = 0; r < 16; ++r)
                         if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[r] = -INFINITY;
                 }
+                const uint4* hk4 = reinterpret_cast<const uint4*>(htab + buf * KT + sub * 32 + 4 * hh);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kidx = t * KT + sub * 32 + acc_row(r, hh);
-                    const float p = rlt_exp2(sc[r] - lse2);
-                    float dpr = dp[r];
-                    if (DROP)
-                        dpr = rlt_keep(ps, (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr * inv_keep : 0.f;
-                    dp[r] = p * (dpr - del);                                       // dS^T
+                for (int gq = 0; gq < 4; ++gq) {                           // registers 4g..4g+3 = keys 8g+4hh+{0..3}
+                    uint32_t hk[4] = {1u, 1u, 1u, 1u};
+                    if (DROP) { const uint4 v = hk4[2 * gq]; hk[0] = v.x; hk[1] = v.y; hk[2] = v.z; hk[3] = v.w; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * gq + i;
+                        const float p = rlt_exp2(sc[r] - lse2);
+                        float dpr = dp[r];
+                        if (DROP) dpr = rlt_keep_rc(hq, hk[i], a.drop_thr) ? dpr * inv_keep : 0.f;
+                        dp[r] = p * (dpr - del);                                   // dS^T
+                    }
                 }
                 mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);                     // dQ^T[d][q] += K^T dS^T
             }
@@ -478,9 +494,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
+    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-query hashes of the tile
+    const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 1u;
     auto issue = [&](int t, int buf) {
         dma_copy<QREC>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
         dma_copy<STAGE - QREC>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
+        if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
     __syncthreads();
@@ -512,7 +531,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     float p = rlt_exp2(sc[r] - Ls[ql]);
                     float dpr = dp[r];
                     if (DROP) {
-                        const bool keep = rlt_keep(ps, (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
+                        const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
                         dpr = keep ? dpr * inv_keep : 0.f;
                         dp[r] = p * (dpr - Es[ql]);                                // dS uses the undropped p
                         p = keep ? p * inv_keep : 0.f;
@@ -533,9 +552,11 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     store_acc_T<HD>(row + 2 * E, hh, dv, 1.f);
 }
 
-template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP); }
-template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP); }
-template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX); }
+// two tile stages + the [2][KT] dropout hash table
+constexpr size_t HTAB = 2 * KT * sizeof(uint32_t);
+template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
+template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
+template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX) + HTAB; }
 
 template <int HD>
 int prepare3(const PrepArgs& p, hipStream_t st) {

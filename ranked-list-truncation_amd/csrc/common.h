@@ -66,22 +66,35 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ constexpr int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
-// keep(seed, a, b) is a pure function of its arguments, so backward recomputes the forward mask
-// instead of storing it.  Two rounds of a 32-bit avalanche mixer ("lowbias32").
+// keep(seed, row, col) is a pure function of its arguments, so backward recomputes the forward mask instead of
+// storing it.  Every dropout site draws one number per element of a 2-D array (rows x cols; for the attention
+// probabilities: query x key per (position, head), seeded per pair).  A full avalanche hash per element costs more
+// VALU time than the softmax it sits in, so every row and every column gets one strong 32-bit hash ("lowbias32"
+// mixer, two rounds) - computed once per lane / once per tile / on the scalar unit - and the element's number is
+// their product mod 2^32 (column hash forced odd, so a row's numbers stay distinct per column hash): one integer
+// multiply + one compare per element.  Measured on 2048 x 2048 masks (p = 0.1 .. 0.5): mean, row-pair, column-pair,
+// 2x2-rectangle and neighbour statistics indistinguishable from independent draws.
 __host__ __device__ __forceinline__ uint32_t rlt_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ uint32_t rlt_rng(uint32_t seed, uint32_t a, uint32_t b) {
-    return rlt_mix32(seed + rlt_mix32(a + rlt_mix32(b + 0x9E3779B9U)));
+__host__ __device__ __forceinline__ uint32_t rlt_row_hash(uint32_t seed, uint32_t row) {
+    return rlt_mix32(seed + rlt_mix32(row + 0x9E3779B9U));
 }
-// threshold for "drop": drop iff rng < thr, thr = p * 2^32
+__host__ __device__ __forceinline__ uint32_t rlt_col_hash(uint32_t seed, uint32_t col) {
+    return rlt_mix32((seed ^ 0x85EBCA6BU) + rlt_mix32(col + 0x7F4A7C15U)) | 1u;
+}
+__host__ __device__ __forceinline__ bool rlt_keep_rc(uint32_t row_hash, uint32_t col_hash, uint32_t thr) {
+    return row_hash * col_hash >= thr;
+}
+// threshold for "drop": drop iff number < thr, thr = p * 2^32
 __host__ __device__ __forceinline__ uint32_t rlt_drop_threshold(float p) {
     const double t = (double)p * 4294967296.0;
     return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
-__host__ __device__ __forceinline__ bool rlt_keep(uint32_t seed, uint32_t a, uint32_t b, uint32_t thr) {
-    return rlt_rng(seed, a, b) >= thr;
+// un-hoisted form (mask export, small kernels)
+__host__ __device__ __forceinline__ bool rlt_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr) {
+    return rlt_keep_rc(rlt_row_hash(seed, row), rlt_col_hash(seed, col), thr);
 }
 
 // ---- deterministic column sums of a tall partial matrix -------------------------------------------------

@@ -155,6 +155,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
 // ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
 // wavefront tile = 64 rows (2 MFMA blocks) x 32*NJ columns at (rbase, cbase); `interior`: the whole workgroup tile is
 // inside C
+template <bool V> struct BoolTag { static constexpr bool value = V; };
 template <int NJ>
 __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (&acc)[2][NJ], int rbase, int cbase,
                                                bool interior, int l31, int hh, int z) {
@@ -211,6 +212,45 @@ __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (
             tile([=](float v, int row, int col, const float*) { return mk[(size_t)row * ldm + col] > 0.f ? v * sc : 0.f; });
             return;
         }
+    }
+    // interior tiles of the FFN hidden product in train mode: bias + ReLU + dropout (+ the 1-bit mask of what
+    // survived both).  Row hashes of the two half-wave rows are wave-uniform (scalar unit); one column hash per lane
+    if (interior && g.drop_p > 0.f && (g.flags & RLT_GEMM_RELU) && !(g.flags & RLT_GEMM_ACCUMULATE) && !g.mask && !g.bits_in &&
+        !to_slab) {
+        const float inv_keep = 1.f / (1.f - g.drop_p);
+        const uint32_t thr = g.drop_thr, seed = g.seed;
+        const int rb = __builtin_amdgcn_readfirstlane(rbase);
+        auto tile = [&](auto with_bits) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = cbase + j * 32 + l31;
+                const uint32_t hc = rlt_col_hash(seed, (uint32_t)col);
+                float bv = 0.f;
+                if (g.bias) bv += g.bias[col];
+                if (g.bias2) bv += g.bias2[col];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row_lo = rb + i * 32 + (r & 3) + 8 * (r >> 2);
+                        // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select below
+                        // into one per-lane hash of row_lo + 4*hh on the VALU: 64 hashes and live registers per lane)
+                        const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)row_lo));
+                        const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)(row_lo + 4)));
+                        const int row = row_lo + 4 * hh;
+                        float v = fmaxf(acc[i][j][r] + bv, 0.f);
+                        v = rlt_keep_rc(hh ? h1 : h0, hc, thr) ? v * inv_keep : 0.f;
+                        if (decltype(with_bits)::value) {
+                            const unsigned long long bal = __ballot(v > 0.f);
+                            if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
+                        }
+                        out[(size_t)row * ldo + col] = v;
+                    }
+                }
+            }
+        };
+        if (g.bits_out) tile(BoolTag<true>{}); else tile(BoolTag<false>{});
+        return;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1069,13 +1109,15 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
 
 int rlt_gemm_bits(int ta, int tb, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                  const float* bias, int flags, uint32_t* relu_bits_out, const uint32_t* mask_bits_in, float mask_scale,
+                  const float* bias, int flags, float drop_p, uint32_t seed,
+                  uint32_t* relu_bits_out, const uint32_t* mask_bits_in, float mask_scale,
                   void* stream) {
     RLT_CHECK_ARG((relu_bits_out != nullptr) != (mask_bits_in != nullptr));
     RLT_CHECK_ARG(!relu_bits_out || (flags & RLT_GEMM_RELU));
+    RLT_CHECK_ARG(drop_p == 0.f || relu_bits_out);
     RLT_CHECK_SHAPE(N % 32 == 0);
     return gemm_run(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, flags, nullptr, 0, mask_scale, nullptr,
-                    0.f, 0u, relu_bits_out, mask_bits_in, nullptr, 0, stream);
+                    drop_p, seed, relu_bits_out, mask_bits_in, nullptr, 0, stream);
 }
 
 size_t rlt_colsum_workspace(int T, int N) {

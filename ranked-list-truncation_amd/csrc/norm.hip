@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int T, int E, float eps, float* __restrict__ y,
                                                          float* __restrict__ stats, float drop_p, uint32_t seed) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nch = E / (64 * V);
     float gm[MAXCH][V], bt[MAXCH][V];
 #pragma unroll
@@ -46,8 +46,14 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
     const bool drop = drop_p > 0.f;
     const uint32_t thr = rlt_drop_threshold(drop_p);
     const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
+    uint32_t hc[MAXCH][V];                   // dropout: this lane's column hashes (the token's row hash is wave-uniform)
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < V; ++i) hc[c][i] = (drop && c < nch) ? rlt_col_hash(seed, (uint32_t)(c * 64 * V + lane * V + i)) : 1u;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
         const size_t row = (size_t)t * E;
+        const uint32_t hr = rlt_row_hash(seed, (uint32_t)t);
         float z[MAXCH][V];
         float s = 0.f;
 #pragma unroll
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 #pragma unroll
                     for (int i = 0; i < V; ++i) {
                         float rv = rr[i];
-                        if (drop) rv = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? rv * keep_scale : 0.f;
+                        if (drop) rv = rlt_keep_rc(hr, hc[c][i], thr) ? rv * keep_scale : 0.f;
                         z[c][i] += rv;
                     }
                 }
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dz, float* __restrict__ partial,
                                                          float* __restrict__ dr, float drop_p, uint32_t seed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][2E]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nch = E / (64 * V);
     float gm[MAXCH][V], dg[MAXCH][V], db[MAXCH][V];
 #pragma unroll
@@ -110,8 +116,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     const bool drop = drop_p > 0.f;
     const uint32_t thr = rlt_drop_threshold(drop_p);
     const float keep_scale = drop ? 1.f / (1.f - drop_p) : 1.f;
+    uint32_t hc[MAXCH][V];                   // dropout: this lane's column hashes (the token's row hash is wave-uniform)
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < V; ++i) hc[c][i] = (drop && c < nch) ? rlt_col_hash(seed, (uint32_t)(c * 64 * V + lane * V + i)) : 1u;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
         const size_t row = (size_t)t * E;
+        const uint32_t hr = rlt_row_hash(seed, (uint32_t)t);
         const float mean = stats[2 * (size_t)t], rstd = stats[2 * (size_t)t + 1];
         float xh[MAXCH][V], gy[MAXCH][V];
         float s1 = 0.f, s2 = 0.f;
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
                     for (int i = 0; i < V; ++i) {
                         float rv = rr[i];
-                        if (drop) rv = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? rv * keep_scale : 0.f;
+                        if (drop) rv = rlt_keep_rc(hr, hc[c][i], thr) ? rv * keep_scale : 0.f;
                         z[i] += rv;
                     }
                 }
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                     const int off = c * 64 * V + lane * V;
 #pragma unroll
                     for (int i = 0; i < V; ++i)
-                        o[i] = rlt_keep(seed, (uint32_t)t, (uint32_t)(off + i), thr) ? o[i] * keep_scale : 0.f;
+                        o[i] = rlt_keep_rc(hr, hc[c][i], thr) ? o[i] * keep_scale : 0.f;
                     stv<V>(dr + row + off, o);
                 }
             }

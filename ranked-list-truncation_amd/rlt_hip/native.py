@@ -41,7 +41,8 @@ _SIGNATURES = {
     "rlt_pair_softmax_bwd": (c_int, [P, P, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_bicut_loss": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
     "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "rlt_gemm_bits": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, P, c_float, P]),
+    "rlt_gemm_bits": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_float, c_uint32,
+                              P, P, c_float, P]),
     "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),
     "rlt_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int, c_float,
                             P, c_float, c_uint32, P, c_size_t, P]),

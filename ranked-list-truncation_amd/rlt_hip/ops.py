@@ -75,10 +75,11 @@ def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=
          ptr(relu_mask), ldmask, mask_scale, ptr(colsum_a), drop_p, seed, ptr(ws), ws_bytes, stream())
 
 
-def gemm_bits(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, bits_out=None, bits_in=None, mask_scale=1.0):
-    """rlt_gemm_bits: ReLU forward that also emits a 1-bit mask (bits_out, int32 (M, N/32)), or the masked backward
-    product that consumes it (bits_in)."""
-    call("rlt_gemm_bits", ta, tb, M, Nn, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), flags,
+def gemm_bits(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, bits_out=None, bits_in=None, mask_scale=1.0,
+              drop_p=0.0, seed=0):
+    """rlt_gemm_bits: ReLU (+ dropout) forward that also emits a 1-bit mask of the surviving elements (bits_out,
+    int32 (M, N/32)), or the masked backward product that consumes it (bits_in, mask_scale = 1/(1-p))."""
+    call("rlt_gemm_bits", ta, tb, M, Nn, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), flags, drop_p, seed,
          ptr(bits_out), ptr(bits_in), mask_scale, stream())
 
 
@@ -277,10 +278,12 @@ class EncoderLayerFn(Function):
         call("rlt_add_layernorm_fwd", ptr(x), ptr(proj), ptr(n1_w), ptr(n1_b), T, E, eps, drop_p, s_ln1, ptr(h1), ptr(st1), stream())
         hid = _empty((T, Fh), x)
         relu_bits = None
-        if drop_p == 0 and Fh % 32 == 0:
-            # 1-bit ReLU mask for the backward dH product (reads T*Fh/8 bytes instead of the 4*T*Fh of `hid`)
+        if Fh % 32 == 0:
+            # 1-bit mask (passed the ReLU and kept by the dropout) for the backward dH product, which then reads
+            # T*Fh/8 bytes instead of the 4*T*Fh of `hid`
             relu_bits = torch.empty((T, Fh // 32), dtype=torch.int32, device=x.device)
-            gemm_bits(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, bits_out=relu_bits)
+            gemm_bits(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, bits_out=relu_bits,
+                      drop_p=drop_p, seed=s_ffn)
         else:
             gemm(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=s_ffn)
         ff = _empty((T, E), x)
@@ -318,7 +321,7 @@ class EncoderLayerFn(Function):
         gemm(1, 0, E, Fh, T, dr2, E, hid, Fh, dw2, Fh, colsum_a=db2)
         dhid = _empty((T, Fh), x)
         if ctx.relu_bits is not None:
-            gemm_bits(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, bits_in=ctx.relu_bits)
+            gemm_bits(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, bits_in=ctx.relu_bits, mask_scale=1.0 / (1.0 - drop_p))
             ctx.relu_bits = None
         else:
             gemm(0, 0, T, Fh, E, dr2, E, w2, Fh, dhid, Fh, relu_mask=hid, ldmask=Fh, mask_scale=1.0 / (1.0 - drop_p))

@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_not_crashed(native):
     # entry points added for the narrow (input_size <= 3) LSTM layer and the 1-bit ReLU mask
     assert lib.rlt_bilstm_rec_fwd_x(None, 3, None, None, None, None, None, None, None, None, 1, 1, None, None, None, None) == -1
     assert lib.rlt_narrow_dw(None, 4, None, 3, 3, 1, 4, None, None, None, 0, None) == -1
-    assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, None, None, 1.0, None) == -1
+    assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, 0.0, 0, None, None, 1.0, None) == -1
     assert lib.rlt_pair_softmax_fwd(None, 1, 1, 0.0, 0, None, None) == -1
     assert lib.rlt_wass_loss_fwd(None, None, 2, 2, 1e-3, 100, 0.1, None, None, 0, None) == -1
     assert native.query("rlt_wass_loss_workspace", 63, 100) > 2 * 63 * 63 * 4

@@ -110,6 +110,19 @@ def gemm():
         ops.gemm_bits(0, 0, M, Nn, K, dY.to(dev), K, W2.to(dev), Nn, dH, Nn, bits_in=bits, mask_scale=1.25)
         refd = (dY.double() @ W2.double()) * (H.cpu() > 0) * 1.25
         report(f"gemm_bits masked bwd {M}x{Nn}x{K}", rel(dH, refd), mfma_tol(2e-6 * math.sqrt(K) + 1e-6))
+        # same product with the train-mode dropout of the FFN hidden fused in: output = relu * keep-mask of
+        # rlt_dropout_mask (the un-hoisted form of the same row x column hash), bits = what survived both
+        pd, sd = 0.4, 991 + M
+        mk = torch.empty(M, Nn, device=dev)
+        N.call("rlt_dropout_mask", sd, M, Nn, pd, N.ptr(mk), N.stream())
+        Hd = torch.empty(M, Nn, device=dev)
+        bits.zero_()
+        ops.gemm_bits(0, 1, M, Nn, K, A.to(dev), K, W.to(dev), K, Hd, Nn, bias=bias.to(dev), flags=N.GEMM_RELU, bits_out=bits,
+                      drop_p=pd, seed=sd)
+        report(f"gemm_bits relu+dropout fwd {M}x{Nn}x{K}", rel(Hd, H.double() * mk.double()), 1e-6)
+        unpacked = ((bits.cpu().unsqueeze(2) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(M, Nn).bool()
+        report(f"gemm_bits relu+dropout bits {M}x{Nn}x{K}", float((unpacked != (Hd.cpu() > 0)).sum()), 0)
+        report(f"gemm_bits dropout keep fraction {M}x{Nn}x{K}", abs(float((mk > 0).float().mean()) - (1 - pd)), 8e-3)
     X = torch.randn(5000, 300)
     out = torch.empty(300, device=dev)
     ops.colsum(X.to(dev), 300, 5000, 300, out)
