@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     if (a.lse && tid < KT) {
         const int q = tile * KT + tid, qc = min(q, a.B - 1);
         const float l = a.lse[((size_t)s * a.H + h) * a.B + qc], e = a.delta[((size_t)s * a.H + h) * a.B + qc];
-        aux[tid] = q < a.B ? l * LOG2E : 0.f;
-        aux[KT + tid] = q < a.B ? e : 0.f;
+        aux[tid] = q < a.B ? -l * LOG2E : 0.f;          // negated: both seed MFMA accumulators (S - lse, dP - delta)
+        aux[KT + tid] = q < a.B ? -e : 0.f;
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(a.out + (((size_t)m * a.S * a.H + pair) * nt + tile) * Rec<HD>::BYTES);
@@ -404,6 +404,12 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    // the S and dP products start from accumulators holding -lse and -delta of this lane's query (two register
+    // blocks kept for the whole kernel: the MFMA reads them as its C operand), so they come out as S - lse and
+    // dP - delta without a subtraction per element (with dropout delta is subtracted after the mask)
+    f32x16 c_lse, c_del;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c_lse[r] = -lse2; c_del[r] = DROP ? 0.f : -del; }
 
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
@@ -426,11 +432,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
             const uint16_t* vr_lo = vr_hi + rows_elems<HD>();
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows<HD>(kr_hi, kr_lo, sub, l31, hh, qh, ql, sc);       // S^T[key][q]
-                dp = mma_rows<HD>(vr_hi, vr_lo, sub, l31, hh, doh, dol, dp);     // dP^T[key][q]
+                f32x16 sc = mma_rows<HD>(kr_hi, kr_lo, sub, l31, hh, qh, ql, c_lse);      // S^T[key][q] - lse
+                f32x16 dp = mma_rows<HD>(vr_hi, vr_lo, sub, l31, hh, doh, dol, c_del);    // dP^T[key][q] (- delta)
                 if (t == nt - 1) {            // only the last tile can hold keys beyond B
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -444,10 +447,10 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * gq + i;
-                        const float p = rlt_exp2(sc[r] - lse2);
+                        const float p = rlt_exp2(sc[r]);
                         float dpr = dp[r];
-                        if (DROP) dpr = rlt_keep_rc(hq, hk[i], a.drop_thr) ? dpr * inv_keep : 0.f;
-                        dp[r] = p * (dpr - del);                                   // dS^T
+                        if (DROP) dpr = (rlt_keep_rc(hq, hk[i], a.drop_thr) ? dpr * inv_keep : 0.f) - del;
+                        dp[r] = p * dpr;                                           // dS^T
                     }
                 }
                 mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);                     // dQ^T[d][q] += K^T dS^T
@@ -519,24 +522,31 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const float* Es = Ls + KT;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                // the accumulators start at -lse[q] and -delta[q] (the aux block of the dO record holds them negated),
+                // so the products come out as S - lse and dP - delta without a subtraction per element (with dropout
+                // delta is subtracted after the mask)
                 f32x16 sc, dp;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] (Q carries scale*log2e)
-                dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key]
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + acc_row(r, hh);
+                    sc[r] = Ls[ql];
+                    dp[r] = DROP ? 0.f : Es[ql];
+                }
+                sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] - lse (Q carries scale*log2e)
+                dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key] (- delta)
                 // queries beyond B need no mask: their columns of the transposed Q / dO images are zero, p is finite
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
-                    float p = rlt_exp2(sc[r] - Ls[ql]);
+                    float p = rlt_exp2(sc[r]);
                     float dpr = dp[r];
                     if (DROP) {
                         const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
                         dpr = keep ? dpr * inv_keep : 0.f;
-                        dp[r] = p * (dpr - Es[ql]);                                // dS uses the undropped p
+                        dp[r] = p * (dpr + Es[ql]);                                // dS uses the undropped p
                         p = keep ? p * inv_keep : 0.f;
                     } else {
-                        dp[r] = p * (dpr - Es[ql]);
+                        dp[r] = p * dpr;
                     }
                     sc[r] = p;
                 }
