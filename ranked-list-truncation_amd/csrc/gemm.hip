@@ -724,7 +724,12 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
         const uint16_t* pa = lds + buf * 4 * PL2 + (wm * 64 + pl) * 32;
         const uint16_t* pb = lds + buf * 4 * PL2 + 2 * PL2 + (wn * 128 + pl) * 32;
         uint16_t* nb = lds + (buf ^ 1) * 4 * PL2;
-        const bool do_stash = t + 1 < nt_, do_fetch = t + 2 < nt_;
+        // the fetch of tile t+2 is unconditional (the last two iterations re-read the last tile into registers nobody
+        // consumes): with the loads behind a branch hipcc merges the outstanding-load counts of both paths and waits
+        // for the loads it has just issued (vmcnt(3..0) at every staging step instead of vmcnt(7..4)), which exposed
+        // one full memory latency per 32-wide K step
+        const bool do_stash = t + 1 < nt_;
+        const int kf = kbeg + min(t + 2, nt_ - 1) * BK3;
         bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
         auto load_a = [&](int ks, int slot) {
             const int co = 8 * ((2 * ks + hh) ^ sw);
@@ -760,20 +765,20 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
                 if (step < 6) {
                     store3b_part<!TA>(nb, nb + PL2, tid, sa, 2 * (step - 4));
                     store3b_part<!TA>(nb, nb + PL2, tid, sa, 2 * (step - 4) + 1);
-                    if (step == 5 && do_fetch) load3b<!TA>(g.A, g.lda, m0, kbeg + (t + 2) * BK3, tid, sa);
                 } else {
                     store3b_part<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb, 2 * (step - 6));
                     store3b_part<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb, 2 * (step - 6) + 1);
-                    if (step == 7 && do_fetch) load3b<TB>(g.B, g.ldb, n0, kbeg + (t + 2) * BK3, tid, sb);
                 }
             }
+            if (step == 5) load3b<!TA>(g.A, g.lda, m0, kf, tid, sa);
+            if (step == 7) load3b<TB>(g.B, g.ldb, n0, kf, tid, sb);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     const int nt = (kend - kbeg) / BK3;
     fetch(0);
     stash(0);
-    if (nt > 1) fetch(1);
+    fetch(min(1, nt - 1));                             // unconditional, like the fetches in multiply()
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         multiply(t & 1, t, nt);                        // tile t; stashes tile t+1 (in registers), fetches tile t+2
