@@ -232,7 +232,7 @@ def main():
         S_mean = sum(lengths) / len(lengths)                   # positions per launch, averaged over the buckets
         unit_flops = 2.0 * B * B * hd * S_mean * heads_
         if precision == "fp32":
-            kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2>" % hd, 4, 1, PEAK_F32_MFMA_TFLOPS
+            kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2,%s>" % (hd, "true" if args.dropout > 0 else "false"), 4, 1, PEAK_F32_MFMA_TFLOPS
         else:
             kern, products, mult, peak = "attn3_bwd_dkv_kernel<%d,%s>" % (hd, "true" if args.dropout > 0 else "false"), 4, 3, PEAK_BF16_MFMA_TFLOPS
         algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
@@ -243,12 +243,12 @@ def main():
         step_flop = step_algorithmic_flops(args.model, B, S) if headline else None
         step_bytes = 16.0e6 * B * S / 300.0 if headline else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/r01_q_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
+        # same command (tools/pmc_traffic.py -> profiles/r01_r_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
         # applied); only quoted for the exact workload and kernel it was measured on
         traffic = None
         step_traffic = None
         try:
-            with open(os.path.join(REPO, "profiles", "r01_q_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_r_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if (headline and args.dropout == 0 and B == 4096 and S == 300 and precision == "bf16x3"
                     and all(kern.startswith(k) for k in pmc["dominant_launch"])):

@@ -106,7 +106,7 @@ __device__ __forceinline__ void mma_tile_cols(const float* __restrict__ tile, in
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int LD = HD + 4, DT = (HD + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,15 +182,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             l_run = l_run * alpha + psum;
             m_run = m_new;
-            if (a.drop_p > 0.f) {          // dropout acts on the normalised probabilities: the normaliser keeps all keys
+            if (DROP) {                    // dropout acts on the normalised probabilities: the normaliser keeps all keys
+                // (compiled out at p = 0: hipcc if-converts a run-time test and executes the hash regardless)
                 const uint32_t ps = pair_seed(a.seed, pair);
+                const uint32_t hq = rlt_row_hash(ps, (uint32_t)q);
                 const float inv_keep = 1.f / (1.f - a.drop_p);
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = t * KT + sub * 32 + acc_row(r, hh);
-                        sc[sub][r] = rlt_keep(ps, (uint32_t)q, (uint32_t)key, a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
+                        sc[sub][r] = rlt_keep_rc(hq, rlt_col_hash(ps, (uint32_t)key), a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
                     }
             }
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int HD, int OCC>
+template <int HD, int OCC, bool DROP>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int LD = HD + 4, DT = (HD + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
                     const bool ok = t * KT + ql < B;
                     const float p = ok ? rlt_exp2(sc[r] - lt_[ql]) : 0.f;
                     float pd = p, dpr = dp[r];
-                    if (a.drop_p > 0.f) {
+                    if (DROP) {
                         const bool keep = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
                         const float m = keep ? 1.f / (1.f - a.drop_p) : 0.f;
                         pd = p * m;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int LD = HD + 4, DT = (HD + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                     const int kidx = t * KT + sub * 32 + acc_row(r, hh);
                     const float p = kidx < B ? rlt_exp2(sc[r] - lse2) : 0.f;
                     float dpr = dp[r];
-                    if (a.drop_p > 0.f)
+                    if (DROP)
                         dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
                     dp[r] = p * (dpr - del);                              // dS^T
                 }
@@ -416,36 +418,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 template <int HD> size_t fwd_smem() { return (size_t)4 * KT * (HD + 4) * sizeof(float); }
 template <int HD> size_t dkv_smem() { return (size_t)(4 * KT * (HD + 4) + 4 * KT) * sizeof(float); }
 
-template <int HD>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
+template <int HD, bool DROP>
+int launch_fwd_t(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    int rc = rlt_allow_lds(attn_fwd_kernel<HD>, fwd_smem<HD>());
+    int rc = rlt_allow_lds(attn_fwd_kernel<HD, DROP>, fwd_smem<HD>());
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, DROP>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
     return RLT_LAUNCH_RESULT();
 }
-template <int HD>
-int launch_dkv(const AttnArgs& a, hipStream_t st) {
+template <int HD, bool DROP>
+int launch_dkv_t(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
     static const int occ = [] { const char* e = getenv("RLT_DKV_OCC"); return (e && atoi(e) == 1) ? 1 : 2; }();
     if (occ == 2 && HD <= 64) {          // head dim 128 needs the 512-register form
-        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 2>, dkv_smem<HD>());
+        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 2, DROP>, dkv_smem<HD>());
         if (rc) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2, DROP>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
     } else {
-        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 1>, dkv_smem<HD>());
+        int rc = rlt_allow_lds(attn_bwd_dkv_kernel<HD, 1, DROP>, dkv_smem<HD>());
         if (rc) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, DROP>), dim3(grid), dim3(256), dkv_smem<HD>(), st, a);
     }
     return RLT_LAUNCH_RESULT();
 }
-template <int HD>
-int launch_dq(const AttnArgs& a, hipStream_t st) {
+template <int HD, bool DROP>
+int launch_dq_t(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD>, fwd_smem<HD>());
+    int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD, DROP>, fwd_smem<HD>());
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
     return RLT_LAUNCH_RESULT();
+}
+// dropout is a template parameter: hipcc if-converts a run-time `drop_p > 0` test and executes the hash regardless
+template <int HD> int launch_fwd(const AttnArgs& a, hipStream_t st) {
+    return a.drop_p > 0.f ? launch_fwd_t<HD, true>(a, st) : launch_fwd_t<HD, false>(a, st);
+}
+template <int HD> int launch_dkv(const AttnArgs& a, hipStream_t st) {
+    return a.drop_p > 0.f ? launch_dkv_t<HD, true>(a, st) : launch_dkv_t<HD, false>(a, st);
+}
+template <int HD> int launch_dq(const AttnArgs& a, hipStream_t st) {
+    return a.drop_p > 0.f ? launch_dq_t<HD, true>(a, st) : launch_dq_t<HD, false>(a, st);
 }
 
 AttnArgs bwd_args(const float* qkv, const float* dout, const float* lse, const float* delta,

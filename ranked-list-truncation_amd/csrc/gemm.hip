@@ -221,25 +221,32 @@ __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (
         const uint32_t thr = g.drop_thr, seed = g.seed;
         const int rb = __builtin_amdgcn_readfirstlane(rbase);
         auto tile = [&](auto with_bits) {
+            uint32_t hc[NJ];
+            float bv[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int col = cbase + j * 32 + l31;
-                const uint32_t hc = rlt_col_hash(seed, (uint32_t)col);
-                float bv = 0.f;
-                if (g.bias) bv += g.bias[col];
-                if (g.bias2) bv += g.bias2[col];
+                hc[j] = rlt_col_hash(seed, (uint32_t)col);
+                bv[j] = 0.f;
+                if (g.bias) bv[j] += g.bias[col];
+                if (g.bias2) bv[j] += g.bias2[col];
+            }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row_lo = rb + i * 32 + (r & 3) + 8 * (r >> 2);
-                        // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select below
-                        // into one per-lane hash of row_lo + 4*hh on the VALU: 64 hashes and live registers per lane)
-                        const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)row_lo));
-                        const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)(row_lo + 4)));
-                        const int row = row_lo + 4 * hh;
-                        float v = fmaxf(acc[i][j][r] + bv, 0.f);
-                        v = rlt_keep_rc(hh ? h1 : h0, hc, thr) ? v * inv_keep : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int row_lo = rb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select below into
+                    // one per-lane hash of row_lo + 4*hh on the VALU: 64 hashes and as many live registers per lane)
+                    const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)row_lo));
+                    const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)(row_lo + 4)));
+                    const uint32_t hr = hh ? h1 : h0;
+                    const int row = row_lo + 4 * hh;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int col = cbase + j * 32 + l31;
+                        float v = fmaxf(acc[i][j][r] + bv[j], 0.f);
+                        v = rlt_keep_rc(hr, hc[j], thr) ? v * inv_keep : 0.f;
                         if (decltype(with_bits)::value) {
                             const unsigned long long bal = __ballot(v > 0.f);
                             if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
