@@ -258,7 +258,7 @@ __device__ __forceinline__ const uint8_t* record(const uint8_t* img, int m, int 
 
 // ------------------------------------------------------------------------------------------ forward
 template <int HD, bool DROP>
-__global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
+__global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
     constexpr int STAGE = Rec<HD>::RP + Rec<HD>::TP;                        // K rows pair | V transposed pair
