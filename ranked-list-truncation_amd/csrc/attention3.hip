@@ -147,12 +147,13 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
         split8(x, wh, wl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
+            // head dim 16: lanes 16..31 supply A rows d >= HD.  They re-read row HD-1 (clamped address): output row d
+            // depends on A row d only, and store_acc_T never writes rows >= HD, so no zeroing (a divergent branch and 8
+            // moves per 8 scores when it was there)
             const int d = dt * 32 + l31;
-            const bool ok = d < HD;
             const int off = min(d, HD - 1) * LDT3 + sub * 32 + 16 * s + 8 * hh;
-            uint4 ah = *reinterpret_cast<const uint4*>(thi + off);
-            uint4 al = *reinterpret_cast<const uint4*>(tlo + off);
-            if (HD < 32 && !ok) { ah = make_uint4(0, 0, 0, 0); al = make_uint4(0, 0, 0, 0); }
+            const uint4 ah = *reinterpret_cast<const uint4*>(thi + off);
+            const uint4 al = *reinterpret_cast<const uint4*>(tlo + off);
             acc[dt] = mfma3(as_frag(ah), as_frag(al), wh, wl, acc[dt]);
         }
     }
