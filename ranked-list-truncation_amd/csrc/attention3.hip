@@ -20,6 +20,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDT3 = 72;                 // bf16 elements per row of a transposed [d][64 rows] image (144 B)
+// rows of a transposed image: the HD rows of the tile, plus - where the 32-row MFMA operand has rows to spare (head
+// dim 16) - one row of ones: the product that forms O^T = V^T P^T then also delivers sum_k P[k][q] in its row HD, i.e.
+// the softmax normaliser, and the forward kernel keeps no running sum of its own (32 adds per 64 keys less)
+template <int HD> constexpr int T_rows() { return HD < 32 ? HD + 1 : HD; }
 
 __device__ __forceinline__ uint32_t pk2(float a, float b) {
     typedef __bf16 v2 __attribute__((ext_vector_type(2)));
@@ -147,11 +151,11 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
         split8(x, wh, wl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            // head dim 16: lanes 16..31 supply A rows d >= HD.  They re-read row HD-1 (clamped address): output row d
-            // depends on A row d only, and store_acc_T never writes rows >= HD, so no zeroing (a divergent branch and 8
-            // moves per 8 scores when it was there)
+            // head dim 16: lanes 16..31 supply A rows d >= HD.  They read the row of ones (clamped address): output
+            // row d depends on A row d only, and store_acc_T never writes rows >= HD, so no zeroing (a divergent branch
+            // and 8 moves per 8 scores when it was there)
             const int d = dt * 32 + l31;
-            const int off = min(d, HD - 1) * LDT3 + sub * 32 + 16 * s + 8 * hh;
+            const int off = min(d, T_rows<HD>() - 1) * LDT3 + sub * 32 + 16 * s + 8 * hh;
             const uint4 ah = *reinterpret_cast<const uint4*>(thi + off);
             const uint4 al = *reinterpret_cast<const uint4*>(tlo + off);
             acc[dt] = mfma3(as_frag(ah), as_frag(al), wh, wl, acc[dt]);
@@ -160,7 +164,7 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
 }
 
 template <int HD> constexpr int rows_elems() { return KT * (HD + 8); }     // one hi or lo rows image
-template <int HD> constexpr int T_elems() { return HD * LDT3; }             // one hi or lo transposed image
+template <int HD> constexpr int T_elems() { return T_rows<HD>() * LDT3; }   // one hi or lo transposed image
 
 // ---- pre-split tile images in HBM -----------------------------------------------------------------------
 // A one-time "prepare" pass splits each 64-row tile of Q, K, V (and dO) into bf16 hi/lo ONCE and writes it in
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     }
     stage_store_rows<HD>(r_hi, r_lo, tid, st);
     stage_store_T<HD>(t_hi, t_lo, tid, st);
+    if (T_rows<HD>() > HD && tid < KT) t_hi[HD * LDT3 + tid] = 0x3F80;      // bf16 1.0 (lo plane stays 0)
     if (a.lse && tid < KT) {
         const int q = tile * KT + tid, qc = min(q, a.B - 1);
         const float l = a.lse[((size_t)s * a.H + h) * a.B + qc], e = a.delta[((size_t)s * a.H + h) * a.B + qc];
@@ -286,6 +291,8 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // head dim 16 without dropout: the normaliser is row HD of O^T (T_rows above; with dropout P.V runs on the dropped P)
+    constexpr bool LROW = T_rows<HD>() > HD && !DROP;
 
     // dropout: hash of this lane's query once; hashes of a tile's keys in LDS, written while the tile is in flight
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
                 for (int r = 0; r < 16; ++r) {
                     const float p = rlt_exp2(sc[sub][r] - m_new);
                     sc[sub][r] = p;
-                    psum += p;
+                    if (!LROW) psum += p;
                 }
                 if (DROP) {
                     const uint4* hk4 = reinterpret_cast<const uint4*>(htab + buf * KT + sub * 32 + 4 * hh);
@@ -357,13 +364,13 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
                 }
                 mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
             }
-            l_run = l_run * alpha + psum;
+            if (!LROW) l_run = l_run * alpha + psum;
             m_run = m_new;
         }
         __syncthreads();
     }
     if (!wave_live) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = LROW ? oacc[0][8] : l_run + __shfl_xor(l_run, 32, 64);   // register 8 = row 16 (20 for the upper lane half)
     if (q < B) {
         store_acc_T<HD>(a.o + ((size_t)s * B + q) * E + h * HD, hh, oacc, 1.f / l_tot);
         if (hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_tot)) * LN2;
