@@ -257,6 +257,9 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
     hi.x = pk2(a, b);
     hi.y = pk2(c, d);
+    // opaque to the optimiser: otherwise hipcc re-derives the low element's bf16 with a second v_cvt_pk (x, 0) instead
+    // of shifting the packed pair (one extra VALU instruction per two elements)
+    asm("" : "+v"(hi.x), "+v"(hi.y));
     lo.x = pk2(a - __builtin_bit_cast(float, hi.x << 16), b - __builtin_bit_cast(float, hi.x & 0xffff0000u));
     lo.y = pk2(c - __builtin_bit_cast(float, hi.y << 16), d - __builtin_bit_cast(float, hi.y & 0xffff0000u));
 }
