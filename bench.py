@@ -243,12 +243,12 @@ def main():
         step_flop = step_algorithmic_flops(args.model, B, S) if headline else None
         step_bytes = 16.0e6 * B * S / 300.0 if headline else None
         # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/r01_r_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
+        # same command (tools/pmc_traffic.py -> profiles/r01_s_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
         # applied); only quoted for the exact workload and kernel it was measured on
         traffic = None
         step_traffic = None
         try:
-            with open(os.path.join(REPO, "profiles", "r01_r_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_s_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if (headline and args.dropout == 0 and B == 4096 and S == 300 and precision == "bf16x3"
                     and all(kern.startswith(k) for k in pmc["dominant_launch"])):
