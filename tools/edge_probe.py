@@ -31,6 +31,7 @@ for prec in ("bf16x3", "fp32"):
         outs_d = mod(x.to(dev))
         outs_r = outs_r if isinstance(outs_r, (list, tuple)) else [outs_r]
         outs_d = outs_d if isinstance(outs_d, (list, tuple)) else [outs_d]
+        torch.manual_seed(11)                                      # same cotangents on every run
         g = [torch.randn_like(o) for o in outs_r]
         sum((o * gi).sum() for o, gi in zip(outs_r, g)).backward()
         sum((o * gi.to(dev)).sum() for o, gi in zip(outs_d, g)).backward()
@@ -44,14 +45,15 @@ for prec in ("bf16x3", "fp32"):
             # either branch (tools/gpu_probe.py, dropout section).  One flipped unit moves one row of linear1's gradient -
             # and, through dX, everything upstream - by ~1/sqrt(tokens) of the gradient's size: percent-level at these
             # token counts.  bf16x3 pre-activations carry ~1e-5 relative error, so a few units per ~1e6 flip; in fp32
-            # mode ~1e-7, i.e. rarely any.  A wrong kernel is O(1) in this metric.
+            # mode ~1e-7, i.e. rarely any (the 33 x 64 AttnCut case has one: 0.8-1.3e-3 depending on the cotangents).
+            # A wrong kernel is O(1) in this metric.
             scale = max(float(p2.grad.norm()), 1e-3 * p2.grad.numel() ** 0.5)
             e = float((p1.grad.cpu() - p2.grad).norm()) / scale
             worst.append((e, n1))
             eg = max(eg, e)
         if os.environ.get("EDGE_VERBOSE") and eg >= 1e-3:
             print("     worst:", [(f"{e:.1e}", n) for e, n in sorted(worst, reverse=True)[:6]])
-        ok = eo < 1e-5 and eg < (2e-2 if prec == "bf16x3" else 1e-3)      # see the comment at the metric
+        ok = eo < 1e-5 and eg < (2e-2 if prec == "bf16x3" else 3e-3)      # see the comment at the metric
         bad += not ok
         print(f"{'OK  ' if ok else 'FAIL'} {prec:6s} {name:10s} {kw} B{B} S{S}: out err {eo:.2e} grad err {eg:.2e}", flush=True)
 sys.exit(1 if bad else 0)
