@@ -3,15 +3,23 @@
 + backward [+ gradient all-reduce] + Adam + cut metrics) of AttnCut on synthetic robust04-shaped
 lists of length 300, batch 4096 per GPU (BASELINE.json configs[1]), on the HIP hot path.
 
-    python bench.py [--gpus N --steps K --warmup W]          # N=1 directly
+    python bench.py [--gpus N --steps K --warmup W]          # N=1 directly; N>1 starts its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
 
+Launched with --gpus N > 1 and no WORLD_SIZE in the environment, this process never touches the GPU:
+it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (fresh
+processes, one rank per GPU over RCCL), lets rank 0 print the JSON line and exits with the child's
+status.
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream
-for the dominant kernel (the attention dK/dV backward kernel); `cpu_baseline` times the CPU oracle
-(oracle/, the pinned restatement of the reference) on a bounded sample on this box's host cores.
+for the dominant kernel (the attention dK/dV backward kernel) in a short loop AFTER the timed
+region; `fp32_mode` times the same step in the library's exact-fp32 MFMA mode (the reference's own
+arithmetic) in the same run; `cpu_baseline` times the CPU oracle (oracle/, the pinned restatement
+of the reference) on bounded samples on this box's host cores.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -20,12 +28,15 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "ranked-list-truncation_amd"))
 
-import numpy as np
-import torch
+import torch          # importing torch does not initialise the GPU
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
+PEAK_HBM_BPS = 8.0e12
+# HBM traffic per launch / per step is NOT measured by this script: it comes from separate rocprofv3 --pmc passes of
+# this same command (tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) committed here:
+PMC_TRAFFIC_FILES = (os.path.join("profiles", "r02_pmc_traffic.json"), os.path.join("profiles", "r01_s_pmc_traffic.json"))
 
 
 def synth_batch(batch, seq_len, n_feat, seed, device):
@@ -43,8 +54,34 @@ def synth_batch(batch, seq_len, n_feat, seed, device):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(seq_len, sample_batch, steps):
-    """The CPU oracle's training step (fwd + vectorised reward loss + bwd) on the host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_cpu_steps(step, budget_s, max_steps, tag):
+    t0 = time.time()
+    step()
+    warm = time.time() - t0
+    print(f"[bench] cpu baseline ({tag}) warm-up step: {warm:.1f}s", file=sys.stderr, flush=True)
+    steps = max(1, min(max_steps, int(budget_s / max(warm, 1e-3))))
+    t0 = time.time()
+    for i in range(steps):
+        step()
+        print(f"[bench] cpu baseline ({tag}) step {i + 1}/{steps}", file=sys.stderr, flush=True)
+    return (time.time() - t0) / steps, steps
+
+
+def cpu_baseline(seq_len, vec_batch, loop_batch):
+    """The CPU oracle's training step (zero_grad + fwd + reward loss + bwd) on the host cores, the two variants of
+    SURVEY.md 8(d): `value` = closed-form (vectorised) reward at batch `vec_batch`; `loop_faithful` = the reference's
+    B*S python reward loop (utils/losses.py:217-225 -> utils/metrics.py:85-101) at batch `loop_batch`."""
     from oracle import losses as olosses, models as omodels
     # threads = this process's CPU share (the GPU box gives 16 of the host's cores to a 1-GPU job;
     # os.cpu_count() would report the whole host and oversubscribe)
@@ -55,35 +92,52 @@ def cpu_baseline(seq_len, sample_batch, steps):
     cores = int(os.environ.get("RLT_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     model = omodels.AttnCut(dropout=0.0)
-    crit = olosses.DivLoss(metric='f1', div_type='js', augmented=True)
-    x, y = synth_batch(sample_batch, seq_len, 3, 20240, "cpu")
 
-    def step():
-        model.zero_grad()
-        loss = crit(model(x), y)
-        loss.backward()
+    def make_step(crit, batch):
+        x, y = synth_batch(batch, seq_len, 3, 20240, "cpu")
 
-    t0 = time.time()
-    step()
-    warm = time.time() - t0
-    print(f"[bench] cpu baseline warm-up step: {warm:.1f}s on {cores} threads", file=sys.stderr, flush=True)
-    steps = max(1, min(steps, int(20.0 / max(warm, 1e-3))))       # bound the CPU leg to ~20 s
-    t0 = time.time()
-    for i in range(steps):
-        step()
-        print(f"[bench] cpu baseline step {i + 1}/{steps}", file=sys.stderr, flush=True)
-    dt = (time.time() - t0) / steps
-    return {"value": round(sample_batch / dt, 3), "unit": "lists/s", "cores": cores, "kind": "port",
-            "sample": f"oracle AttnCut+DivLoss(js,f1) fwd+bwd, batch {sample_batch} x len {seq_len}, "
-                      f"{steps} steps after 1 warm-up, closed-form reward (the reference's python reward loop "
-                      f"adds ~20 ms per list on top); attention cost grows with batch, so per-list CPU cost at "
-                      f"batch 4096 is higher than at this sample"}
+        def step():
+            model.zero_grad()
+            loss = crit(model(x), y)
+            loss.backward()
+        return step
+
+    vec_dt, vec_steps = _time_cpu_steps(
+        make_step(olosses.DivLoss(metric='f1', div_type='js', augmented=True), vec_batch), 14.0, 3,
+        f"vectorised reward, batch {vec_batch}")
+    loop_dt, loop_steps = _time_cpu_steps(
+        make_step(olosses.DivLoss(metric='f1', div_type='js', augmented=True, loop=True), loop_batch), 8.0, 3,
+        f"loop-faithful reward, batch {loop_batch}")
+    return {"value": round(vec_batch / vec_dt, 3), "unit": "lists/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(),
+            "sample": f"oracle AttnCut+DivLoss(js,f1) fwd+bwd, batch {vec_batch} x len {seq_len}, {vec_steps} steps after 1 "
+                      f"warm-up, closed-form reward; list-axis attention cost grows with the batch, so the per-list CPU cost "
+                      f"at batch 4096 is higher than at this sample",
+            "loop_faithful": {"value": round(loop_batch / loop_dt, 3), "unit": "lists/s",
+                              "sample": f"same step with the reference's B*S python reward loop, batch {loop_batch} x len "
+                                        f"{seq_len}, {loop_steps} steps after 1 warm-up"}}
 
 
 def step_algorithmic_flops(model, B, S):
     """AttnCut fwd FLOPs per token = 3,676,672 + 1024*L (L = lists the attention spans); fwd+bwd = 3x."""
     assert model == "attncut"
     return 3.0 * (3676672 + 1024 * B) * S * B
+
+
+def spawn_ranks(n, argv):
+    """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run (a CHILD process - never an
+    exec - from this parent, which has not initialised the GPU) and return the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode        # rank 0 writes the JSON line to the inherited stdout
 
 
 def main():
@@ -96,8 +150,11 @@ def main():
     ap.add_argument("--model", default="attncut", choices=["attncut", "choopy", "mtattncut", "mmoecut"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32"],
-                    help="MFMA product mode of the library (default: the library default, bf16x3)")
-    ap.add_argument("--cpu-sample-batch", type=int, default=128)
+                    help="MFMA product mode of the library for the headline figure (default: the library default, bf16x3)")
+    ap.add_argument("--fp32-steps", type=int, default=5,
+                    help="steps timed in exact-fp32 mode after the headline loop (0: skip); ignored with --precision fp32")
+    ap.add_argument("--cpu-sample-batch", type=int, default=512, help="batch of the vectorised-reward CPU sample")
+    ap.add_argument("--cpu-loop-batch", type=int, default=32, help="batch of the loop-faithful CPU sample")
     # side configurations of SURVEY.md 8(d); the headline line uses none of them
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train-mode dropout (parity runs use 0.0; the reference conf values are 0.4 / 0.2)")
@@ -108,11 +165,14 @@ def main():
                          "(BASELINE configs[4]: 100,200,300); --steps should be a multiple of their number")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     # RLT_BENCH_DEVICE / RLT_DIST_BACKEND exist only to rehearse the N>1 launch contract on a one-GPU box
@@ -127,6 +187,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
 
     import models as hip_models
     from utils import losses as hip_losses
@@ -136,28 +197,29 @@ def main():
     if args.precision:
         native.set_precision(args.precision)
     precision = native.get_precision()
+    ops.set_seed_stream(rank)             # decorrelates the dropout masks of the ranks (same torch seed everywhere)
 
     torch.manual_seed(1234)
     S, B = args.seq_len, args.batch
     if args.model == "attncut":
         model = hip_models.AttnCut(input_size=3, dropout=args.dropout).to(dev)
         crit = hip_losses.DivLoss(metric=args.reward, div_type='js', augmented=True)
-        n_feat, heads_, hd, layers, wl = 3, 4, 64, 1, f"AttnCut + DivLoss(js,{args.reward},augmented) [BASELINE configs[1]]"
+        n_feat, heads_, hd, wl = 3, 4, 64, f"AttnCut + DivLoss(js,{args.reward},augmented) [BASELINE configs[1]]"
     elif args.model == "choopy":
         model = hip_models.Choopy(seq_len=S, dropout=args.dropout).to(dev)
         crit = hip_losses.ChoopyLoss(metric=args.reward)
-        n_feat, heads_, hd, layers, wl = 1, 8, 16, 3, f"Choopy + ChoopyLoss({args.reward}) [BASELINE configs[2] at batch 8192]"
+        n_feat, heads_, hd, wl = 1, 8, 16, f"Choopy + ChoopyLoss({args.reward}) [BASELINE configs[2] at batch 8192]"
     elif args.model == "mtattncut":
         nt = 3 if args.num_tasks is None else args.num_tasks
         model = hip_models.MtAttnCut(input_size=3, num_tasks=nt, dropout=args.dropout).to(dev)
         crit = hip_losses.MtCutLoss(metric=args.reward, num_tasks=nt)
-        n_feat, heads_, hd, layers = 3, 4, 64, 1
+        n_feat, heads_, hd = 3, 4, 64
         wl = f"MtAttnCut(tasks {nt:g}) + MtCutLoss({args.reward}) [BASELINE configs[4]]"
     else:
         nt = 2.1 if args.num_tasks is None else args.num_tasks
         model = hip_models.MMOECut(seq_len=S, num_experts=4, num_tasks=nt, dropout=args.dropout).to(dev)
         crit = hip_losses.MtCutLoss(metric=args.reward, rerank_weight=0.4, classi_weight=0.6, num_tasks=nt)
-        n_feat, heads_, hd, layers = 3, 4, 64, 4
+        n_feat, heads_, hd = 3, 4, 64
         wl = f"MMOECut(4 experts, tasks {nt:g}) + MtCutLoss({args.reward}) [BASELINE configs[3]]"
     flat = FlatModel(model)
     flat.broadcast_params()
@@ -171,7 +233,6 @@ def main():
             raise SystemExit("--buckets: Choopy / MMOECut are built for one list length (seq_len)")
         wl += f", length buckets {lengths} round-robin"
     batches = [synth_batch(B, L, n_feat, 20240 + rank + 7 * i, dev) for i, L in enumerate(lengths)]
-    timer = ops.KernelTimer()
     turn = [0]
 
     def step():
@@ -194,6 +255,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps):
+        """n_steps steps bracketed by barrier + synchronize on both sides; (max-over-ranks seconds, last state)."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            state = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, state
+
+    def kernel_times(n_steps):
+        """HIP-event times of the named attention launches, taken OUTSIDE the timed region (short separate loop)."""
+        timer = ops.KernelTimer()
+        ops.KernelTimer.active = timer
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.KernelTimer.active = None
+        return timer.summary()
+
+    def check_state(state, what):
+        vals = [float(v.detach()) for v in state]
+        if not all(math.isfinite(v) for v in vals):
+            raise SystemExit(f"bench.py: non-finite training state after {what}: loss/f1/dcg = {vals}")
+        return vals
+
     # every bucket is served at least once untimed (first use of a shape allocates its buffers)
     n_warm = args.warmup if len(batches) == 1 else max(args.warmup, len(batches))
     for i in range(n_warm):
@@ -201,25 +292,38 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warm-up step {i + 1}/{n_warm} done", file=sys.stderr, flush=True)
-    fence()
-    ops.KernelTimer.active = timer
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, f1, dcg = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ops.KernelTimer.active = None
+    elapsed, state = timed(args.steps)
+    loss_v, f1_v, dcg_v = check_state(state, f"{args.steps} timed steps")
     if rank == 0:
         print(f"[bench] {args.steps} timed steps: {elapsed / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    ksum = kernel_times(len(batches) * 3)
+    S_mean = sum(lengths) / len(lengths)                   # positions per launch, averaged over the buckets
+    unit_flops = 2.0 * B * B * hd * S_mean * heads_        # one B x B x hd product per (position, head)
+
+    # the same step in the library's exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32: the reference's own arithmetic)
+    fp32_mode = None
+    if precision != "fp32" and args.fp32_steps > 0:
+        native.set_precision("fp32")
+        for _ in range(len(batches)):
+            step()
+        f_elapsed, f_state = timed(args.fp32_steps)
+        check_state(f_state, "the fp32-mode steps")
+        f_ksum = kernel_times(len(batches) * 2)
+        native.set_precision(precision)
+        f_ms = f_elapsed / args.fp32_steps * 1e3
+        f_launches, f_dkv_ms = f_ksum.get("attn_bwd_dkv", (0, float("nan")))
+        f_ach = 4 * unit_flops / (f_dkv_ms * 1e-3) / 1e12 if f_launches else float("nan")
+        fp32_mode = {"dtype": "f32 (v_mfma_f32_32x32x2_f32 products, f32 accumulate)", "steps": args.fp32_steps,
+                     "ms_per_step": round(f_ms, 3), "value": round(B * world * args.fp32_steps / f_elapsed, 2), "unit": "lists/s",
+                     "kernel": "attn_bwd_dkv_kernel<%d,2,%s>" % (hd, "true" if args.dropout > 0 else "false"),
+                     "launch_ms": round(f_dkv_ms, 3), "achieved": round(f_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "roofline_unit": "TFLOP/s", "frac": round(f_ach / PEAK_F32_MFMA_TFLOPS, 4)}
+        if rank == 0:
+            print(f"[bench] fp32 mode: {f_ms:.1f} ms/step", file=sys.stderr, flush=True)
 
     if rank == 0:
-        ksum = timer.summary()
         # dominant launch: the attention dK/dV backward (one rlt_list_attention_bwd_dkv call).
         #   fp32 mode  : one kernel, 4 MFMA products of 2*B*B*HD per (position, head) on the f32 MFMA
         #   bf16x3 mode: one fused kernel (S, dP, dV, dK) = 4 products, each executed as 3 bf16 MFMA products
@@ -229,12 +333,11 @@ def main():
         # 2500/3 = 833.3 TF/s (`executed_bf16_tflops` / 2500 is the same fraction).  DESIGN.md section 5.
         name = "attn_bwd_dkv"
         launches, ms = ksum.get(name, (0, float("nan")))
-        S_mean = sum(lengths) / len(lengths)                   # positions per launch, averaged over the buckets
-        unit_flops = 2.0 * B * B * hd * S_mean * heads_
+        drop_tag = "true" if args.dropout > 0 else "false"
         if precision == "fp32":
-            kern, products, mult, peak = "attn_bwd_dkv_kernel<%d,2,%s>" % (hd, "true" if args.dropout > 0 else "false"), 4, 1, PEAK_F32_MFMA_TFLOPS
+            kern, products, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 4, 1, PEAK_F32_MFMA_TFLOPS
         else:
-            kern, products, mult, peak = "attn3_bwd_dkv_kernel<%d,%s>" % (hd, "true" if args.dropout > 0 else "false"), 4, 3, PEAK_BF16_MFMA_TFLOPS
+            kern, products, mult, peak = f"attn3_bwd_dkv_kernel<{hd},{drop_tag}>", 4, 3, PEAK_BF16_MFMA_TFLOPS
         algorithmic = products * unit_flops / (ms * 1e-3) / 1e12 if launches else float("nan")
         achieved, executed = algorithmic, algorithmic * mult
         peak = round(peak / mult, 1)
@@ -242,20 +345,20 @@ def main():
         headline = args.model == "attncut" and not args.buckets
         step_flop = step_algorithmic_flops(args.model, B, S) if headline else None
         step_bytes = 16.0e6 * B * S / 300.0 if headline else None
-        # HBM traffic of that launch: PMC FETCH_SIZE/WRITE_SIZE collected in separate rocprofv3 --pmc passes of this
-        # same command (tools/pmc_traffic.py -> profiles/r01_s_pmc_traffic.json, gfx950 FETCH_SIZE x2 correction
-        # applied); only quoted for the exact workload and kernel it was measured on
-        traffic = None
-        step_traffic = None
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_s_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if (headline and args.dropout == 0 and B == 4096 and S == 300 and precision == "bf16x3"
-                    and all(kern.startswith(k) for k in pmc["dominant_launch"])):
-                traffic = pmc["traffic_bytes_per_launch"]
-                step_traffic = pmc.get("step_traffic_bytes")
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = step_traffic = traffic_source = None
+        for cand in PMC_TRAFFIC_FILES:
+            try:
+                with open(os.path.join(REPO, cand)) as f:
+                    pmc = json.load(f)
+                if (headline and args.dropout == 0 and B == 4096 and S == 300 and precision == "bf16x3"
+                        and all(kern.startswith(k) for k in pmc["dominant_launch"])):
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    step_traffic = pmc.get("step_traffic_bytes")
+                    traffic_source = cand + " (separate rocprofv3 --pmc passes of this command, committed; NOT measured by this run)"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+        sec = ms_per_step * 1e-3
         out = {
             "metric": "ranked-lists/sec (fwd+bwd) at len=300; F1@k vs CPU ref",
             "value": round(value, 2), "unit": "lists/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,28 +368,34 @@ def main():
             "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S}, "
                                    f"full train step incl. Adam and cut metrics", "global_batch": B * world,
                        "seq_len": S if not args.buckets else lengths, "parallelism": f"dp{world}"},
+            "collective": None if world == 1 else {
+                "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+                "per_step": f"one all-reduce(AVG) of the flat fp32 gradient bucket, {flat.numel * 4 / 1e6:.2f} MB"},
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "executed_bf16_tflops": round(executed, 2) if mult > 1 else None,
                          "mfma_products_per_fp32_product": mult,
                          "launch_ms": round(ms, 3), "launches_timed": launches,
+                         "timed_in": "separate loop after the timed region (HIP events on the launch stream)",
                          "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name},
                          "whole_step": None if step_flop is None else {
                              "algorithmic_tflop": round(step_flop / 1e12, 2),
-                             "tflops": round(step_flop / (ms_per_step * 1e-3) / 1e12, 1),
-                             "frac_of_f32_mfma_peak": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                             "tflops": round(step_flop / sec / 1e12, 1),
+                             "frac_of_f32_mfma_peak": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
                              "algorithmic_GB": round(step_bytes / 1e9, 1),
-                             "hbm_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                             "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 8.0e12, 4),
-                             # all kernels' FETCH_SIZE/WRITE_SIZE of one step (same PMC passes as `traffic`) / this run's time
-                             "measured_traffic_GB": None if step_traffic is None else round(step_traffic / 1e9, 1),
-                             "measured_hbm_GBps": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9, 1),
-                             "measured_frac_of_hbm_peak": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 8.0e12, 4)}},
-            "train_state": {"loss": round(float(loss.detach()), 6), "f1": round(float(f1), 6), "dcg": round(float(dcg), 6)},
+                             "hbm_GBps": round(step_bytes / sec / 1e9, 1),
+                             "frac_of_hbm_peak": round(step_bytes / sec / PEAK_HBM_BPS, 4),
+                             # all kernels' FETCH_SIZE/WRITE_SIZE of one step (same PMC file as `traffic`) / this run's time
+                             "pmc_file_traffic_GB": None if step_traffic is None else round(step_traffic / 1e9, 1),
+                             "pmc_file_hbm_GBps": None if step_traffic is None else round(step_traffic / sec / 1e9, 1),
+                             "pmc_file_frac_of_hbm_peak": None if step_traffic is None else round(step_traffic / sec / PEAK_HBM_BPS, 4)}},
+            "fp32_mode": fp32_mode,
+            "train_state": {"loss": round(loss_v, 6), "f1": round(f1_v, 6), "dcg": round(dcg_v, 6)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, args.cpu_sample_batch, 3)
+            out["cpu_baseline"] = cpu_baseline(S, args.cpu_sample_batch, args.cpu_loop_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

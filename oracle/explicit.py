@@ -71,13 +71,20 @@ def list_axis_attention(x, in_w, in_b, out_w, out_b, n_head):
     return ctx @ out_w.t() + out_b
 
 
-def encoder_layer(x, sd, prefix, n_head):
-    """Post-norm encoder layer (dropout 0) from a `TransformerEncoderLayer` state_dict."""
+def encoder_layer(x, sd, prefix, n_head, relu_gate=None):
+    """Post-norm encoder layer (dropout 0) from a `TransformerEncoderLayer` state_dict.
+
+    `relu_gate(z) -> 0/1 tensor` (tests only) replaces the ReLU's own branch decision `z > 0`: ReLU is discontinuous in
+    its derivative, so a unit whose pre-activation lies within rounding distance of zero may legitimately take either
+    branch in two implementations; a test that wants to bound everything ELSE passes the other implementation's
+    decisions for exactly those units (and counts them)."""
     g = lambda name: sd[prefix + name].to(x.dtype)
     att = list_axis_attention(x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"),
                               g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_head)
     x = layer_norm(x + att, g("norm1.weight"), g("norm1.bias"))
-    ff = torch.relu(x @ g("linear1.weight").t() + g("linear1.bias")) @ g("linear2.weight").t() + g("linear2.bias")
+    z = x @ g("linear1.weight").t() + g("linear1.bias")
+    hid = torch.relu(z) if relu_gate is None else z * relu_gate(z.detach())
+    ff = hid @ g("linear2.weight").t() + g("linear2.bias")
     return layer_norm(x + ff, g("norm2.weight"), g("norm2.bias"))
 
 

@@ -41,13 +41,21 @@ class KernelTimer:
 
 
 _SEED_COUNTER = [0]
+_SEED_STREAM = [0]
+
+
+def set_seed_stream(stream_id):
+    """Data-parallel runs: every rank has the same torch seed (identical initial weights) but must draw its own
+    dropout masks - the rank is mixed into the seed as a stream id."""
+    _SEED_STREAM[0] = int(stream_id)
 
 
 def next_seed():
-    """A fresh 32-bit dropout seed: a function of torch's seed and a call counter, so that
+    """A fresh 32-bit dropout seed: a function of torch's seed, the stream id (rank) and a call counter, so that
     torch.manual_seed(...) makes a training run reproducible."""
     _SEED_COUNTER[0] += 1
-    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0] * 0xD1B54A32D192ED03
+         + _SEED_STREAM[0] * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
     x ^= x >> 29
     return int((x * 0xBF58476D1CE4E5B9 >> 32) & 0xFFFFFFFF)
 
@@ -374,6 +382,9 @@ class BiLSTMLayerFn(Function):
         H4 = w_ih_f.shape[0]
         if H4 != 512 or w_hh_f.shape != (512, 128):
             raise RuntimeError("the HIP BiLSTM kernel is specialised for hidden_size=128 (as the reference hard-codes)")
+        if w_ih_f.shape[1] != I or w_ih_r.shape[1] != I or T != S * B:
+            raise RuntimeError(f"BiLSTM input has {I} features x {T} rows; the layer was built for "
+                               f"{w_ih_f.shape[1]} features and S*B = {S * B} rows")
         gates = _empty((T, 2 * H4), x)
         h = _empty((T, 256), x)
         c = _empty((T, 256), x)
