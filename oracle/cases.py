@@ -10,10 +10,10 @@ MT = ["mtcut_f1", "mtcut_dcg"]
 
 
 def _case(tag, model, kwargs, batch, seq_len, n_feat, seed, criteria, grad_crit,
-          gate_scale=None, w_r=0.5, w_c=0.5):
+          gate_scale=None, w_r=0.5, w_c=0.5, pe_scale=None, x_noise=0.0):
     return dict(tag=tag, model=model, kwargs=kwargs, batch=batch, seq_len=seq_len, n_feat=n_feat,
                 seed=seed, criteria=list(criteria), grad_crit=grad_crit, gate_scale=gate_scale,
-                w_r=w_r, w_c=w_c)
+                w_r=w_r, w_c=w_c, pe_scale=pe_scale, x_noise=x_noise)
 
 
 MODEL_CASES = [
@@ -24,12 +24,19 @@ MODEL_CASES = [
     _case("choopy_b5_s300", "Choopy", {}, 5, 300, 1, 111, SINGLE_CRITERIA, "choopy_f1"),
     _case("choopy_b32_s300", "Choopy", {}, 32, 300, 1, 112, ["choopy_f1"], "choopy_f1"),
     _case("choopy_b6_s40", "Choopy", {"seq_len": 40}, 6, 40, 1, 113, FEW, "choopy_f1"),
+    # many distinct cut positions per batch (small position encoding, unsorted list-specific scores): with the plain
+    # recipe every list of a Choopy batch cuts at the same position, which makes "k identical" weak evidence
+    _case("choopy_b24_s300_manyk", "Choopy", {}, 24, 300, 1, 118, ["choopy_f1", "div_js_f1_aug1"], "choopy_f1",
+          pe_scale=0.05, x_noise=2.0),
+    _case("choopy_b24_s300_closek", "Choopy", {}, 24, 300, 1, 120, ["choopy_f1"], "choopy_f1", pe_scale=0.05, x_noise=2.0),
     _case("mtattncut_t3_b5_s300", "MtAttnCut", {"num_tasks": 3}, 5, 300, 3, 122, MT, "mtcut_f1"),
     _case("mtattncut_t21_b5_s300", "MtAttnCut", {"num_tasks": 2.1}, 5, 300, 3, 120, MT, "mtcut_f1"),
     _case("mtattncut_t22_b5_s300", "MtAttnCut", {"num_tasks": 2.2}, 5, 300, 3, 121, MT, "mtcut_f1"),
     _case("mtattncut_t3_b8_s100", "MtAttnCut", {"num_tasks": 3}, 8, 100, 3, 127, MT, "mtcut_dcg"),
+    _case("mtattncut_t3_b8_s200", "MtAttnCut", {"num_tasks": 3}, 8, 200, 3, 134, MT, "mtcut_f1"),
     _case("mtchoopy_t3_b5_s300", "MtChoopy", {"num_tasks": 3}, 5, 300, 1, 131, MT, "mtcut_f1"),
     _case("mtchoopy_t21_b4_s300", "MtChoopy", {"num_tasks": 2.1}, 4, 300, 1, 132, MT, "mtcut_f1"),
+    _case("mtchoopy_t3_b12_s300_manyk", "MtChoopy", {"num_tasks": 3}, 12, 300, 1, 133, MT, "mtcut_f1", pe_scale=0.05, x_noise=2.0),
     _case("mmoecut_e3_t3_b5_s300", "MMOECut", {"num_experts": 3, "num_tasks": 3}, 5, 300, 3, 141, MT,
           "mtcut_f1", w_r=0.4, w_c=0.6),
     _case("mmoecut_e4_t21_b5_s300", "MMOECut", {"num_experts": 4, "num_tasks": 2.1}, 5, 300, 3, 142, MT,

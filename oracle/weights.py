@@ -11,11 +11,12 @@ import numpy as np
 import torch
 
 
-def fill_state_dict(model: torch.nn.Module, seed: int, gate_scale: float = None) -> None:
+def fill_state_dict(model: torch.nn.Module, seed: int, gate_scale: float = None, pe_scale: float = None) -> None:
     """Overwrite every entry of `model.state_dict()` in key order.
 
     * LayerNorm weights ~ 1 + 0.1*U(-1,1); all biases ~ 0.1*U(-1,1)
-    * `position_encoding` ~ N(0,1) (as the reference initialises it)
+    * `position_encoding` ~ N(0,1) (as the reference initialises it) * pe_scale (default 1; a small pe_scale lets the
+      score column, the only list-dependent input of Choopy, decide the cut position: cases with many distinct k)
     * `w_gates.*` ~ N(0,1)*gate_scale (reference: gate_scale=1 => near one-hot gates;
       tests also use 1/sqrt(fan_in) so that the gate softmax is exercised away from saturation)
     * every other matrix ~ U(-1,1)/sqrt(fan_in)
@@ -25,7 +26,7 @@ def fill_state_dict(model: torch.nn.Module, seed: int, gate_scale: float = None)
     for key, ten in model.state_dict().items():
         shape = tuple(ten.shape)
         if key.endswith("position_encoding"):
-            val = rs.standard_normal(shape)
+            val = rs.standard_normal(shape) * (1.0 if pe_scale is None else pe_scale)
         elif ".w_gates." in "." + key or key.startswith("w_gates.") or key == "w_gates":
             scale = gate_scale if gate_scale is not None else 1.0 / math.sqrt(shape[0])
             val = rs.standard_normal(shape) * scale
@@ -40,11 +41,13 @@ def fill_state_dict(model: torch.nn.Module, seed: int, gate_scale: float = None)
     model.load_state_dict(new)
 
 
-def synthetic_lists(batch: int, seq_len: int, n_features: int, seed: int):
+def synthetic_lists(batch: int, seq_len: int, n_features: int, seed: int, noise: float = 0.0):
     """robust04-shaped synthetic ranked lists.
 
     scores: per list, descending sort of N(3, 2.5^2); extra feature columns U(0,1);
     labels: Bernoulli(0.55*exp(-j/45)+0.02) at rank j, at least one positive per list.
+    noise > 0 adds N(0, noise^2) to every score AFTER the sort (drawn last, so noise = 0 reproduces the plain lists):
+    unsorted, list-specific inputs for the cases that want many distinct cut positions.
     Returns X (B,S,F) float32, y (B,S) float32 in {0,1}.
     """
     rs = np.random.RandomState(seed)
@@ -58,4 +61,6 @@ def synthetic_lists(batch: int, seq_len: int, n_features: int, seed: int):
     for i in range(batch):
         if y[i].sum() == 0:
             y[i, rs.randint(0, min(10, seq_len))] = 1.0
+    if noise:
+        x[:, :, 0] += (rs.standard_normal((batch, seq_len)) * noise).astype(np.float32)
     return torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(y)

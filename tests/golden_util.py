@@ -31,8 +31,8 @@ def build(models_mod, case, device="cpu"):
     """Instantiate case['model'] from `models_mod` (oracle.models or the HIP package's models)
     with the deterministic weights of the case; returns (model, x, y)."""
     model = getattr(models_mod, case["model"])(dropout=0.0, **case["kwargs"])
-    fill_state_dict(model, case["seed"], gate_scale=case["gate_scale"])
-    x, y = synthetic_lists(case["batch"], case["seq_len"], case["n_feat"], case["seed"] + 1)
+    fill_state_dict(model, case["seed"], gate_scale=case["gate_scale"], pe_scale=case.get("pe_scale"))
+    x, y = synthetic_lists(case["batch"], case["seq_len"], case["n_feat"], case["seed"] + 1, noise=case.get("x_noise", 0.0))
     model = model.to(device)
     return model, x.to(device), y.to(device)
 

@@ -24,7 +24,10 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
                 BiLSTM at B=4096, LayerNorm at 1,228,800 rows
     full_size_kernels  BiLSTM 4096x300 and encoder layers 4096x300 (E256/H4), 8192x300 (E128/H8) at full size against
                 list-/position-subset references with sparse upstream gradients
-    models      all 18 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
+    flip_aligned_grads  whole-model gradients vs the oracle with knife-edge ReLU units following the device's branch
+                (counted): per-parameter rel-L2 1e-4 (fp32 mode) / 1e-3 (bf16x3)
+    trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
+    models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
 Tolerances are written next to each case in tools/gpu_probe.py; BASELINE.json asks for 1e-4.
 """
@@ -50,7 +53,7 @@ def probe():
 
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
-                  "scale_models", "scale_ops", "full_size_kernels"]
+                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
 
 

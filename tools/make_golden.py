@@ -73,8 +73,8 @@ def run_model_case(case):
     tag, batch, seq_len = case["tag"], case["batch"], case["seq_len"]
     cls = getattr(ref_models, case["model"])
     model = cls(dropout=0.0, **case["kwargs"])
-    fill_state_dict(model, case["seed"], gate_scale=case["gate_scale"])
-    x, y = synthetic_lists(batch, seq_len, case["n_feat"], case["seed"] + 1)
+    fill_state_dict(model, case["seed"], gate_scale=case["gate_scale"], pe_scale=case.get("pe_scale"))
+    x, y = synthetic_lists(batch, seq_len, case["n_feat"], case["seed"] + 1, noise=case.get("x_noise", 0.0))
     gs = case["gate_scale"]
     rec = {"x": x.numpy(), "y": y.numpy(), "seed": np.int64(case["seed"]),
            "gate_scale": np.float64(-1.0 if gs is None else gs)}
