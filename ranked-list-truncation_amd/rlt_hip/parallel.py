@@ -100,3 +100,11 @@ def shard_batch(x, y, rank, world):
         raise ValueError(f"global batch {n} is not divisible by world size {world}")
     per = n // world
     return x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+
+
+def shard_bounds(n, rank, world):
+    """[lo, hi) of rank's contiguous shard of an n-list batch when n need not divide: the first n % world ranks take one
+    list more; a rank may get an empty shard (n < world).  The shards of all ranks partition range(n) exactly."""
+    per, extra = divmod(n, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)

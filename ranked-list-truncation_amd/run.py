@@ -9,13 +9,17 @@ state_dict checkpoint on best test F1, run.py:153-232) and the same log lines.  
     pinned-memory loader in dataloader/ (the reference's pickle layout);
   * F1/DCG are evaluated on the device (no (B,S) round trip per step); one host sync per step for
     the three logged scalars;
-  * launched under torch.distributed.run it is data-parallel: every rank takes its shard of each batch,
-    one RCCL all-reduce of the flat gradient bucket per step (rlt_hip/parallel.py);
-  * not carried over: tensorboard, matplotlib plots, the hyper-parameter random search, and the
-    out-of-scope models (bicut / moecut / mtple).
+  * launched under torch.distributed.run it is data-parallel: all ranks draw the same batch permutation (one seed
+    broadcast from rank 0), every rank takes its contiguous shard of each batch (an exact partition, ragged tails
+    included: shards are weighted by their list counts in the loss, the gradient and the logged means), one RCCL
+    all-reduce of the flat gradient bucket per step (rlt_hip/parallel.py);
+  * the scalars the reference sends to tensorboardX (run.py:146,154-156,196-198) go, under the same tags, to
+    `<tensorboard-dir>/scalars.jsonl` (and to a SummaryWriter when tensorboard is installed);
+  * not carried over: matplotlib plots and the hyper-parameter random search.
 """
 import argparse
 import configparser
+import json
 import logging
 import os
 import time
@@ -26,11 +30,42 @@ import torch.distributed as dist
 HERE = os.path.dirname(os.path.abspath(__file__))
 logging.basicConfig(level=logging.INFO)
 
-from dataloader import at_dataloader, cp_dataloader, write_synthetic_robust04  # noqa: E402
+from dataloader import at_dataloader, cp_dataloader, mc_dataloader, write_synthetic_robust04  # noqa: E402
 from models import AttnCut, BiCut, Choopy, MMOECut, MOECut, MtAttnCut, MtChoopy, PLECut  # noqa: E402
 from utils import losses  # noqa: E402
 from utils.metrics import Metric  # noqa: E402
-from rlt_hip.parallel import FlatModel, FusedAdam, shard_batch  # noqa: E402
+from rlt_hip import ops  # noqa: E402
+from rlt_hip.parallel import FlatModel, FusedAdam, shard_bounds  # noqa: E402
+
+
+class ScalarLog:
+    """add_scalar(tag, value, step) of the reference's tensorboardX writer (run.py:111): one JSON line per scalar in
+    <dir>/scalars.jsonl, mirrored into torch.utils.tensorboard when that package is importable."""
+
+    def __init__(self, log_dir):
+        self.file = self.tb = None
+        if not log_dir:
+            return
+        os.makedirs(log_dir, exist_ok=True)
+        self.file = open(os.path.join(log_dir, "scalars.jsonl"), "w")
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.tb = SummaryWriter(log_dir=log_dir)
+        except Exception:                      # tensorboard is not part of this image
+            self.tb = None
+
+    def add_scalar(self, tag, value, step):
+        if self.file is not None:
+            self.file.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+        if self.tb is not None:
+            self.tb.add_scalar(tag, value, step)
+
+    def close(self):
+        if self.file is not None:
+            self.file.close()
+            self.file = None
+        if self.tb is not None:
+            self.tb.close()
 
 
 class Trainer:
@@ -49,11 +84,23 @@ class Trainer:
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(self.device)
 
-        feat = 3 if args.retrieve_data == 'robust04' else 25
         name = self.model_name
-        loader = cp_dataloader if name in ('choopy', 'mtchoopy') else at_dataloader
-        self.train_loader, self.test_loader, _ = loader(args.retrieve_data, args.dataset_name, args.batch_size,
-                                                        device=self.device, base=args.dataset_base, seed=args.seed)
+        if name in ('choopy', 'mtchoopy'):
+            loader = cp_dataloader
+        elif name in ('mmoecut', 'moecut', 'mtple') and args.retrieve_data != 'robust04':
+            loader = mc_dataloader                                             # run.py:87-88: MQ2007 multi-task statistics
+        else:
+            loader = at_dataloader
+        self.train_loader, self.test_loader, data = loader(args.retrieve_data, args.dataset_name, args.batch_size,
+                                                           device=self.device, base=args.dataset_base, seed=args.seed)
+        # the reference hard-codes 3 / 25 / 47 input features and 300 / 40 positions (run.py:34,60,70,86); here both
+        # come from the files, and a mismatch with the reference's numbers is reported instead of mis-striding the LSTM
+        feat = data.n_features
+        if len(data.lengths) == 1:
+            self.seq_len = data.lengths[0]
+        elif name not in ('bicut', 'attncut', 'mtattncut'):
+            raise ValueError(f"{name} is built for ONE list length; the data holds lengths {data.lengths} "
+                             "(only the BiLSTM models bicut / attncut / mtattncut take length-bucketed batches)")
         if name == 'bicut':                                                    # run.py:59-64
             self.model = BiCut(input_size=feat, dropout=args.dropout)
             self.criterion = losses.BiCutLoss(metric=args.criterion)
@@ -92,40 +139,54 @@ class Trainer:
         self.flat = FlatModel(self.model)
         self.flat.broadcast_params()
         self.optimizer = FusedAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)   # run.py:104
+        ops.set_seed_stream(self.rank)          # same torch seed on every rank, different dropout masks
+        self.writer = ScalarLog(getattr(args, "tensorboard_dir", None) if self.rank == 0 else None)   # run.py:111
+        self.history = []                       # per epoch: train / test (loss, f1, dcg) means
 
     # ------------------------------------------------------------------------------------------
-    def _shard(self, X, y):
-        if self.world == 1:
-            return X, y
-        n = (X.shape[0] // self.world) * self.world          # ragged tail lists are dropped per step
-        return shard_batch(X[:n], y[:n], self.rank, self.world)
-
     def _step(self, X, y, train):
-        X, y = self._shard(X, y)
-        output = self.model(X)
-        loss = self.criterion(output, y)
+        """One batch.  Data-parallel: every rank holds the SAME batch (shared permutation) and works on its contiguous
+        shard; shards partition the batch exactly (a ragged tail gives unequal, possibly empty shards), so loss,
+        gradient and logged means are weighted by the shards' list counts - what comes out is the batch mean of the
+        shard-wise reference computation."""
+        n_all = X.shape[0]
+        lo, hi = shard_bounds(n_all, self.rank, self.world)
+        n_own = hi - lo
+        stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+        if n_own > 0:
+            Xs, ys = (X, y) if self.world == 1 else (X[lo:hi], y[lo:hi])
+            output = self.model(Xs)
+            loss = self.criterion(output, ys)
+            if train:
+                # AVG all-reduce of sum_r (n_r * world / n) * grad_r / world = sum_r (n_r / n) * grad_r
+                (loss if n_own * self.world == n_all else loss * (n_own * self.world / n_all)).backward()
+            cut = output[-1] if self.multi_task else output    # run.py:131-142 (Metric.evaluate applies BiCut's rule to (B,S,2))
+            _k, f1, dcg = Metric.evaluate(cut, ys)
+            stats = torch.stack([loss.detach().double(), f1, dcg, torch.ones((), dtype=torch.float64, device=self.device)]) * n_own
         if train:
-            loss.backward()
-            self.flat.all_reduce_grads()
+            self.flat.all_reduce_grads()                        # an empty shard contributes its zeroed bucket
             self.optimizer.step()
-        cut = output[-1] if self.multi_task else output        # run.py:131-142 (Metric.evaluate applies BiCut's rule to (B,S,2))
-        _k, f1, dcg = Metric.evaluate(cut, y)
-        stats = torch.stack([loss.detach().double(), f1, dcg])
         if self.world > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.AVG)
-        return stats.tolist()                                   # the step's only host sync
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        vals = stats.tolist()                                   # the step's only host sync
+        return [v / vals[3] for v in vals[:3]]
 
     def train_epoch(self, epoch):
         start = time.time()
-        tot, step = [0.0, 0.0, 0.0], 0
+        tot, step, num_itr = [0.0, 0.0, 0.0], 0, len(self.train_loader)
         logging.info('-' * 100)
         for X, y in self.train_loader:
             self.model.train()
             self.optimizer.zero_grad()
             vals = self._step(X, y, True)
+            self.writer.add_scalar('train/loss_step', vals[0], step + num_itr * epoch)   # run.py:146
             tot = [a + b for a, b in zip(tot, vals)]
             step += 1
         loss, f1, dcg = [v / step for v in tot]                 # unweighted over steps, run.py:153
+        self.writer.add_scalar('train/loss_epoch', loss, epoch)
+        self.writer.add_scalar('train/F1_epoch', f1, epoch)
+        self.writer.add_scalar('train/DCG_epoch', dcg, epoch)
+        self.history.append({"epoch": epoch, "train": (loss, f1, dcg)})
         if self.rank == 0:
             logging.info('\nEpoch: {} | Epoch Time: {:.2f} s'.format(epoch, time.time() - start))
             logging.info('\tTrain: loss = {} | f1 = {:.6f} | dcg = {:.6f}\n'.format(loss, f1, dcg))
@@ -140,12 +201,17 @@ class Trainer:
             tot = [a + b for a, b in zip(tot, vals)]
             step += 1
         loss, f1, dcg = [v / step for v in tot]                 # run.py:195
+        self.writer.add_scalar('test/loss_epoch', loss, epoch)
+        self.writer.add_scalar('test/F1_epoch', f1, epoch)
+        self.writer.add_scalar('test/DCG_epoch', dcg, epoch)
+        if self.history and self.history[-1]["epoch"] == epoch:
+            self.history[-1]["test"] = (loss, f1, dcg)
         self.f1_record.append(f1)
         self.dcg_record.append(dcg)
         if self.rank == 0:
             logging.info('\tTest: loss = {} | f1 = {:.6f} | dcg = {:.6f}\n'.format(loss, f1, dcg))
         if f1 > self.best_test_f1:                              # run.py:203-206
-            self.best_test_f1 = f1
+            self.best_test_f1, self.best_epoch = f1, epoch
             if self.model_persist and self.rank == 0:
                 self.save_model()
         if dcg > self.best_test_dcg:
@@ -172,6 +238,8 @@ class Trainer:
         top = sorted(self.f1_record, reverse=True)[:5]
         topd = sorted(self.dcg_record, reverse=True)[:5]
         best5_f1, best5_dcg = sum(top) / 5, sum(topd) / 5       # run.py:229-230 divides by 5 regardless
+        self.best5_f1, self.best5_dcg = best5_f1, best5_dcg
+        self.writer.close()
         if self.rank == 0:
             logging.info('the best metric of this model: f1: {} | dcg: {}'.format(self.best_test_f1, self.best_test_dcg))
             logging.info('the best-5 metric of this model: f1: {} | dcg: {}'.format(best5_f1, best5_dcg))
@@ -204,6 +272,8 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help="write a robust04-shaped synthetic set into --dataset-base first")
     p.add_argument('--use-conf', type=int, default=1, help="override lr/batch/dropout/wd/task weights from hyper_parameter_<dataset>.conf")
     p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--tensorboard-dir', type=str, default=os.path.join(HERE, 'Tensorboard_summary', 'Truncation'),
+                   help="scalars.jsonl (+ tensorboard event files when tensorboard is installed); '' disables")
     return p
 
 
@@ -211,11 +281,11 @@ def apply_conf(args):
     """run.py:338-347: the .conf section of the model overrides the CLI values."""
     conf = configparser.ConfigParser()
     path = os.path.join(HERE, 'hyper_parameter_{}.conf'.format(args.dataset_name))
-    if not conf.read(path):
-        return args
     sec = '{}_conf'.format(args.model_name)
-    if not conf.has_section(sec):
-        return args
+    if not conf.read(path) or not conf.has_section(sec):
+        # the reference dies with configparser.NoSectionError here (run.py:340); running on silently with the CLI
+        # defaults would train a different model than the user asked for
+        raise configparser.NoSectionError(f"{sec} (in {path}; pass --use-conf 0 to train with the command-line values)")
     args.lr = conf.getfloat(sec, 'lr')
     if args.retrieve_data == 'robust04':
         args.batch_size = conf.getint(sec, 'batch_size')

@@ -44,3 +44,47 @@ def test_batches_cover_every_list_once(tmp_path):
     for x, y in test:
         assert x.shape[0] == 3 and y.shape == (3, 300)
         assert set(np.unique(y.numpy())) <= {0.0, 1.0}
+
+
+def test_length_buckets_round_robin(tmp_path):
+    """BASELINE configs[4]: lists of 100 / 200 / 300 documents -> homogeneous batches, buckets served round-robin,
+    every list exactly once per epoch (SURVEY.md 8f N1 'length bucketing')."""
+    from dataloader import at_dataloader
+    from dataloader.synth import write_synthetic_robust04
+    write_synthetic_robust04(str(tmp_path), "robust04", "drmm_tks", n_train=20, n_test=6, seed=5, lengths=(100, 200, 300))
+    train, test, data = at_dataloader("robust04", "drmm_tks", batch_size=3, base=str(tmp_path), seed=2)
+    assert data.lengths == [100, 200, 300] and data.n_features == 3
+    sizes = {s: data.buckets["train"][s][0].shape[0] for s in data.lengths}
+    assert sizes == {100: 7, 200: 7, 300: 6}
+    seq = [(x.shape[1], x.shape[0]) for x, _ in train]
+    assert len(seq) == len(train) == 3 + 3 + 2
+    assert [s for s, _ in seq[:6]] == [100, 200, 300, 100, 200, 300]            # round-robin over the buckets
+    for s in data.lengths:
+        got = torch.cat([x for x, _ in train if x.shape[1] == s])
+        want = data.buckets["train"][s][0]
+        assert sorted(float(v) for v in got[:, :, 0].sum(1)) == sorted(float(v) for v in want[:, :, 0].sum(1))
+    for x, y in test:
+        assert y.shape == (x.shape[0], x.shape[1])
+
+
+def test_generic_statistics_width_and_mtcut_dir(tmp_path):
+    """mtcut_dataloader.py:48: column_stack(score, statistics) for any statistics width (MQ2007: 46 -> 47 features)."""
+    from dataloader import mc_dataloader
+    from dataloader.synth import write_synthetic_robust04
+    write_synthetic_robust04(str(tmp_path), "mq2007", "bm25", n_train=5, n_test=2, seq_len=40, seed=9, stats_width=46,
+                             stats_dir="mtcut")
+    train, _test, data = mc_dataloader("mq2007", "bm25", batch_size=4, base=str(tmp_path), seed=0)
+    assert data.n_features == 47 and data.lengths == [40]
+    assert [tuple(x.shape) for x, _ in train] == [(4, 40, 47), (1, 40, 47)]
+
+
+def test_shard_bounds_partition():
+    from rlt_hip.parallel import shard_bounds
+    for n in (0, 1, 2, 7, 8, 63, 64):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_bounds(n, r, world)
+                assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+                cover.extend(range(lo, hi))
+            assert cover == list(range(n))

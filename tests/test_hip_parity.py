@@ -26,6 +26,8 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
                 list-/position-subset references with sparse upstream gradients
     flip_aligned_grads  whole-model gradients vs the oracle with knife-edge ReLU units following the device's branch
                 (counted): per-parameter rel-L2 1e-4 (fp32 mode) / 1e-3 (bf16x3)
+    trainer_bookkeeping  run.py's Trainer vs the same loop on the oracle: per-epoch means, best / best-5, checkpointed
+                epoch and weights, scalar log
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
     models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
@@ -53,7 +55,7 @@ def probe():
 
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
-                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory"]
+                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
 
 

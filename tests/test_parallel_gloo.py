@@ -110,3 +110,53 @@ def test_shard_batch_rejects_ragged_split():
     from rlt_hip.parallel import shard_batch
     with pytest.raises(ValueError):
         shard_batch(torch.zeros(5, 3, 1), torch.zeros(5, 3), 0, 2)
+
+
+def _loader_worker(rank, port, data_dir, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "ranked-list-truncation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from dataloader import at_dataloader
+    from rlt_hip.parallel import shard_bounds
+    torch.manual_seed(1000 + rank)            # ranks do NOT share torch's default generator state
+    train, test, _ = at_dataloader("robust04", "drmm_tks", batch_size=4, base=data_dir, seed=None)
+    rec = {}
+    for name, loader in (("train", train), ("test", test)):
+        keys, sizes = [], []
+        for x, _y in loader:
+            lo, hi = shard_bounds(x.shape[0], rank, WORLD)
+            keys.extend(float(v) for v in x[lo:hi, :, 0].sum(1))
+            sizes.append((x.shape[0], hi - lo))
+        rec[name + "_keys"] = np.array(keys)
+        rec[name + "_sizes"] = np.array(sizes)
+    np.savez(os.path.join(out_dir, f"shards{rank}.npz"), **rec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_partition_every_batch(tmp_path):
+    """run.py under torch.distributed without --seed: both ranks must iterate the SAME permutation (seed broadcast from
+    rank 0), so that the union of their shards is the dataset - no list twice, none missing, ragged tail included
+    (each rank used to draw its own permutation)."""
+    from dataloader import RankData
+    from dataloader.synth import write_synthetic_robust04
+    data_dir = tmp_path / "data"
+    write_synthetic_robust04(str(data_dir), "robust04", "drmm_tks", n_train=11, n_test=5, seq_len=40, seed=3)
+    port = _free_port()
+    mp.spawn(_loader_worker, args=(port, str(data_dir), str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = np.load(tmp_path / "shards0.npz"), np.load(tmp_path / "shards1.npz")
+    rd = RankData("robust04", "drmm_tks", True, str(data_dir))
+    for name, full in (("train", rd.getX_train()), ("test", rd.getX_test())):
+        want = sorted(float(v) for v in full[:, :, 0].sum(1))
+        got = sorted(np.concatenate([r0[name + "_keys"], r1[name + "_keys"]]).tolist())
+        assert got == want, name
+        s0, s1 = r0[name + "_sizes"], r1[name + "_sizes"]
+        np.testing.assert_array_equal(s0[:, 0], s1[:, 0])                 # same batch sizes in the same order
+        np.testing.assert_array_equal(s0[:, 1] + s1[:, 1], s0[:, 0])      # the two shards make up every batch
+    assert (r0["train_sizes"][-1] == [3, 2]).all() and (r1["train_sizes"][-1] == [3, 1]).all()   # ragged tail 11 = 4+4+3
+    assert (r0["test_sizes"][-1] == [1, 1]).all() and (r1["test_sizes"][-1] == [1, 0]).all()     # 5 = 4+1: rank 1 gets an empty shard

@@ -415,7 +415,8 @@ def optimizer_and_trainer():
                             ("choopy", []), ("mtattncut", [])):
             argv = ["--model-name", name, "--dataset-base", tmp, "--epochs", "2", "--use-conf", "0", "--batch-size", "8",
                     "--criterion", "f1", "--dropout", "0.1", "--lr", "1e-3", "--weight-decay", "0", "--seed", "3",
-                    "--model-persist", "1", "--save-path", os.path.join(tmp, "ckpt")] + extra
+                    "--model-persist", "1", "--save-path", os.path.join(tmp, "ckpt"),
+                    "--tensorboard-dir", os.path.join(tmp, "tb")] + extra
             f1, dcg = hip_run.main(argv)
             report(f"Trainer {name}: best test F1 in [0,1]", 0.0 if 0.0 <= f1 <= 1.0 and math.isfinite(dcg) else 1.0, 0)
             sd = torch.load(os.path.join(tmp, "ckpt", f"{name}.pkl"))
@@ -1195,6 +1196,103 @@ def _fresh_params(om, cls, kw, seed):
     m = getattr(om, cls)(dropout=0.0, **kw)
     fill_state_dict(m, seed)
     return [q.detach() for q in m.parameters()]
+
+
+
+@section
+def trainer_bookkeeping():
+    """run.py's Trainer against the same loop written with the CPU oracle (model, criterion, torch.optim.Adam, numpy
+    metrics) on the same files, the same loader seed and the same initial weights: per-epoch train / test means
+    (unweighted over batches, run.py:153,195), best and best-5 test F1 / DCG (best-5 divides by 5 whatever the number
+    of epochs, run.py:229-230), the epoch whose weights are checkpointed (run.py:203-205), and the scalar log."""
+    import json
+    import tempfile
+    import run as hip_run
+    from dataloader import BatchLoader, RankData, write_synthetic_robust04
+    from oracle import losses as ol, metrics as omet, models as om
+    EPOCHS, BS, LR, WD, SEED = 7, 8, 1e-4, 0.0025, 3
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=22, n_test=20, seq_len=300, seed=5)
+        for name in ("attncut", "mtattncut"):
+            tb, ck = os.path.join(tmp, "tb_" + name), os.path.join(tmp, "ck_" + name)
+            argv = ["--model-name", name, "--dataset-base", tmp, "--epochs", str(EPOCHS), "--use-conf", "0", "--batch-size", str(BS),
+                    "--criterion", "f1", "--dropout", "0.0", "--lr", str(LR), "--weight-decay", str(WD), "--seed", str(SEED),
+                    "--model-persist", "1", "--save-path", ck, "--tensorboard-dir", tb]
+            args = hip_run.build_parser().parse_args(argv)
+            args.model_path = os.path.join(ck, name + ".pkl")
+            torch.manual_seed(SEED)
+            trainer = hip_run.Trainer(args)
+            init = {k: v.detach().clone().cpu() for k, v in trainer.model.state_dict().items()}
+            trainer.run()
+            # ---- the same loop on the oracle
+            if name == "attncut":
+                ref, crit = om.AttnCut(input_size=3, dropout=0.0), ol.DivLoss(metric="f1", div_type="js", augmented=True)
+            else:
+                ref = om.MtAttnCut(input_size=3, num_tasks=3, dropout=0.0)
+                crit = ol.MtCutLoss(metric="f1", rerank_weight=args.rerank_weight, classi_weight=args.class_weight, num_tasks=3)
+            ref.load_state_dict(init)
+            opt = torch.optim.Adam(ref.parameters(), lr=LR, weight_decay=WD)
+            rd = RankData("robust04", "drmm_tks", True, tmp)
+            tr = BatchLoader([(rd.getX_train(), rd.gety_train())], BS, True, None, SEED)
+            te = BatchLoader([(rd.getX_test(), rd.gety_test())], BS, True, None, SEED + 1)
+
+            def evaluate(out, y):
+                p = (out[-1] if isinstance(out, (list, tuple)) else out).detach().squeeze(2).numpy()
+                k = omet.cut_positions(p)
+                return omet.Metric.f1(y.numpy(), k), omet.Metric.dcg(y.numpy(), k)
+
+            hist, f1_rec, dcg_rec, best, best_epoch, best_sd = [], [], [], -float("inf"), None, None
+            for epoch in range(EPOCHS):
+                tot, n = np.zeros(3), 0
+                ref.train()
+                for x, y in tr:
+                    opt.zero_grad()
+                    out = ref(x)
+                    loss = crit(out, y)
+                    loss.backward()
+                    opt.step()
+                    tot += np.array([loss.item(), *evaluate(out, y)])
+                    n += 1
+                row = {"train": tot / n}
+                tot, n = np.zeros(3), 0
+                ref.eval()
+                with torch.no_grad():
+                    for x, y in te:
+                        out = ref(x)
+                        tot += np.array([crit(out, y).item(), *evaluate(out, y)])
+                        n += 1
+                row["test"] = tot / n
+                hist.append(row)
+                f1_rec.append(row["test"][1])
+                dcg_rec.append(row["test"][2])
+                if row["test"][1] > best:
+                    best, best_epoch = row["test"][1], epoch
+                    best_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+            for e in range(EPOCHS):
+                for split in ("train", "test"):
+                    got, want = np.array(trainer.history[e][split]), hist[e][split]
+                    report(f"Trainer {name} epoch {e} {split} loss/F1/DCG means", float(np.abs(got - want).max() / max(1.0, np.abs(want).max())), 1e-4)
+            report(f"Trainer {name} best test F1", abs(trainer.best_test_f1 - best), 1e-4)
+            report(f"Trainer {name} best test DCG", abs(trainer.best_test_dcg - max(dcg_rec)), 1e-4 * max(1.0, abs(max(dcg_rec))))
+            report(f"Trainer {name} best-5 F1 (sum of top 5 / 5)", abs(trainer.best5_f1 - sum(sorted(f1_rec, reverse=True)[:5]) / 5), 1e-4)
+            report(f"Trainer {name} best-5 DCG", abs(trainer.best5_dcg - sum(sorted(dcg_rec, reverse=True)[:5]) / 5), 1e-4 * max(1.0, abs(max(dcg_rec))))
+            report(f"Trainer {name} checkpointed epoch", abs(trainer.best_epoch - best_epoch), 0)
+            sd = torch.load(os.path.join(ck, name + ".pkl"))
+            chk = type(ref)(**({"input_size": 3, "dropout": 0.0} if name == "attncut" else {"input_size": 3, "num_tasks": 3, "dropout": 0.0}))
+            chk.load_state_dict(sd)                          # loads into the reference-shaped module
+            num = sum(float((sd[k] - best_sd[k]).double().pow(2).sum()) for k in sd)
+            den = sum(float((best_sd[k] - init[k]).double().pow(2).sum()) for k in sd)
+            report(f"Trainer {name} checkpoint vs oracle weights at that epoch (relative to the path from init)", math.sqrt(num / den), 0.1)
+            # scalars under the reference's tags
+            rows = [json.loads(line) for line in open(os.path.join(tb, "scalars.jsonl"))]
+            tags = {}
+            for r in rows:
+                tags.setdefault(r["tag"], []).append(r)
+            steps_per_epoch = len(tr)
+            report(f"Trainer {name} scalar tags", 0.0 if set(tags) == {"train/loss_step", "train/loss_epoch", "train/F1_epoch", "train/DCG_epoch",
+                                                                       "test/loss_epoch", "test/F1_epoch", "test/DCG_epoch"} else 1.0, 0)
+            report(f"Trainer {name} train/loss_step count and steps", 0.0 if [r["step"] for r in tags["train/loss_step"]] == list(range(EPOCHS * steps_per_epoch)) else 1.0, 0)
+            report(f"Trainer {name} test/F1_epoch scalars", float(np.abs(np.array([r["value"] for r in tags["test/F1_epoch"]]) - np.array([h["test"][1] for h in trainer.history])).max()), 1e-12)
 
 
 if __name__ == "__main__":
