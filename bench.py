@@ -241,12 +241,10 @@ def main():
         model.train()
         opt.zero_grad()
         out = model(x)
-        loss = crit(out, y)
+        loss, _k, f1, dcg = Metric.step(crit, out, y)          # loss + cut metrics in one kernel pass, on device
         loss.backward()
         flat.all_reduce_grads()
         opt.step()
-        cut = out[-1] if isinstance(out, (list, tuple)) else out
-        k, f1, dcg = Metric.evaluate(cut, y)                   # stays on device
         return loss, f1, dcg
 
     def fence():

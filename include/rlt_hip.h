@@ -72,10 +72,27 @@ const char* rlt_error_string(int code);
 int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, int B, int S,
                     int metric, int kind, float tau,
                     float* loss_per_list, float* loss_out, float* dp, void* stream);
+/* the same with the `penalty` argument of Metric_for_Loss.dcg (utils/metrics.py:94): the DCG gain of a non-relevant
+ * document is penalty / log2(j+2); rlt_reward_loss is this call with the reference's default -1.  Ignored for F1. */
+int rlt_reward_loss_ex(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                       int metric, float penalty, int kind, float tau,
+                       float* loss_per_list, float* loss_out, float* dp, void* stream);
 /* reward matrix r (B,S) and its distribution q = softmax(r/tau) (either may be NULL):
  * the B*S python loop of utils/losses.py:217-228 on its own (tests, plots). */
 int rlt_reward_matrix(const float* labels, const float* dcg_coef, int B, int S, int metric, float tau,
                       float* r_out, float* q_out, void* stream);
+int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int S, int metric, float penalty, float tau,
+                         float* r_out, float* q_out, void* stream);
+/* Training-step form (run.py:126 + :141-145 in ONE pass over p and labels): everything rlt_reward_loss_ex produces, plus
+ * the cut metrics of rlt_cut_metrics_ex on the same rows while they are in LDS - k_out (B) int32 = argmax_j p + 1 (first
+ * maximum), f1_out / dcg_out (B) float64 (DCG with `metric_penalty`, utils/metrics.py:27), sums[0..1] = their batch sums.
+ * loss_out = sum(loss_per_list)/B from a float64 sum.  All outputs required except dp.  Two launches: the pass (a grid
+ * sized to the chip striding over groups of 4 lists) and a one-workgroup fixed-order reduction.
+ * Algorithmic bytes per list: read p, labels 8S, write dp 4S + 24 B of results (3.6 KB at S = 300). */
+int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                     int metric, float penalty, int kind, float tau, double metric_penalty,
+                     float* loss_per_list, float* loss_out, float* dp,
+                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
 
 /* ------------------------------------------------------------------ multi-task terms (L7-L8)
  * utils/losses.py:99-141 (RerankLoss) and nn.BCELoss of :177,:187 (MtCutLoss).
@@ -107,6 +124,9 @@ int rlt_weighted_sum(const float* const* x, const float* w, int n, float* out, v
  */
 int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
+/* the same with Metric.dcg's `penalty` argument (utils/metrics.py:27; rlt_cut_metrics uses the default -1) */
+int rlt_cut_metrics_ex(const float* p, const float* labels, const int32_t* k_in, int B, int S, double penalty,
+                       int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
 
 /* Task metrics of utils/metrics.py:40-76 (section 8f row N4), per list in float64:
  *   dcg_out[b] = taskr_metric's DCG of list b re-ordered by descending pred (relevant +1/log2(i+2), else -1/log2(i+2));

@@ -55,7 +55,7 @@ def reward_matrix_loop(labels: torch.Tensor, metric: str) -> torch.Tensor:
     return r
 
 
-def reward_matrix(labels: torch.Tensor, metric: str) -> torch.Tensor:
+def reward_matrix(labels: torch.Tensor, metric: str, penalty: float = -1) -> torch.Tensor:
     labels = labels.float()
     n_pos = labels.shape[1]
     if metric == 'f1':
@@ -69,7 +69,7 @@ def reward_matrix(labels: torch.Tensor, metric: str) -> torch.Tensor:
         safe = torch.where(total != 0, total, torch.ones_like(total))
         return torch.where(total != 0, (prec * rec * 2) / safe, torch.zeros_like(total))
     coef = torch.tensor(dcg_coef(n_pos))
-    gain = (labels == 1.).float() / coef + ((labels != 1.).float() / coef) * -1
+    gain = (labels == 1.).float() / coef + ((labels != 1.).float() / coef) * penalty
     return gain.cumsum(dim=1)
 
 

@@ -26,21 +26,37 @@ struct RewardArgs {
     float* q_out;          // (B,S) or null
     int B, S, metric, kind;
     float tau, gscale;     // gscale = 1/B
+    float penalty;         // DCG gain of a non-relevant document (utils/metrics.py:94; the reference's default is -1)
+    // fused cut metrics (E1-E3, run.py:141-145), only read by the METRICS instantiation
+    int32_t* k_out;        // (B) argmax_j p + 1
+    double* f1_out;        // (B) F1@k, float64
+    double* dcg_out;       // (B) DCG@k, float64 (metric penalty = mpenalty)
+    double mpenalty;
 };
 
 // element j of a list lives at lds[(j / C) * STRIDE + j % C], STRIDE = C|1 (odd => conflict-free)
 template <int C>
 __device__ __forceinline__ int lds_slot(int j) { return (j / C) * (C | 1) + (j % C); }
 
-template <int C>
+// METRICS: the same pass also emits the cut position k = argmax_j p + 1 (first maximum) and F1@k / DCG@k in float64
+// (run.py:141-145 -> utils/metrics.py:15-38) - labels and p are already in LDS / registers, so the metric costs no
+// HBM traffic beyond its 20 B of results per list.  The grid is sized to the chip (launch_reward) and every
+// workgroup strides over groups of 4 lists.
+template <int C, bool METRICS>
 __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     constexpr int STRIDE = C | 1;
     constexpr int ROW = 64 * STRIDE;
     __shared__ float sp[LISTS_PER_WG * ROW];
     __shared__ float sy[LISTS_PER_WG * ROW];
+    __shared__ double icoef[METRICS ? 64 * C : 1];      // 1 / log2(j + 2), float64 (utils/metrics.py:7)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int S = a.S;
-    const int b0 = blockIdx.x * LISTS_PER_WG;
+    if (METRICS) {
+        for (int j = tid; j < S; j += 256) icoef[j] = 1.0 / log2((double)(j + 2));
+    }
+    const int ngroups = (a.B + LISTS_PER_WG - 1) / LISTS_PER_WG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b0 = grp * LISTS_PER_WG;
     const int nl = min(LISTS_PER_WG, a.B - b0);
     const size_t base = (size_t)b0 * S;
     const int total = nl * S;
@@ -117,7 +133,7 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
                 float g = 0.f;
                 if (ok[i]) {
                     const float cf = a.coef[j];
-                    g = (yv[i] == 1.f) ? 1.f / cf : (1.f / cf) * -1.f;
+                    g = (yv[i] == 1.f) ? 1.f / cf : (1.f / cf) * a.penalty;
                 }
                 run += g;
                 pre[i] = run;
@@ -172,6 +188,49 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
             if (lane == 0 && a.loss_per_list) a.loss_per_list[b0 + wv] = tot;
         }
     }
+    // ---- cut metrics of the same lists (METRICS) ---------------------------------------------------
+    if (METRICS && wv < nl) {
+        const float* ly = sy + wv * ROW + lane * STRIDE;
+        const float* lp = sp + wv * ROW + lane * STRIDE;
+        // first maximum, like np.argmax (run.py:141-142): per-lane scan in index order, then (value, index) reduction
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int j = lane * C + i;
+            if (j < S && lp[i] > best) { best = lp[i]; bi = j; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int k = (bi == 0x7fffffff ? 0 : bi) + 1;
+        double hits = 0.0, n_rel = 0.0, dcg = 0.0;          // utils/metrics.py:15-38 in float64
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int j = lane * C + i;
+            if (j < S) {
+                const double t = (double)ly[i];
+                n_rel += t;
+                if (j < k) {
+                    hits += t;
+                    dcg += ((ly[i] == 1.f) ? 1.0 : a.mpenalty) * icoef[j];
+                }
+            }
+        }
+        hits = wave_sum(hits);
+        n_rel = wave_sum(n_rel);
+        dcg = wave_sum(dcg);
+        if (lane == 0) {
+            const double prec = hits / (double)k;
+            const double rec = (n_rel != 0.0) ? hits / n_rel : 0.0;
+            a.k_out[b0 + wv] = k;
+            a.f1_out[b0 + wv] = (prec + rec != 0.0) ? 2.0 * prec * rec / (prec + rec) : 0.0;
+            a.dcg_out[b0 + wv] = dcg;
+        }
+    }
     // ---- coalesced write-back through LDS ---------------------------------------------------------
     auto write_back = [&](float* dst, const float (&vals)[C]) {
         __syncthreads();
@@ -188,6 +247,8 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     if (a.dp) write_back(a.dp, dpv);
     if (a.r_out) write_back(a.r_out, rv);
     if (a.q_out) write_back(a.q_out, qv);
+    __syncthreads();          // the next group's staging overwrites sp / sy
+    }
 }
 
 // out[0] = scale * sum_i x[i], single workgroup, fixed summation order (deterministic)
@@ -204,26 +265,53 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* x, int n, f
     if (threadIdx.x == 0) out[0] = (float)(sm[0] * (double)scale);
 }
 
-template <int C>
+// loss = sum(loss_per_list) / B in float32 from a float64 sum, sums = {sum F1, sum DCG} in float64: one workgroup,
+// fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void loss_metrics_final_kernel(const float* loss_per_list, const double* f1, const double* dcg,
+                                                                 int n, float scale, float* loss_out, double* sums) {
+    __shared__ double sm[3][256];
+    double l = 0.0, x = 0.0, z = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { l += (double)loss_per_list[i]; x += f1[i]; z += dcg[i]; }
+    sm[0][threadIdx.x] = l; sm[1][threadIdx.x] = x; sm[2][threadIdx.x] = z;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int k = 0; k < 3; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = (float)(sm[0][0] * (double)scale);
+        sums[0] = sm[1][0];
+        sums[1] = sm[2][0];
+    }
+}
+
+// grid: one workgroup per group of 4 lists up to 8 workgroups per CU (256 CUs), beyond that the workgroups stride
+constexpr int REWARD_MAX_GRID = 256 * 8;
+
+template <int C, bool METRICS>
 int launch_reward(const RewardArgs& a, hipStream_t st) {
-    const int grid = rlt_cdiv(a.B, LISTS_PER_WG);
-    hipLaunchKernelGGL(reward_loss_kernel<C>, dim3(grid), dim3(256), 0, st, a);
+    const int groups = rlt_cdiv(a.B, LISTS_PER_WG);
+    const int grid = groups < REWARD_MAX_GRID ? groups : REWARD_MAX_GRID;
+    hipLaunchKernelGGL((reward_loss_kernel<C, METRICS>), dim3(grid), dim3(256), 0, st, a);
     return RLT_LAUNCH_RESULT();
 }
 
-int dispatch_reward(const RewardArgs& a, hipStream_t st) {
+template <bool METRICS>
+int dispatch_reward_m(const RewardArgs& a, hipStream_t st) {
     const int c = rlt_cdiv(a.S, 64);
-    if (c <= 1) return launch_reward<1>(a, st);
-    if (c <= 2) return launch_reward<2>(a, st);
-    if (c <= 3) return launch_reward<3>(a, st);
-    if (c <= 4) return launch_reward<4>(a, st);
-    if (c <= 5) return launch_reward<5>(a, st);
-    if (c <= 6) return launch_reward<6>(a, st);
-    if (c <= 8) return launch_reward<8>(a, st);
-    if (c <= 12) return launch_reward<12>(a, st);
-    if (c <= 16) return launch_reward<16>(a, st);
+    if (c <= 1) return launch_reward<1, METRICS>(a, st);
+    if (c <= 2) return launch_reward<2, METRICS>(a, st);
+    if (c <= 3) return launch_reward<3, METRICS>(a, st);
+    if (c <= 4) return launch_reward<4, METRICS>(a, st);
+    if (c <= 5) return launch_reward<5, METRICS>(a, st);
+    if (c <= 6) return launch_reward<6, METRICS>(a, st);
+    if (c <= 8) return launch_reward<8, METRICS>(a, st);
+    if (c <= 12) return launch_reward<12, METRICS>(a, st);
+    if (c <= 16) return launch_reward<16, METRICS>(a, st);
     return RLT_E_SHAPE;
 }
+int dispatch_reward(const RewardArgs& a, hipStream_t st) { return dispatch_reward_m<false>(a, st); }
 
 // ------------------------------------------------------------------------------ multi-task terms
 constexpr int MT_PART = 8;   // floats per partial record
@@ -304,7 +392,7 @@ __global__ void weighted_sum_kernel(WSumArgs a, float* out) {
 
 // ------------------------------------------------------------------------------ cut metrics
 __global__ __launch_bounds__(256) void cut_metrics_kernel(const float* p, const float* y, const int32_t* k_in,
-                                                          int B, int S, int32_t* k_out, double* f1_out, double* dcg_out) {
+                                                          int B, int S, double penalty, int32_t* k_out, double* f1_out, double* dcg_out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wv;
     if (b >= B) return;
@@ -336,7 +424,7 @@ __global__ __launch_bounds__(256) void cut_metrics_kernel(const float* p, const 
         n_rel += t;
         if (j < k) {
             hits += t;
-            dcg += ((yr[j] == 1.f) ? 1.0 : -1.0) / log2((double)(j + 2));
+            dcg += ((yr[j] == 1.f) ? 1.0 : penalty) / log2((double)(j + 2));
         }
     }
     hits = wave_sum(hits);
@@ -427,17 +515,25 @@ __global__ __launch_bounds__(256) void task_metrics_sum_kernel(const double* __r
 
 extern "C" {
 
-int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, int B, int S,
-                    int metric, int kind, float tau,
-                    float* loss_per_list, float* loss_out, float* dp, void* stream) {
-    RLT_CHECK_ARG(p && labels && loss_per_list && B > 0 && S > 0);
+static int reward_args_ok(const float* p, const float* labels, const float* dcg_coef, int B, int S, int metric, int kind) {
+    RLT_CHECK_ARG(labels && B > 0 && S > 0);
     RLT_CHECK_ARG(metric == RLT_METRIC_F1 || (metric == RLT_METRIC_DCG && dcg_coef));
     RLT_CHECK_ARG(kind >= RLT_LOSS_EXPECT && kind <= RLT_LOSS_JS);
     RLT_CHECK_SHAPE(S <= 1024);
-    if ((S & 3) == 0 && !(rlt_aligned16(p) && rlt_aligned16(labels))) return RLT_E_ALIGN;
-    RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B};
+    if ((S & 3) == 0 && !((!p || rlt_aligned16(p)) && rlt_aligned16(labels))) return RLT_E_ALIGN;
+    return 0;
+}
+
+int rlt_reward_loss_ex(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                       int metric, float penalty, int kind, float tau,
+                       float* loss_per_list, float* loss_out, float* dp, void* stream) {
+    RLT_CHECK_ARG(p && loss_per_list);
+    int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
+    if (rc) return rc;
+    RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
+                 nullptr, nullptr, nullptr, -1.0};
     hipStream_t st = rlt_stream(stream);
-    int rc = dispatch_reward(a, st);
+    rc = dispatch_reward(a, st);
     if (rc) return rc;
     if (loss_out) {
         hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_per_list, B, 1.0f / (float)B, loss_out);
@@ -446,14 +542,42 @@ int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, 
     return rc;
 }
 
+int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                    int metric, int kind, float tau,
+                    float* loss_per_list, float* loss_out, float* dp, void* stream) {
+    return rlt_reward_loss_ex(p, labels, dcg_coef, B, S, metric, -1.f, kind, tau, loss_per_list, loss_out, dp, stream);
+}
+
+int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
+                     int metric, float penalty, int kind, float tau, double metric_penalty,
+                     float* loss_per_list, float* loss_out, float* dp,
+                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
+    RLT_CHECK_ARG(p && loss_per_list && loss_out && k_out && f1_out && dcg_out && sums);
+    int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
+    if (rc) return rc;
+    RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
+                 k_out, f1_out, dcg_out, metric_penalty};
+    hipStream_t st = rlt_stream(stream);
+    rc = dispatch_reward_m<true>(a, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_metrics_final_kernel, dim3(1), dim3(256), 0, st, loss_per_list, f1_out, dcg_out, B,
+                       1.0f / (float)B, loss_out, sums);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int S, int metric, float penalty, float tau,
+                         float* r_out, float* q_out, void* stream) {
+    RLT_CHECK_ARG(r_out || q_out);
+    int rc = reward_args_ok(nullptr, labels, dcg_coef, B, S, metric, RLT_LOSS_KL);
+    if (rc) return rc;
+    RewardArgs a{nullptr, labels, dcg_coef, nullptr, nullptr, r_out, q_out, B, S, metric, RLT_LOSS_KL, tau, 1.0f, penalty,
+                 nullptr, nullptr, nullptr, -1.0};
+    return dispatch_reward(a, rlt_stream(stream));
+}
+
 int rlt_reward_matrix(const float* labels, const float* dcg_coef, int B, int S, int metric, float tau,
                       float* r_out, float* q_out, void* stream) {
-    RLT_CHECK_ARG(labels && B > 0 && S > 0 && (r_out || q_out));
-    RLT_CHECK_ARG(metric == RLT_METRIC_F1 || (metric == RLT_METRIC_DCG && dcg_coef));
-    RLT_CHECK_SHAPE(S <= 1024);
-    if ((S & 3) == 0 && !rlt_aligned16(labels)) return RLT_E_ALIGN;
-    RewardArgs a{nullptr, labels, dcg_coef, nullptr, nullptr, r_out, q_out, B, S, metric, RLT_LOSS_KL, tau, 1.0f};
-    return dispatch_reward(a, rlt_stream(stream));
+    return rlt_reward_matrix_ex(labels, dcg_coef, B, S, metric, -1.f, tau, r_out, q_out, stream);
 }
 
 static int mt_grid(size_t n) { return (int)((n + 256 * 8 - 1) / (256 * 8) < 1024 ? (n + 256 * 8 - 1) / (256 * 8) : 1024); }
@@ -497,15 +621,20 @@ int rlt_weighted_sum(const float* const* x, const float* w, int n, float* out, v
     return RLT_LAUNCH_RESULT();
 }
 
-int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
-                    int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
+int rlt_cut_metrics_ex(const float* p, const float* labels, const int32_t* k_in, int B, int S, double penalty,
+                       int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
     RLT_CHECK_ARG(labels && (p || k_in) && B > 0 && S > 0);
     RLT_CHECK_ARG(!sums || (f1_out && dcg_out));
     hipStream_t st = rlt_stream(stream);
-    hipLaunchKernelGGL(cut_metrics_kernel, dim3(rlt_cdiv(B, 4)), dim3(256), 0, st, p, labels, k_in, B, S,
+    hipLaunchKernelGGL(cut_metrics_kernel, dim3(rlt_cdiv(B, 4)), dim3(256), 0, st, p, labels, k_in, B, S, penalty,
                        k_out, f1_out, dcg_out);
     if (sums) hipLaunchKernelGGL(sum2_f64_kernel, dim3(1), dim3(256), 0, st, f1_out, dcg_out, B, sums);
     return RLT_LAUNCH_RESULT();
+}
+
+int rlt_cut_metrics(const float* p, const float* labels, const int32_t* k_in, int B, int S,
+                    int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
+    return rlt_cut_metrics_ex(p, labels, k_in, B, S, -1.0, k_out, f1_out, dcg_out, sums, stream);
 }
 
 int rlt_task_metrics(const float* labels, const float* pred, int B, int S,

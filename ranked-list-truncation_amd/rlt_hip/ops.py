@@ -614,29 +614,43 @@ def dcg_coef(S, device):
     return _COEF_CACHE[key]
 
 
+def _fused_metric_buffers(B, dev):
+    return (torch.empty((B,), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.float64, device=dev),
+            torch.empty((B,), dtype=torch.float64, device=dev), torch.empty((2,), dtype=torch.float64, device=dev))
+
+
 class RewardLossFn(Function):
-    """Fused reward matrix + {Choopy | AttnCut | KL | JS} loss; returns a 0-d tensor."""
+    """Fused reward matrix + {Choopy | AttnCut | KL | JS} loss; returns a 0-d tensor.  `penalty`: the DCG gain numerator of
+    a non-relevant document (Metric_for_Loss.dcg's argument, utils/metrics.py:94).  With `with_metrics` the same kernel
+    pass also yields the cut metrics of run.py:141-145 and the call returns (loss, k (B) int32, sums (2) float64 =
+    [sum F1@k, sum DCG@k])."""
 
     @staticmethod
-    def forward(ctx, p, labels, metric, kind, tau):
+    def forward(ctx, p, labels, metric, kind, tau, penalty=-1.0, with_metrics=False, metric_penalty=-1.0):
         B, S = labels.shape
         coef = dcg_coef(S, p.device) if metric == N.METRIC_DCG else None
         per_list = _empty((B,), p)
         loss = _empty((1,), p)
         dp = _empty((B, S), p)
-        call("rlt_reward_loss", ptr(p), ptr(labels), ptr(coef), B, S, metric, kind, tau,
-             ptr(per_list), ptr(loss), ptr(dp), stream())
         ctx.save_for_backward(dp)
         ctx.pshape = p.shape
-        return loss.reshape(())
+        if not with_metrics:
+            call("rlt_reward_loss_ex", ptr(p), ptr(labels), ptr(coef), B, S, metric, penalty, kind, tau,
+                 ptr(per_list), ptr(loss), ptr(dp), stream())
+            return loss.reshape(())
+        k, f1, dcg, sums = _fused_metric_buffers(B, p.device)
+        call("rlt_loss_metrics", ptr(p), ptr(labels), ptr(coef), B, S, metric, penalty, kind, tau, metric_penalty,
+             ptr(per_list), ptr(loss), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+        ctx.mark_non_differentiable(k, sums)
+        return loss.reshape(()), k, sums
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go, *_unused):
         (dp,) = ctx.saved_tensors
         g = dp.clone()
         go = N.f32c(go).reshape(1)
         call("rlt_scale", ptr(g), ptr(go), g.numel(), stream())
-        return g.view(ctx.pshape), None, None, None, None
+        return g.view(ctx.pshape), None, None, None, None, None, None, None
 
 
 class WassDistLossFn(Function):
@@ -712,18 +726,24 @@ class BiCutLossFn(Function):
 
 
 class MtCutLossFn(Function):
-    """cut JS loss + w_r * rerank hinge + w_c * BCE, one tape node (utils/losses.py:180-191)."""
+    """cut JS loss + w_r * rerank hinge + w_c * BCE, one tape node (utils/losses.py:180-191).  `with_metrics`: the cut term's
+    kernel pass also yields the cut metrics; returns (loss, k, sums) as RewardLossFn does."""
 
     @staticmethod
-    def forward(ctx, cut_p, rerank, cls, labels, metric, tau, w_r, w_c, margin):
+    def forward(ctx, cut_p, rerank, cls, labels, metric, tau, w_r, w_c, margin, with_metrics=False):
         B, S = labels.shape
         dev = cut_p.device
         coef = dcg_coef(S, dev) if metric == N.METRIC_DCG else None
         per_list = _empty((B,), cut_p)
         cut = _empty((1,), cut_p)
         dp = _empty((B, S), cut_p)
-        call("rlt_reward_loss", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, N.LOSS_JS, tau,
-             ptr(per_list), ptr(cut), ptr(dp), stream())
+        if with_metrics:
+            k, f1, dcg, sums = _fused_metric_buffers(B, dev)
+            call("rlt_loss_metrics", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, -1.0, N.LOSS_JS, tau, -1.0,
+                 ptr(per_list), ptr(cut), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+        else:
+            call("rlt_reward_loss", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, N.LOSS_JS, tau,
+                 ptr(per_list), ptr(cut), ptr(dp), stream())
         terms = _empty((4,), cut_p)
         ws_bytes = query("rlt_mt_terms_workspace", B, S)
         ws = workspace(ws_bytes, dev)
@@ -740,10 +760,13 @@ class MtCutLossFn(Function):
         ctx.save_for_backward(dp, cls, labels, terms)
         ctx.meta = (w_r, w_c, rerank is not None, cut_p.shape, None if rerank is None else rerank.shape,
                     None if cls is None else cls.shape)
+        if with_metrics:
+            ctx.mark_non_differentiable(k, sums)
+            return loss.reshape(()), k, sums
         return loss.reshape(())
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go, *_unused):
         dp, cls, labels, terms = ctx.saved_tensors
         w_r, w_c, has_rr, pshape, rshape, cshape = ctx.meta
         B, S = labels.shape
@@ -755,7 +778,7 @@ class MtCutLossFn(Function):
         if has_rr or cls is not None:
             call("rlt_mt_terms_bwd", ptr(cls), ptr(labels), ptr(terms), B, S, w_r, w_c, ptr(go), ptr(d_rr), ptr(d_cl), stream())
         return (g.view(pshape), None if d_rr is None else d_rr.view(rshape), None if d_cl is None else d_cl.view(cshape),
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class RerankLossFn(Function):
@@ -783,22 +806,19 @@ class RerankLossFn(Function):
 
 
 # ------------------------------------------------------------------------------ metrics
-def cut_metrics(p, labels, k_in=None):
+def cut_metrics(p, labels, k_in=None, penalty=-1.0):
     """Per-list (k, F1@k, DCG@k) on device; p (B,S) or (B,S,1), labels (B,S).  Returns tensors."""
     B, S = labels.shape
     dev = labels.device
-    k = torch.empty((B,), dtype=torch.int32, device=dev)
-    f1 = torch.empty((B,), dtype=torch.float64, device=dev)
-    dcg = torch.empty((B,), dtype=torch.float64, device=dev)
-    sums = torch.empty((2,), dtype=torch.float64, device=dev)
-    call("rlt_cut_metrics", ptr(p), ptr(labels), ptr(k_in), B, S, ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+    k, f1, dcg, sums = _fused_metric_buffers(B, dev)
+    call("rlt_cut_metrics_ex", ptr(p), ptr(labels), ptr(k_in), B, S, float(penalty), ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
     return k, f1, dcg, sums
 
 
-def reward_matrix(labels, metric, tau=1.0, want_q=False):
+def reward_matrix(labels, metric, tau=1.0, want_q=False, penalty=-1.0):
     B, S = labels.shape
     coef = dcg_coef(S, labels.device) if metric == N.METRIC_DCG else None
     r = _empty((B, S), labels)
     q = _empty((B, S), labels) if want_q else None
-    call("rlt_reward_matrix", ptr(labels), ptr(coef), B, S, metric, tau, ptr(r), ptr(q), stream())
+    call("rlt_reward_matrix_ex", ptr(labels), ptr(coef), B, S, metric, float(penalty), tau, ptr(r), ptr(q), stream())
     return (r, q) if want_q else r

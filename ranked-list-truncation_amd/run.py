@@ -156,12 +156,12 @@ class Trainer:
         if n_own > 0:
             Xs, ys = (X, y) if self.world == 1 else (X[lo:hi], y[lo:hi])
             output = self.model(Xs)
-            loss = self.criterion(output, ys)
+            # loss and cut metrics (run.py:126,131-145) out of one pass over p and the labels; BiCut's (B,S,2) output goes
+            # through its own criterion and Metric.evaluate's cut rule
+            loss, _k, f1, dcg = Metric.step(self.criterion, output, ys)
             if train:
                 # AVG all-reduce of sum_r (n_r * world / n) * grad_r / world = sum_r (n_r / n) * grad_r
                 (loss if n_own * self.world == n_all else loss * (n_own * self.world / n_all)).backward()
-            cut = output[-1] if self.multi_task else output    # run.py:131-142 (Metric.evaluate applies BiCut's rule to (B,S,2))
-            _k, f1, dcg = Metric.evaluate(cut, ys)
             stats = torch.stack([loss.detach().double(), f1, dcg, torch.ones((), dtype=torch.float64, device=self.device)]) * n_own
         if train:
             self.flat.all_reduce_grads()                        # an empty shard contributes its zeroed bucket

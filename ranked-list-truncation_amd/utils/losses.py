@@ -34,6 +34,11 @@ class ChoopyLoss(nn.Module):
         p, y = _prep(output, labels)
         return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), N.LOSS_EXPECT, 1.0)
 
+    def forward_with_metrics(self, output, labels):
+        """(loss, k, [sum F1@k, sum DCG@k]) from one kernel pass (utils.metrics.Metric.step)."""
+        p, y = _prep(output, labels)
+        return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), N.LOSS_EXPECT, 1.0, -1.0, True)
+
 
 class AttnCutLoss(nn.Module):
     def __init__(self, metric: str = 'f1', tau: float = 0.95):
@@ -43,6 +48,10 @@ class AttnCutLoss(nn.Module):
     def forward(self, output, labels):
         p, y = _prep(output, labels)
         return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), N.LOSS_CE, float(self.tau))
+
+    def forward_with_metrics(self, output, labels):
+        p, y = _prep(output, labels)
+        return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), N.LOSS_CE, float(self.tau), -1.0, True)
 
 
 class DivLoss(nn.Module):
@@ -55,6 +64,11 @@ class DivLoss(nn.Module):
         p, y = _prep(output, labels)
         kind = N.LOSS_KL if self.div_type == 'kl' else N.LOSS_JS
         return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), kind, float(self.tau))
+
+    def forward_with_metrics(self, output, labels):
+        p, y = _prep(output, labels)
+        kind = N.LOSS_KL if self.div_type == 'kl' else N.LOSS_JS
+        return ops.RewardLossFn.apply(p, y, _metric_code(self.metric), kind, float(self.tau), -1.0, True)
 
 
 class RerankLoss(nn.Module):
@@ -84,7 +98,7 @@ class MtCutLoss(nn.Module):
         self.num_tasks = num_tasks
         self.metric = metric
 
-    def forward(self, output, labels):
+    def _apply(self, output, labels, with_metrics):
         y_class = y_rerank = None
         if self.num_tasks == 3:
             y_class, y_rerank, y_cut = output
@@ -97,7 +111,13 @@ class MtCutLoss(nn.Module):
         cl = None if y_class is None else N.f32c(y_class)
         return ops.MtCutLossFn.apply(p, rr, cl, y, _metric_code(self.metric), float(self.cutloss.tau),
                                      float(self.rerank_weight), float(self.classi_weight),
-                                     float(self.rerankloss.margin))
+                                     float(self.rerankloss.margin), with_metrics)
+
+    def forward(self, output, labels):
+        return self._apply(output, labels, False)
+
+    def forward_with_metrics(self, output, labels):
+        return self._apply(output, labels, True)
 
 
 class BiCutLoss(nn.Module):

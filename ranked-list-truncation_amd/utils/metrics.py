@@ -30,10 +30,10 @@ class Metric:
     """F1 / penalised DCG of the top-k prefix, averaged over the batch (float64 on device)."""
 
     @classmethod
-    def _run(cls, labels, k_s):
+    def _run(cls, labels, k_s, penalty=-1):
         y = _labels(labels)
         k = torch.as_tensor(np.asarray(k_s), dtype=torch.int32).to(y.device).contiguous()
-        _, f1, dcg, sums = ops.cut_metrics(None, y, k_in=k)
+        _, f1, dcg, sums = ops.cut_metrics(None, y, k_in=k, penalty=penalty)
         return sums.cpu().numpy() / y.shape[0]
 
     @classmethod
@@ -42,9 +42,7 @@ class Metric:
 
     @classmethod
     def dcg(cls, labels, k_s, penalty=-1):
-        if penalty != -1:
-            raise NotImplementedError("only the reference's default penalty=-1 is implemented")
-        return float(cls._run(labels, k_s)[1])
+        return float(cls._run(labels, k_s, penalty)[1])
 
     @classmethod
     def _task(cls, labels, predictions):
@@ -88,6 +86,22 @@ class Metric:
         mean = sums / y.shape[0]
         return k, mean[0], mean[1]
 
+    @classmethod
+    def step(cls, criterion, output, labels):
+        """criterion(output, labels) and evaluate(cut distribution, labels) of one training step (run.py:126,137-145).
+        Criteria built on the reward kernel (ChoopyLoss / AttnCutLoss / DivLoss / MtCutLoss) produce the metrics in the
+        same pass over p and the labels (`rlt_loss_metrics`); any other criterion is followed by `evaluate`.
+        Returns (loss, k, mean F1, mean DCG)."""
+        fused = getattr(criterion, "forward_with_metrics", None)
+        if fused is not None:
+            loss, k, sums = fused(output, labels)
+            mean = sums / labels.shape[0]
+            return loss, k, mean[0], mean[1]
+        loss = criterion(output, labels)
+        cut = output[-1] if isinstance(output, (list, tuple)) else output
+        k, f1, dcg = cls.evaluate(cut, labels)
+        return loss, k, f1, dcg
+
 
 class Metric_for_Loss:
     """Reward of ONE (list, k) pair, as the reference's per-element interface (utils/metrics.py:85-101).
@@ -95,9 +109,9 @@ class Metric_for_Loss:
     kernel - it exists for drop-in completeness (plots, notebooks)."""
 
     @classmethod
-    def _reward(cls, label, k, metric):
+    def _reward(cls, label, k, metric, penalty=-1):
         y = _labels(label).reshape(1, -1)
-        r = ops.reward_matrix(y, metric)
+        r = ops.reward_matrix(y, metric, penalty=penalty)
         return r[0, k - 1].clone()
 
     @classmethod
@@ -106,6 +120,4 @@ class Metric_for_Loss:
 
     @classmethod
     def dcg(cls, label, k: int, penalty: int = -1):
-        if penalty != -1:
-            raise NotImplementedError("only the reference's default penalty=-1 is implemented")
-        return cls._reward(label, k, N.METRIC_DCG)
+        return cls._reward(label, k, N.METRIC_DCG, penalty)

@@ -207,3 +207,20 @@ def test_wassdist_loss_and_gradient():
         assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (tag, loss.item(), ref)
         dp = gold[f"{tag}/dp"]
         np.testing.assert_allclose(p.grad.squeeze(2).numpy(), dp, rtol=0, atol=1e-4 * np.abs(dp).max())
+
+
+def test_dcg_penalty_argument_against_reference():
+    """Metric.dcg(..., penalty) / Metric_for_Loss.dcg(..., penalty) (utils/metrics.py:27,94) at non-default penalties,
+    values produced by the reference (tools/make_golden.py losses)."""
+    import numpy as np
+    import torch
+    from oracle import losses as ol, metrics as om
+    gold = gu.load("losses_edge_s300")
+    y = torch.from_numpy(gold["y"])
+    for pen in (-0.5, -2.0, 0.25):
+        assert abs(om.Metric.dcg(gold["y"], gold["k_s"], pen) - float(gold[f"metric_dcg_pen/{pen:g}"])) < 1e-9
+        want = torch.from_numpy(gold[f"reward_dcg_pen/{pen:g}"])
+        rows = y[[0, 1, 4, 7]]
+        assert float((ol.reward_matrix(rows, "dcg", pen) - want).abs().max()) < 4e-5
+        loop = torch.stack([torch.stack([ol.reward_dcg(r, j + 1, pen) for j in range(0, 300, 37)]) for r in rows])
+        assert float((loop - want[:, 0:300:37]).abs().max()) < 1e-6

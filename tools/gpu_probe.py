@@ -160,6 +160,31 @@ def losses():
     for metric in ("f1", "dcg"):
         r = ops.reward_matrix(y.to(dev), N.METRIC_F1 if metric == "f1" else N.METRIC_DCG)
         report(f"reward matrix {metric}", float(np.abs(r.cpu().numpy() - gold["reward/" + metric]).max()), 2e-5)
+    # the `penalty` argument of Metric_for_Loss.dcg / Metric.dcg (utils/metrics.py:94,27), reference values
+    from utils.metrics import Metric, Metric_for_Loss
+    for pen in (-0.5, -2.0, 0.25):
+        r = ops.reward_matrix(y[[0, 1, 4, 7]].to(dev), N.METRIC_DCG, penalty=pen)
+        report(f"reward matrix dcg penalty {pen:g}", float(np.abs(r.cpu().numpy() - gold[f"reward_dcg_pen/{pen:g}"]).max()), 4e-5)
+        report(f"Metric.dcg penalty {pen:g}", abs(Metric.dcg(gold["y"], gold["k_s"], penalty=pen) - float(gold[f"metric_dcg_pen/{pen:g}"])), 1e-9)
+        report(f"Metric_for_Loss.dcg penalty {pen:g}", abs(float(Metric_for_Loss.dcg(y[4], 17, penalty=pen)) - float(gold[f"reward_dcg_pen/{pen:g}"][2, 16])), 1e-5)
+    # loss + cut metrics in one pass (rlt_loss_metrics) == the separate kernels, bit for bit; at B = 5000 the grid strides
+    for (Bf, Sf) in ((10, 300), (5000, 300), (9001, 100), (33, 777)):
+        g = torch.Generator().manual_seed(Bf)
+        yy = (torch.rand(Bf, Sf, generator=g) < 0.2).float().to(dev)
+        pp = torch.softmax(torch.randn(Bf, Sf, generator=g) * 2, 1).unsqueeze(2).to(dev)
+        for cname in ("div_js_f1_aug1", "div_kl_dcg_aug0", "choopy_f1", "attncutloss_dcg"):
+            crit = make_criterion(hl, cname)
+            p1 = pp.clone().requires_grad_(True)
+            l1 = crit(p1, yy)
+            l1.backward()
+            k1, f1, d1 = Metric.evaluate(p1, yy)
+            p2 = pp.clone().requires_grad_(True)
+            l2, k2, f2, d2 = Metric.step(crit, p2, yy)
+            l2.backward()
+            report(f"fused loss+metrics {cname} B{Bf} S{Sf}: loss", abs(float(l1) - float(l2)) / max(1.0, abs(float(l1))), 1e-6)
+            report(f"fused loss+metrics {cname} B{Bf} S{Sf}: dp", float((p1.grad - p2.grad).abs().max()), 0)
+            report(f"fused loss+metrics {cname} B{Bf} S{Sf}: k", float((k1 != k2).sum()), 0)
+            report(f"fused loss+metrics {cname} B{Bf} S{Sf}: F1, DCG", max(abs(float(f1) - float(f2)), abs(float(d1) - float(d2)) / max(1.0, abs(float(d1)))), 1e-12)
     # odd S
     for S in (40, 100, 200, 301, 777):
         yy = (torch.rand(7, S) < 0.2).float()
@@ -662,8 +687,9 @@ def _param_rel_l2(hip, ref):
     top = max(float(v.grad.norm()) for v in refs.values() if v.grad is not None)
     out = {}
     for n, a in hip.named_parameters():
-        g = refs[n].grad
-        out[n] = float((a.grad.detach().cpu().double() - g.double()).norm()) / max(float(g.norm()), 1e-3 * top)
+        g = refs[n].grad if refs[n].grad is not None else torch.zeros_like(refs[n])    # parameter not on the loss's path
+        mine = a.grad.detach().cpu().double() if a.grad is not None else torch.zeros_like(g).double()
+        out[n] = float((mine - g.double()).norm()) / max(float(g.norm()), 1e-3 * top)
     return out
 
 

@@ -33,7 +33,7 @@ sys.modules["numpy.lib.financial"] = _stub
 sys.path.insert(0, REF)
 import models as ref_models  # noqa: E402
 from utils import losses as ref_losses  # noqa: E402
-from utils.metrics import Metric as RefMetric  # noqa: E402
+from utils.metrics import Metric as RefMetric, Metric_for_Loss as RefMetricForLoss  # noqa: E402
 sys.path.remove(REF)
 
 torch.set_num_threads(8)
@@ -190,6 +190,14 @@ def loss_cases():
     kat_k = np.array([1, 2, 1])
     rec["kat_f1"] = np.float64(RefMetric.f1(kat_x, kat_k))
     rec["kat_dcg"] = np.float64(RefMetric.dcg(kat_x, kat_k))
+    # the `penalty` argument of Metric.dcg (utils/metrics.py:27) and Metric_for_Loss.dcg (:94), non-default values
+    for pen in (-0.5, -2.0, 0.25):
+        rec[f"metric_dcg_pen/{pen:g}"] = np.float64(RefMetric.dcg(y, k_s, penalty=pen))
+        r = np.zeros((4, n_pos), dtype=np.float32)
+        for i, row in enumerate((0, 1, 4, 7)):                      # no relevant doc, all relevant, two random rows
+            for j in range(n_pos):
+                r[i, j] = float(RefMetricForLoss.dcg(y_t[row], j + 1, penalty=pen))
+        rec[f"reward_dcg_pen/{pen:g}"] = r
     np.savez_compressed(os.path.join(OUT, "losses_edge_s300.npz"), **rec)
     print("losses_edge_s300: kat_f1=%.16f kat_dcg=%.16f" % (rec["kat_f1"], rec["kat_dcg"]), flush=True)
 
