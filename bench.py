@@ -268,7 +268,9 @@ def main():
         return elapsed, state
 
     def kernel_times(n_steps):
-        """HIP-event times of the named attention launches, taken OUTSIDE the timed region (short separate loop)."""
+        """HIP-event times (on the launch stream) of the three list-attention launches of REAL training steps, taken
+        OUTSIDE the timed region: with the timer active the encoder layer is driven launch by launch from the host
+        (ops.EncoderLayerKernelsFn: the same launches, in the same order, as the one path-level call of the timed steps)."""
         timer = ops.KernelTimer()
         ops.KernelTimer.active = timer
         for _ in range(n_steps):
@@ -376,7 +378,7 @@ def main():
                          "executed_bf16_tflops": round(executed, 2) if mult > 1 else None,
                          "mfma_products_per_fp32_product": mult,
                          "launch_ms": round(ms, 3), "launches_timed": launches,
-                         "timed_in": "separate loop after the timed region (HIP events on the launch stream)",
+                         "timed_in": "separate training steps after the timed region, encoder layer driven launch by launch (HIP events on the launch stream)",
                          "other_kernels_ms": {k: round(v[1], 3) for k, v in ksum.items() if k != name},
                          "whole_step": None if step_flop is None else {
                              "algorithmic_tflop": round(step_flop / 1e12, 2),

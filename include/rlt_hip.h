@@ -35,7 +35,7 @@ extern "C" {
 #define RLT_E_WORKSPACE (-3)  /* workspace too small                               */
 #define RLT_E_ALIGN    (-4)   /* pointer / leading dimension not 16-byte aligned   */
 
-#define RLT_ABI_VERSION 1
+#define RLT_ABI_VERSION 2
 int rlt_abi_version(void);
 /* Precision of the MFMA contractions (rlt_gemm*, rlt_list_attention_*); inputs, outputs, softmax, LayerNorm,
  * LSTM and accumulators are fp32 in both modes.
@@ -282,6 +282,62 @@ int rlt_bilstm_rec_fwd_x(const float* x, int I, const float* w_ih_fwd, const flo
                          float* gates, float* h_out, float* c_out, void* stream);
 int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
                        const float* d_hout, int S, int B, void* stream);
+
+/* ------------------------------------------------------------------ PATH-LEVEL ENTRY POINTS
+ * One call = the forward or the backward of one module of the reference's models, composed inside the library from
+ * the kernel-level entry points of this header (same launches, same order, same in-place accumulation): a host in any
+ * language drives the hot path with these, the kernel-level entry points stay for tests and for hosts that fuse
+ * differently.  Activations are position-major (S*B, E).  The caller owns two buffers per module:
+ *   stash  written by the forward, read (the BiLSTM's: also overwritten) by the backward; layout documented at
+ *          enc_stash() / lstm_stash() in csrc/path.hip;
+ *   ws     scratch, dead after the call.
+ * rlt_workspace_bytes(op, S, B, E, H, FF, train_dropout) reports their sizes; all regions are 256-byte aligned, pass
+ * 256-byte aligned buffers.  For the RLT_OP_BILSTM_* queries E = the input feature count of layer 0, H and FF unused.
+ */
+#define RLT_OP_ENCODER_STASH   1   /* stash of rlt_encoder_layer_fwd/bwd                                        */
+#define RLT_OP_ENCODER_FWD_WS  2   /* ws of rlt_encoder_layer_fwd                                               */
+#define RLT_OP_ENCODER_BWD_WS  3   /* ws of rlt_encoder_layer_bwd (train_dropout != 0: + two (T,E) dropout grads) */
+#define RLT_OP_BILSTM_STASH    4   /* stash of rlt_bilstm_fwd/bwd                                               */
+#define RLT_OP_BILSTM_WS       5   /* ws of rlt_bilstm_fwd and rlt_bilstm_bwd                                   */
+size_t rlt_workspace_bytes(int op, int S, int B, int E, int H, int FF, int train_dropout);
+
+/* nn.TransformerEncoderLayer(d_model=E, nhead=H, dim_feedforward=FF, dropout) parameters, by state_dict name
+ * (models/AttnCut.py:9: `attention_layer.layers.<i>.` + self_attn.in_proj_weight (3E,E), self_attn.in_proj_bias (3E),
+ * self_attn.out_proj.weight (E,E), .bias (E), norm1.weight/.bias (E), linear1.weight (FF,E), .bias (FF),
+ * linear2.weight (E,FF), .bias (E), norm2.weight/.bias (E)) */
+typedef struct rlt_encoder_weights {
+    const float *in_proj_weight, *in_proj_bias, *out_proj_weight, *out_proj_bias, *norm1_weight, *norm1_bias,
+                *linear1_weight, *linear1_bias, *linear2_weight, *linear2_bias, *norm2_weight, *norm2_bias;
+} rlt_encoder_weights;
+typedef struct rlt_encoder_grads {     /* same shapes; every member is WRITTEN (=), not accumulated */
+    float *in_proj_weight, *in_proj_bias, *out_proj_weight, *out_proj_bias, *norm1_weight, *norm1_bias,
+          *linear1_weight, *linear1_bias, *linear2_weight, *linear2_bias, *norm2_weight, *norm2_bias;
+} rlt_encoder_grads;
+/* y = norm2(h1 + drop2(linear2(drop(relu(linear1(h1)))))),  h1 = norm1(x + drop1(out_proj(list_attention(in_proj(x)))))
+ * (post-norm, ReLU, attention over the B lists at each of the S positions: F.multi_head_attention_forward on a
+ * (L=B, N=S, E) input - models/AttnCut.py:9-10,18).  x, y: (S*B, E).  drop_p = 0 in eval();
+ * seeds[4] = {attention probabilities, dropout1, FFN hidden, dropout2} (may be NULL when drop_p == 0).
+ * bwd: dx (S*B, E) = d/dx, every member of g written; needs the same x, w, seeds and the forward's stash. */
+int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, int B, int E, int H, int FF, float eps,
+                          float drop_p, const uint32_t* seeds, float* y, void* stash, size_t stash_bytes,
+                          void* ws, size_t ws_bytes, void* stream);
+int rlt_encoder_layer_bwd(const float* x, const rlt_encoder_weights* w, int S, int B, int E, int H, int FF, float eps,
+                          float drop_p, const uint32_t* seeds, const float* dy, const void* stash, size_t stash_bytes,
+                          float* dx, const rlt_encoder_grads* g, void* ws, size_t ws_bytes, void* stream);
+
+/* One bidirectional layer of nn.LSTM(input, 128, num_layers=2, batch_first=True, bidirectional=True)
+ * (models/AttnCut.py:8), index 0 = forward direction, 1 = reverse: weight_ih_l{k}[_reverse] (512, in),
+ * weight_hh_l{k}[_reverse] (512,128), bias_ih_l{k}[_reverse] (512), bias_hh_l{k}[_reverse] (512). */
+typedef struct rlt_lstm_layer_weights { const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2]; } rlt_lstm_layer_weights;
+typedef struct rlt_lstm_layer_grads { float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2]; } rlt_lstm_layer_grads;   /* written (=) */
+/* The whole 2-layer stack: x (S*B, I) -> h_out (S*B, 256) = [forward | reverse] hidden states of layer 1; w[2], g[2] =
+ * layers 0 and 1 (layer 1 has 256 inputs).  bwd: dh_out (S*B,256) -> g and, when dx != NULL, dx (S*B, I); it needs the
+ * forward's h_out and stash, and overwrites the gate stashes (call it once per forward). */
+int rlt_bilstm_fwd(const float* x, int I, const rlt_lstm_layer_weights* w, int S, int B, float* h_out,
+                   void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, void* stream);
+int rlt_bilstm_bwd(const float* x, int I, const rlt_lstm_layer_weights* w, const float* h_out, const float* dh_out, int S, int B,
+                   void* stash, size_t stash_bytes, float* dx, const rlt_lstm_layer_grads* g,
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ layout helpers
  * (B,S,F) user layout <-> (S*B,F) position-major */

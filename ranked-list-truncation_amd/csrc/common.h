@@ -15,6 +15,7 @@ static inline hipStream_t rlt_stream(void* s) { return (hipStream_t)s; }
 static inline bool rlt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int rlt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ int rlt_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ bool rlt_aligned16_dev(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // kernels that use more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in
 template <typename K>

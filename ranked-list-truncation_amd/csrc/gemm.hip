@@ -153,136 +153,191 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
 }
 
 // ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
+// The kernels issue their MFMAs with the operands SWAPPED (the B-tile fragment as the instruction's A operand), so
+// every 32x32 accumulator block holds C TRANSPOSED: lane l31 = ROW of C inside the block, register r = COLUMN
+// (r&3) + 8(r>>2) + 4hh.  Four consecutive registers are then four consecutive columns of one row: the epilogue stores
+// 16 bytes per lane (a wavefront instruction covers 32 rows x 32 B; four of them finish the rows' 128-B lines) where the
+// untransposed layout needed one 4-byte store per element - 128 store instructions per wavefront per 256x256 tile, and
+// the K = 256 products that write 10 GB were bound by issuing them.  The 1-bit ReLU masks fall out of the same layout:
+// a lane owns half the bits of its row's mask word (one cross-half shuffle, one store per row) and reads a row's
+// words with one load.
 // wavefront tile = 64 rows (2 MFMA blocks) x 32*NJ columns at (rbase, cbase); `interior`: the whole workgroup tile is
 // inside C
 template <bool V> struct BoolTag { static constexpr bool value = V; };
+__device__ __forceinline__ float4 f4(const f32x16& a, int q) { return make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]); }
+__device__ __forceinline__ float4 f4add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ uint32_t pos4(float4 v) {
+    return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+}
 template <int NJ>
 __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (&acc)[2][NJ], int rbase, int cbase,
                                                bool interior, int l31, int hh, int z) {
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
     const int ldo = to_slab ? g.N : g.ldc;
-    // interior tiles with one of the common epilogues: the bounds and mode tests are hoisted out of the per-element
-    // loop (tested per element they cost >1 ms of a K = 256 product that writes 10 GB)
-    if (interior && g.drop_p <= 0.f) {
+    const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
+    // 16-byte stores need 16-byte aligned rows (every caller of the hot path has them; otherwise the element loop below)
+    const bool vec_ok = interior && (ldo & 3) == 0 && rlt_aligned16_dev(out) &&
+                        (to_slab || ((!g.bias || rlt_aligned16_dev(g.bias)) && (!g.bias2 || rlt_aligned16_dev(g.bias2))));
+    if (vec_ok && g.drop_p <= 0.f && !(g.mask && (relu || accum || g.bits_in || g.bits_out)) &&
+        !(g.bits_out && (!relu || accum || to_slab)) && !(g.bits_in && (relu || accum || to_slab))) {
+        // f(v, row, col0, dst, i, j, q) -> the float4 to store at row `row`, columns col0..col0+3
         auto tile = [&](auto f) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int col = cbase + j * 32 + l31;
+                float4 bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c0 = cbase + j * 32 + 8 * q + 4 * hh;
+                    if (!to_slab && g.bias) bv[q] = *reinterpret_cast<const float4*>(g.bias + c0);
+                    if (!to_slab && g.bias2) bv[q] = f4add4(bv[q], *reinterpret_cast<const float4*>(g.bias2 + c0));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rbase + i * 32 + l31;
+                    float* rowp = out + (size_t)row * ldo + cbase + j * 32 + 4 * hh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4* dst = reinterpret_cast<float4*>(rowp + 8 * q);
+                        *dst = f(f4add4(f4(acc[i][j], q), bv[q]), row, cbase + j * 32 + 8 * q + 4 * hh, dst, i, j, q);
+                    }
+                }
+            }
+        };
+        if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) {
+            tile([](float4 v, int, int, const float4*, int, int, int) { return v; });
+            return;
+        }
+        if (accum && !relu && !g.mask && !g.bits_in) {
+            tile([](float4 v, int, int, const float4* d, int, int, int) { return f4add4(v, *d); });
+            return;
+        }
+        if (relu && !accum && !g.mask && !g.bits_in) {
+            // bits: this lane's 16 columns of the row's 32-column mask word, the other half comes from lane ^ 32
+            uint32_t w[2][NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) w[i][j] = 0u;
+            tile([&](float4 v, int, int, const float4*, int i, int j, int q) {
+                v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                w[i][j] |= pos4(v) << (8 * q + 4 * hh);
+                return v;
+            });
+            if (g.bits_out) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    uint32_t* wp = g.bits_out + (size_t)(rbase + i * 32 + l31) * g.ldbits + (cbase >> 5);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const uint32_t full = w[i][j] | (uint32_t)__shfl_xor((int)w[i][j], 32, 64);
+                        if (hh == (j & 1)) wp[j] = full;          // the two lane halves share the stores
+                    }
+                }
+            }
+            return;
+        }
+        if (g.bits_in) {
+            const float sc = g.mask_scale;
+            uint32_t w[2][NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t* wp = g.bits_in + (size_t)(rbase + i * 32 + l31) * g.ldbits + (cbase >> 5);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) w[i][j] = wp[j];
+            }
+            tile([&](float4 v, int, int, const float4*, int i, int j, int q) {
+                const uint32_t m = w[i][j] >> (8 * q + 4 * hh);
+                return make_float4((m & 1u) ? v.x * sc : 0.f, (m & 2u) ? v.y * sc : 0.f, (m & 4u) ? v.z * sc : 0.f, (m & 8u) ? v.w * sc : 0.f);
+            });
+            return;
+        }
+        if (g.mask && (g.ldmask & 3) == 0 && rlt_aligned16_dev(g.mask)) {
+            const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
+            tile([=](float4 v, int row, int col, const float4*, int, int, int) {
+                const float4 m = *reinterpret_cast<const float4*>(mk + (size_t)row * ldm + col);
+                return make_float4(m.x > 0.f ? v.x * sc : 0.f, m.y > 0.f ? v.y * sc : 0.f, m.z > 0.f ? v.z * sc : 0.f, m.w > 0.f ? v.w * sc : 0.f);
+            });
+            return;
+        }
+    }
+    // interior tiles of the FFN hidden product in train mode: bias + ReLU + dropout (+ the 1-bit mask of what
+    // survived both).  One row hash per lane and MFMA block; the column hashes of the two lane halves are wave-uniform
+    // (scalar unit)
+    if (vec_ok && g.drop_p > 0.f && relu && !accum && !g.mask && !g.bits_in && !to_slab) {
+        const float inv_keep = 1.f / (1.f - g.drop_p);
+        const uint32_t thr = g.drop_thr, seed = g.seed;
+        const int cb = __builtin_amdgcn_readfirstlane(cbase);
+        uint32_t hr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hr[i] = rlt_row_hash(seed, (uint32_t)(rbase + i * 32 + l31));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            uint32_t w[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c_lo = cb + j * 32 + 8 * q;
+                const int c0 = c_lo + 4 * hh;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + c0);
+                if (g.bias2) bv = f4add4(bv, *reinterpret_cast<const float4*>(g.bias2 + c0));
+                uint32_t hc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select into one
+                    // per-lane hash on the VALU)
+                    const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_col_hash(seed, (uint32_t)(c_lo + e)));
+                    const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_col_hash(seed, (uint32_t)(c_lo + 4 + e)));
+                    hc[e] = hh ? h1 : h0;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float4 v = f4add4(f4(acc[i][j], q), bv);
+                    v.x = rlt_keep_rc(hr[i], hc[0], thr) ? fmaxf(v.x, 0.f) * inv_keep : 0.f;
+                    v.y = rlt_keep_rc(hr[i], hc[1], thr) ? fmaxf(v.y, 0.f) * inv_keep : 0.f;
+                    v.z = rlt_keep_rc(hr[i], hc[2], thr) ? fmaxf(v.z, 0.f) * inv_keep : 0.f;
+                    v.w = rlt_keep_rc(hr[i], hc[3], thr) ? fmaxf(v.w, 0.f) * inv_keep : 0.f;
+                    w[i] |= pos4(v) << (8 * q + 4 * hh);
+                    *reinterpret_cast<float4*>(out + (size_t)(rbase + i * 32 + l31) * ldo + c0) = v;
+                }
+            }
+            if (g.bits_out) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t full = w[i] | (uint32_t)__shfl_xor((int)w[i], 32, 64);
+                    if (hh == (j & 1)) g.bits_out[(size_t)(rbase + i * 32 + l31) * g.ldbits + ((cb + j * 32) >> 5)] = full;
+                }
+            }
+        }
+        return;
+    }
+    // edge tiles and everything else: one element at a time
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = rbase + i * 32 + l31;
+            uint32_t word = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = cbase + j * 32 + acc_row(r, hh);
+                if (row >= g.M || col >= g.N) continue;
                 float bv = 0.f;
                 if (!to_slab) {
                     if (g.bias) bv += g.bias[col];
                     if (g.bias2) bv += g.bias2[col];
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row0 = rbase + i * 32 + 4 * hh;
-                    float* dst = out + (size_t)row0 * ldo + col;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        dst[(size_t)dr * ldo] = f(acc[i][j][r] + bv, row0 + dr, col, dst + (size_t)dr * ldo);
-                    }
-                }
-            }
-        };
-        const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
-        if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) { tile([](float v, int, int, const float*) { return v; }); return; }
-        if (relu && !accum && !g.mask && !g.bits_out && !g.bits_in) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
-        if (accum && !relu && !g.mask && !g.bits_in) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
-        if (g.bits_out && relu && !accum && !g.mask && !to_slab) {
-            uint32_t* bo = g.bits_out; const int ldw = g.ldbits;
-            tile([=](float v, int row, int col, const float*) {
-                v = fmaxf(v, 0.f);
-                const unsigned long long bal = __ballot(v > 0.f);
-                if (l31 == 0) bo[(size_t)row * ldw + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
-                return v;
-            });
-            return;
-        }
-        if (g.bits_in && !relu && !accum && !g.mask && !to_slab) {
-            const uint32_t* bi = g.bits_in; const int ldw = g.ldbits; const float sc = g.mask_scale;
-            tile([=](float v, int row, int col, const float*) {
-                return ((bi[(size_t)row * ldw + (col >> 5)] >> (col & 31)) & 1u) ? v * sc : 0.f;
-            });
-            return;
-        }
-        if (g.mask && !relu && !accum && !g.bits_in && !g.bits_out) {
-            const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
-            tile([=](float v, int row, int col, const float*) { return mk[(size_t)row * ldm + col] > 0.f ? v * sc : 0.f; });
-            return;
-        }
-    }
-    // interior tiles of the FFN hidden product in train mode: bias + ReLU + dropout (+ the 1-bit mask of what
-    // survived both).  Row hashes of the two half-wave rows are wave-uniform (scalar unit); one column hash per lane
-    if (interior && g.drop_p > 0.f && (g.flags & RLT_GEMM_RELU) && !(g.flags & RLT_GEMM_ACCUMULATE) && !g.mask && !g.bits_in &&
-        !to_slab) {
-        const float inv_keep = 1.f / (1.f - g.drop_p);
-        const uint32_t thr = g.drop_thr, seed = g.seed;
-        const int rb = __builtin_amdgcn_readfirstlane(rbase);
-        auto tile = [&](auto with_bits) {
-            uint32_t hc[NJ];
-            float bv[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = cbase + j * 32 + l31;
-                hc[j] = rlt_col_hash(seed, (uint32_t)col);
-                bv[j] = 0.f;
-                if (g.bias) bv[j] += g.bias[col];
-                if (g.bias2) bv[j] += g.bias2[col];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row_lo = rb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select below into
-                    // one per-lane hash of row_lo + 4*hh on the VALU: 64 hashes and as many live registers per lane)
-                    const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)row_lo));
-                    const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)(row_lo + 4)));
-                    const uint32_t hr = hh ? h1 : h0;
-                    const int row = row_lo + 4 * hh;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int col = cbase + j * 32 + l31;
-                        float v = fmaxf(acc[i][j][r] + bv[j], 0.f);
-                        v = rlt_keep_rc(hr, hc[j], thr) ? v * inv_keep : 0.f;
-                        if (decltype(with_bits)::value) {
-                            const unsigned long long bal = __ballot(v > 0.f);
-                            if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
-                        }
-                        out[(size_t)row * ldo + col] = v;
-                    }
-                }
-            }
-        };
-        if (g.bits_out) tile(BoolTag<true>{}); else tile(BoolTag<false>{});
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = cbase + j * 32 + l31;
-        if (col >= g.N) continue;
-        float bv = 0.f;
-        if (!to_slab) {
-            if (g.bias) bv += g.bias[col];
-            if (g.bias2) bv += g.bias2[col];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + i * 32 + acc_row(r, hh);
-                if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 float* dst = out + (size_t)row * ldo + col;
                 if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
                 if (!to_slab && g.bits_in) v = ((g.bits_in[(size_t)row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? v * g.mask_scale : 0.f;
-                if (!to_slab && g.bits_out) {
-                    const unsigned long long bal = __ballot(v > 0.f);
-                    if (l31 == 0) g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(hh ? (bal >> 32) : bal);
-                }
+                if (v > 0.f) word |= 1u << (col & 31);
                 *dst = v;
+            }
+            if (!to_slab && g.bits_out) {            // N % 32 == 0 (rlt_gemm_bits): a word's 32 columns are all in range
+                const uint32_t full = word | (uint32_t)__shfl_xor((int)word, 32, 64);
+                if (hh == 0 && row < g.M && cbase + j * 32 < g.N) g.bits_out[(size_t)row * g.ldbits + ((cbase + j * 32) >> 5)] = full;
             }
         }
     }
@@ -377,10 +432,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
             const int kk = (2 * ks + hh) * LDT;
             const float a0 = a_[kk], a1 = a_[kk + 32];
             const float b0 = b_[kk], b1 = b_[kk + 32];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            // operands swapped: the accumulators hold C transposed (write_output_t)
+            acc[0][0] = mfma32(b0, a0, acc[0][0]);
+            acc[0][1] = mfma32(b1, a0, acc[0][1]);
+            acc[1][0] = mfma32(b0, a1, acc[1][0]);
+            acc[1][1] = mfma32(b1, a1, acc[1][1]);
         }
         if (more) consume(k0 + BK, buf ^ 1);
         __syncthreads();
@@ -588,9 +644,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    // operands swapped: the accumulators hold C transposed (write_output_t)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -763,9 +820,10 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
             if (step == 2) load_a(1, 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[step & 1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
+                // operands swapped: the accumulators hold C transposed (write_output_t)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[step & 1], al[ks][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[step & 1], ah[ks][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[step & 1], ah[ks][i], acc[i][j], 0, 0, 0);
             }
             if (step >= 4 && do_stash) {
                 if (step == 4 && want_cs) {

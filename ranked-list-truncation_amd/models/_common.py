@@ -62,9 +62,8 @@ def check_dropout(module, p):
 
 
 def bilstm(x_pm, params, S, B):
-    """2 stacked bidirectional layers, position-major in and out."""
-    h = ops.bilstm_layer(x_pm, params, 0, S, B)
-    return ops.bilstm_layer(h, params, 1, S, B)
+    """2 stacked bidirectional layers, position-major in and out (one call into the library per direction of travel)."""
+    return ops.bilstm(x_pm, params, S, B)
 
 
 def encoder(x_pm, params, n_head, S, B, drop_p=0.0):

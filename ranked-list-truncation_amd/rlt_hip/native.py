@@ -84,7 +84,47 @@ _SIGNATURES = {
     "rlt_mmoe_mix_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "rlt_mmoe_mix_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "rlt_adam_step": (c_int, [P, P, P, P, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float, P]),
+    # path-level entry points (one call per module forward / backward)
+    "rlt_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rlt_encoder_layer_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, c_size_t, P]),
+    "rlt_encoder_layer_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, P, P, c_size_t, P]),
+    "rlt_bilstm_fwd": (c_int, [P, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, P]),
+    "rlt_bilstm_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, P]),
 }
+OP_ENCODER_STASH, OP_ENCODER_FWD_WS, OP_ENCODER_BWD_WS, OP_BILSTM_STASH, OP_BILSTM_WS = 1, 2, 3, 4, 5
+ENCODER_FIELDS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "norm1_weight", "norm1_bias",
+                  "linear1_weight", "linear1_bias", "linear2_weight", "linear2_bias", "norm2_weight", "norm2_bias")
+
+
+class EncoderPtrs(ctypes.Structure):
+    """rlt_encoder_weights / rlt_encoder_grads: 12 device pointers in ENCODER_FIELDS order."""
+    _fields_ = [(f, c_void_p) for f in ENCODER_FIELDS]
+
+
+class LstmLayerPtrs(ctypes.Structure):
+    """rlt_lstm_layer_weights / rlt_lstm_layer_grads: w_ih[2], w_hh[2], b_ih[2], b_hh[2] (0 = forward, 1 = reverse)."""
+    _fields_ = [("w_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_ih", c_void_p * 2), ("b_hh", c_void_p * 2)]
+
+
+def encoder_ptrs(tensors):
+    return EncoderPtrs(*[t.data_ptr() for t in tensors])
+
+
+def lstm_ptrs(layers):
+    """layers: per layer (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r) -> array of LstmLayerPtrs."""
+    arr = (LstmLayerPtrs * len(layers))()
+    for i, (wif, whf, bif, bhf, wir, whr, bir, bhr) in enumerate(layers):
+        arr[i].w_ih[0], arr[i].w_ih[1] = wif.data_ptr(), wir.data_ptr()
+        arr[i].w_hh[0], arr[i].w_hh[1] = whf.data_ptr(), whr.data_ptr()
+        arr[i].b_ih[0], arr[i].b_ih[1] = bif.data_ptr(), bir.data_ptr()
+        arr[i].b_hh[0], arr[i].b_hh[1] = bhf.data_ptr(), bhr.data_ptr()
+    return arr
+
+
+def byte_buffer(nbytes, device):
+    """256-byte aligned device buffer of at least nbytes (torch's caching allocator aligns to 512)."""
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None
@@ -104,7 +144,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.rlt_abi_version() != 1:
+    if lib.rlt_abi_version() != 2:
         raise RuntimeError("librlt_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -42,6 +42,7 @@ class KernelTimer:
 
 _SEED_COUNTER = [0]
 _SEED_STREAM = [0]
+KERNEL_LEVEL_ENCODER = [False]      # tests: run the encoder layer launch by launch from the host (EncoderLayerKernelsFn)
 
 
 def set_seed_stream(stream_id):
@@ -257,7 +258,57 @@ def list_attention(qkv, S, B, H, drop_p=0.0):
 
 # ------------------------------------------------------------------------------ whole encoder layer
 class EncoderLayerFn(Function):
-    """One post-norm nn.TransformerEncoderLayer (list-axis attention, ReLU FFN) as ONE tape node.
+    """One post-norm nn.TransformerEncoderLayer (list-axis attention, ReLU FFN) as ONE tape node on the path-level
+    entry points rlt_encoder_layer_fwd / _bwd: the launch sequence (in_proj, attention, out_proj, residual+LayerNorm,
+    the FFN pair with its 1-bit ReLU mask, residual+LayerNorm), the stash layout and the in-place accumulation of the
+    two fan-out gradients live in the library (csrc/path.hip); here: buffers and the tape."""
+
+    @staticmethod
+    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, S, B, H, eps, drop_p, seeds):
+        T, E = x.shape
+        FF = w1.shape[0]
+        if T != S * B or in_w.shape != (3 * E, E) or w2.shape != (E, FF):
+            raise RuntimeError(f"encoder layer: x {tuple(x.shape)} does not match S*B = {S * B} / the layer's weights")
+        weights = (in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)
+        stash_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0)
+        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 0)
+        stash = N.byte_buffer(stash_bytes, x.device)
+        ws = N.byte_buffer(ws_bytes, x.device)
+        y = _empty((T, E), x)
+        sarr = (N.c_uint32 * 4)(*seeds)
+        wp = N.encoder_ptrs(weights)
+        _launch("encoder_fwd", lambda: call("rlt_encoder_layer_fwd", ptr(x), N.ctypes.byref(wp), S, B, E, H, FF, eps, drop_p, sarr,
+                                            ptr(y), ptr(stash), stash_bytes, ptr(ws), ws_bytes, stream()))
+        ctx.cfg = (S, B, E, H, FF, eps, drop_p, tuple(seeds), stash_bytes)
+        ctx.stash = stash
+        ctx.save_for_backward(x, *weights)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *weights = ctx.saved_tensors
+        S, B, E, H, FF, eps, drop_p, seeds, stash_bytes = ctx.cfg
+        if ctx.stash is None:
+            raise RuntimeError("EncoderLayerFn.backward frees its stash and can run only once")
+        dy = N.f32c(dy)
+        dx = torch.empty_like(x)
+        grads = [torch.empty_like(w) for w in weights]
+        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1 if drop_p > 0 else 0)
+        ws = N.byte_buffer(ws_bytes, x.device)
+        sarr = (N.c_uint32 * 4)(*seeds)
+        wp, gp = N.encoder_ptrs(weights), N.encoder_ptrs(grads)
+        _launch("encoder_bwd", lambda: call("rlt_encoder_layer_bwd", ptr(x), N.ctypes.byref(wp), S, B, E, H, FF, eps, drop_p, sarr,
+                                            ptr(dy), ptr(ctx.stash), stash_bytes, ptr(dx), N.ctypes.byref(gp),
+                                            ptr(ws), ws_bytes, stream()))
+        ctx.stash = None
+        return (dx, *grads, None, None, None, None, None, None)
+
+
+class EncoderLayerKernelsFn(Function):
+    """The encoder layer composed from the KERNEL-level entry points, launch by launch, on the host: the same launches
+    in the same order as rlt_encoder_layer_fwd / _bwd (csrc/path.hip) make inside the library.  Not the product path -
+    it exists so that bench.py can bracket the three attention launches of a REAL training step with HIP events
+    (`KernelTimer.active`), and as a cross-check of the path-level composition in the tests.
 
     Same kernels as LinearFn / ListAttentionFn / AddLayerNormFn / FFNFn chained by hand; what the single node buys is
     the two fan-out points of the layer (x feeds in_proj and the first residual; LN1's output feeds the FFN and the
@@ -366,92 +417,75 @@ def encoder_layer(x, layer, S, B, H, drop_p=0.0, eps=1e-5):
     """`layer`: a ParamTree mirror of nn.TransformerEncoderLayer."""
     att = layer.self_attn
     seeds = tuple(next_seed() for _ in range(4)) if drop_p > 0 else (0, 0, 0, 0)
-    return EncoderLayerFn.apply(x, att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias,
+    fn = EncoderLayerKernelsFn if (KernelTimer.active is not None or KERNEL_LEVEL_ENCODER[0]) else EncoderLayerFn
+    return fn.apply(x, att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias,
                                 layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
                                 layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias,
                                 S, B, H, eps, drop_p, seeds)
 
 
-# ------------------------------------------------------------------------------ BiLSTM layer (H = 128)
-class BiLSTMLayerFn(Function):
-    """One bidirectional LSTM layer on position-major input x (S*B, I) -> (S*B, 256)."""
+def encoder_ffn_hidden(y):
+    """Tests only: the FFN hidden activation (T, FF) inside the stash of the encoder-layer tape node `y` (or the node
+    that produced the tensor `y`); offsets: enc_stash() in csrc/path.hip; valid until that node's backward has run."""
+    node = y.grad_fn if torch.is_tensor(y) else y
+    if type(node).__name__ != "EncoderLayerFnBackward" or node.stash is None:
+        raise RuntimeError("not the output of a live encoder-layer tape node")
+    S, B, E, H, FF = node.cfg[:5]
+    T, rup = S * B, lambda n: (n + 255) // 256 * 256
+    off = rup(T * 3 * E * 4) + rup(T * E * 4) + rup(S * H * B * 4) + rup(T * E * 4) + rup(T * 2 * 4) + rup(T * E * 4)
+    return node.stash[off:off + T * FF * 4].view(torch.float32).view(T, FF)
+
+
+# ------------------------------------------------------------------------------ 2-layer BiLSTM (H = 128)
+class BiLSTMFn(Function):
+    """nn.LSTM(input, 128, num_layers=2, batch_first=True, bidirectional=True) on position-major input x (S*B, I) ->
+    (S*B, 256), ONE tape node on the path-level entry points rlt_bilstm_fwd / _bwd (csrc/path.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, S, B):
+    def forward(ctx, x, S, B, *w):          # w: 16 tensors, per layer w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r
         T, I = x.shape
-        H4 = w_ih_f.shape[0]
-        if H4 != 512 or w_hh_f.shape != (512, 128):
+        if len(w) != 16:
+            raise RuntimeError("BiLSTMFn takes the 16 parameters of a 2-layer bidirectional LSTM")
+        if w[0].shape[0] != 512 or w[1].shape != (512, 128):
             raise RuntimeError("the HIP BiLSTM kernel is specialised for hidden_size=128 (as the reference hard-codes)")
-        if w_ih_f.shape[1] != I or w_ih_r.shape[1] != I or T != S * B:
-            raise RuntimeError(f"BiLSTM input has {I} features x {T} rows; the layer was built for "
-                               f"{w_ih_f.shape[1]} features and S*B = {S * B} rows")
-        gates = _empty((T, 2 * H4), x)
+        if w[0].shape[1] != I or w[4].shape[1] != I or w[8].shape[1] != 256 or T != S * B:
+            raise RuntimeError(f"BiLSTM input has {I} features x {T} rows; the layers were built for "
+                               f"{w[0].shape[1]} features and S*B = {S * B} rows")
+        stash_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, I, 0, 0, 0)
+        ws_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, I, 0, 0, 0)
+        stash = N.byte_buffer(stash_bytes, x.device)
+        ws = N.byte_buffer(ws_bytes, x.device)
         h = _empty((T, 256), x)
-        c = _empty((T, 256), x)
-        if I <= 3:
-            # narrow input (layer 0): the projection is formed inside the recurrence, no pre-activation round trip
-            call("rlt_bilstm_rec_fwd_x", ptr(x), I, ptr(w_ih_f), ptr(b_ih_f), ptr(b_hh_f), ptr(w_ih_r), ptr(b_ih_r),
-                 ptr(b_hh_r), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(gates), ptr(h), ptr(c), stream())
-        else:
-            # input projections of both directions as one product (x is read once), biases b_ih + b_hh folded in
-            w_cat = torch.cat((w_ih_f, w_ih_r), 0)
-            gemm(0, 1, T, 2 * H4, I, x, I, w_cat, I, gates, 2 * H4,
-                 bias=torch.cat((b_ih_f, b_ih_r)), bias2=torch.cat((b_hh_f, b_hh_r)))
-            call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w_hh_f), ptr(w_hh_r), S, B, ptr(h), ptr(c), stream())
-        ctx.dims = (S, B, I)
-        ctx.save_for_backward(x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h)
-        ctx.used = False
+        wp = N.lstm_ptrs([w[0:8], w[8:16]])
+        _launch("bilstm_fwd", lambda: call("rlt_bilstm_fwd", ptr(x), I, wp, S, B, ptr(h), ptr(stash), stash_bytes,
+                                           ptr(ws), ws_bytes, stream()))
+        ctx.cfg = (S, B, I, stash_bytes, ws_bytes)
+        ctx.stash = stash
+        ctx.save_for_backward(x, h, *w)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        if ctx.used:
-            raise RuntimeError("BiLSTMLayerFn.backward overwrites its stash in place and can run only once")
-        ctx.used = True
-        x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, c, h = ctx.saved_tensors
-        S, B, I = ctx.dims
-        T = S * B
+        if ctx.stash is None:
+            raise RuntimeError("BiLSTMFn.backward overwrites its stash in place and can run only once")
+        x, h, *w = ctx.saved_tensors
+        S, B, I, stash_bytes, ws_bytes = ctx.cfg
         dh = N.f32c(dh)
-        # gates <- d(pre-activation gates), in place
-        call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w_hh_f), ptr(w_hh_r), ptr(dh), S, B, stream())
-        dA = gates
-        db = _empty((1024,), x)
-        grads_w = []
-        dw_ih_both = None
-        if I <= 3:
-            # narrow input: dW_ih of both directions and the bias gradients in ONE streaming pass over dA
-            dw_ih_both = _empty((1024, I), x)
-            ws_bytes = query("rlt_narrow_dw_workspace", T, 1024)
-            ws = workspace(ws_bytes, x.device)
-            call("rlt_narrow_dw", ptr(dA), 1024, ptr(x), I, I, T, 1024, ptr(dw_ih_both), ptr(db), ptr(ws), ws_bytes, stream())
-        else:
-            # both directions in one product; the bias gradient (column sums of dA) rides on it
-            dw_ih_both = _empty((1024, I), x)
-            gemm(1, 0, 1024, I, T, dA, 1024, x, I, dw_ih_both, I, colsum_a=db)
-        for d, (w_ih, _w_hh) in enumerate(((w_ih_f, w_hh_f), (w_ih_r, w_hh_r))):
-            dw_ih = dw_ih_both[512 * d:512 * (d + 1)]
-            dw_hh = _empty((512, 128), x) if S > 1 else torch.zeros((512, 128), dtype=torch.float32, device=x.device)
-            if S > 1:
-                K = T - B
-                if d == 0:   # h_{t-1} of position s is the row block of position s-1
-                    gemm(1, 0, 512, 128, K, dA, 1024, h, 256, dw_hh, 128, a_off=B * 1024, b_off=0)
-                else:        # reverse direction: h_{t-1} of position s is position s+1
-                    gemm(1, 0, 512, 128, K, dA, 1024, h, 256, dw_hh, 128, a_off=512, b_off=B * 256 + 128)
-            grads_w.append((dw_ih, dw_hh))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _empty((T, I), x)
-            gemm(0, 0, T, I, 1024, dA, 1024, torch.cat((w_ih_f, w_ih_r), 0), I, dx, I)     # one product over both directions
-        db_f, db_r = db[:512], db[512:]
-        (dwi_f, dwh_f), (dwi_r, dwh_r) = grads_w
-        return dx, dwi_f, dwh_f, db_f, db_f, dwi_r, dwh_r, db_r, db_r, None, None
+        grads = [torch.empty_like(t) for t in w]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = N.byte_buffer(ws_bytes, x.device)
+        wp, gp = N.lstm_ptrs([w[0:8], w[8:16]]), N.lstm_ptrs([grads[0:8], grads[8:16]])
+        _launch("bilstm_bwd", lambda: call("rlt_bilstm_bwd", ptr(x), I, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
+                                           ptr(dx), gp, ptr(ws), ws_bytes, stream()))
+        ctx.stash = None
+        return (dx, None, None, *grads)
 
 
-def bilstm_layer(x, params, layer, S, B):
-    p = lambda n: getattr(params, f"{n}_l{layer}")
-    pr = lambda n: getattr(params, f"{n}_l{layer}_reverse")
-    return BiLSTMLayerFn.apply(x, p("weight_ih"), p("weight_hh"), p("bias_ih"), p("bias_hh"),
-                               pr("weight_ih"), pr("weight_hh"), pr("bias_ih"), pr("bias_hh"), S, B)
+def bilstm(x, params, S, B):
+    """`params`: a ParamTree mirror of the reference's nn.LSTM (state_dict names weight_ih_l0 ... bias_hh_l1_reverse)."""
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    w = [getattr(params, f"{n}_l{layer}{suffix}") for layer in (0, 1) for suffix in ("", "_reverse") for n in names]
+    return BiLSTMFn.apply(x, S, B, *w)
 
 
 # ------------------------------------------------------------------------------ layout

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(native):
     lib = native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rlt_abi_version() == 1
+    assert lib.rlt_abi_version() == 2
     assert b"workspace" in lib.rlt_error_string(-3)
 
 
@@ -50,6 +50,36 @@ def test_argument_errors_are_reported_not_crashed(native):
     assert native.query("rlt_wass_loss_workspace", 63, 100) > 2 * 63 * 63 * 4
     assert lib.rlt_bicut_loss(None, None, 1, 1, 1, 0.65, 0.1, None, None, None, None) == -1
     assert native.query("rlt_narrow_dw_workspace", 1228800, 1024) > 0
+    # the fused loss + metrics pass and the penalty forms
+    assert lib.rlt_loss_metrics(None, None, None, 1, 1, 0, -1.0, 3, 0.85, -1.0, None, None, None, None, None, None, None, None) == -1
+    assert lib.rlt_cut_metrics_ex(None, None, None, 1, 1, -1.0, None, None, None, None, None) == -1
+
+
+def test_path_level_entry_points(native):
+    """rlt_encoder_layer_fwd/bwd, rlt_bilstm_fwd/bwd, rlt_workspace_bytes: sizes are consistent with the
+    documented stash layout and bad arguments are reported (no GPU needed)."""
+    N = native
+    lib = N.load()
+    S, B, E, H, FF = 300, 4096, 256, 4, 2048
+    T = S * B
+    stash = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0)
+    rup = lambda n: (n + 255) // 256 * 256
+    floats = rup(T * 3 * E * 4) + 4 * rup(T * E * 4) + rup(S * H * B * 4) + 2 * rup(T * 2 * 4) + rup(T * FF * 4)
+    bits = rup(T * FF // 8)
+    images = rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H))
+    assert stash == floats + bits + images
+    ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0)
+    ws1 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1)
+    assert ws1 - ws0 >= T * E * 4                       # train-mode dropout keeps the branch gradients apart
+    assert ws0 >= T * E * 4 + T * FF * 4                # dz2 + dhid
+    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, 3, 0, 0, 0) == 2 * (rup(T * 1024 * 4) + rup(T * 256 * 4)) + rup(T * 256 * 4)
+    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, 3, 0, 0, 0) > T * 256 * 4
+    assert N.query("rlt_workspace_bytes", 99, S, B, E, H, FF, 0) == 0
+    assert N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 250, 4, FF, 0) == 0          # E % H != 0
+    assert lib.rlt_encoder_layer_fwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, 0, None) == -1
+    assert lib.rlt_encoder_layer_bwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, None, None, 0, None) == -1
+    assert lib.rlt_bilstm_fwd(None, 3, None, 1, 1, None, None, 0, None, 0, None) == -1
+    assert lib.rlt_bilstm_bwd(None, 3, None, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
 
 
 def test_models_mirror_reference_state_dict():

@@ -901,11 +901,7 @@ def scale_ops():
 
 def _saved_hidden(y):
     """The FFN hidden activation (T, 2048) the encoder-layer tape node of `y` keeps for its backward."""
-    node = y.grad_fn
-    assert type(node).__name__ == "EncoderLayerFnBackward", type(node).__name__
-    hid = [t for t in node.saved_tensors if t is not None and t.dim() == 2 and t.shape == (y.shape[0], 2048)]
-    assert len(hid) == 1
-    return hid[0]
+    return ops.encoder_ffn_hidden(y)
 
 
 @section
@@ -1063,15 +1059,13 @@ def _encoder_nodes(outs):
     found, seen, stack = {}, set(), [o.grad_fn for o in outs if o.grad_fn is not None]
     while stack:
         node = stack.pop()
-        if node is None or id(node) in seen:
+        if node is None or node in seen:
             continue
-        seen.add(id(node))
+        seen.add(node)              # the node itself (not its id): keeps the python wrapper alive, ids are not reused
         if type(node).__name__ == "EncoderLayerFnBackward":
-            saved = [t for t in node.saved_tensors if t is not None]
-            w1 = [t for t in saved if t.dim() == 2 and t.shape[0] == 2048 and t.shape[1] <= 512]
-            hid = [t for t in saved if t.dim() == 2 and t.shape[1] == 2048 and t.shape[0] != w1[0].shape[1]]
-            assert len(w1) == 1 and len(hid) == 1, [tuple(t.shape) for t in saved]
-            found[w1[0].data_ptr()] = (hid[0] > 0).cpu()
+            w1 = node.saved_tensors[7]                     # x, then the 12 weights in rlt_encoder_weights order
+            assert w1.dim() == 2 and w1.shape[0] == 2048, tuple(w1.shape)
+            found[w1.data_ptr()] = (ops.encoder_ffn_hidden(node) > 0).cpu()
         stack.extend(fn for fn, _ in node.next_functions)
     return found
 
@@ -1319,6 +1313,38 @@ def trainer_bookkeeping():
                                                                        "test/loss_epoch", "test/F1_epoch", "test/DCG_epoch"} else 1.0, 0)
             report(f"Trainer {name} train/loss_step count and steps", 0.0 if [r["step"] for r in tags["train/loss_step"]] == list(range(EPOCHS * steps_per_epoch)) else 1.0, 0)
             report(f"Trainer {name} test/F1_epoch scalars", float(np.abs(np.array([r["value"] for r in tags["test/F1_epoch"]]) - np.array([h["test"][1] for h in trainer.history])).max()), 1e-12)
+
+
+
+@section
+def path_level():
+    """The path-level entry points (rlt_encoder_layer_fwd/bwd: launches composed inside the library) against the same
+    layer driven launch by launch from the host through the kernel-level entry points: bit-identical outputs and
+    gradients, with and without train-mode dropout (same seeds)."""
+    for (B, S, E, H, p_drop) in [(33, 7, 256, 4, 0.0), (70, 5, 128, 8, 0.0), (64, 4, 256, 4, 0.3), (300, 3, 128, 8, 0.2)]:
+        torch.manual_seed(B)
+        layer = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dropout=p_drop)
+        from models._common import ParamTree
+        x = torch.randn(S * B, E)
+        dy = torch.randn(S * B, E)
+        res = []
+        for kernel_level in (False, True):
+            pl = ParamTree(layer).to(dev)
+            xin = x.clone().to(dev).requires_grad_(True)
+            torch.manual_seed(5)
+            ops._SEED_COUNTER[0] = 0
+            ops.KERNEL_LEVEL_ENCODER[0] = kernel_level
+            try:
+                y = ops.encoder_layer(xin, pl, S, B, H, p_drop)
+            finally:
+                ops.KERNEL_LEVEL_ENCODER[0] = False
+            y.backward(dy.to(dev))
+            res.append((type(y.grad_fn).__name__, y.detach(), xin.grad, {n: q.grad for n, q in pl.named_parameters()}))
+        (na, ya, dxa, ga), (nb, yb, dxb, gb) = res
+        report(f"path-level B{B} S{S} E{E} p{p_drop}: tape nodes differ", 0.0 if (na, nb) == ("EncoderLayerFnBackward", "EncoderLayerKernelsFnBackward") else 1.0, 0)
+        report(f"path-level B{B} S{S} E{E} p{p_drop}: y", float((ya - yb).abs().max()), 0)
+        report(f"path-level B{B} S{S} E{E} p{p_drop}: dx", float((dxa - dxb).abs().max()), 0)
+        report(f"path-level B{B} S{S} E{E} p{p_drop}: weight grads", max(float((ga[n] - gb[n]).abs().max()) for n in ga), 0)
 
 
 if __name__ == "__main__":
