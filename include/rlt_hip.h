@@ -170,11 +170,13 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
 /* The FFN pair of rlt_gemm_ex epilogues with a 1-bit-per-element mask instead of the fp32 activation
  * (nn.TransformerEncoderLayer's linear1 -> ReLU -> dropout forward and the dH = (dY W2) * mask backward):
  *   relu_bits_out != NULL (flags must hold RLT_GEMM_RELU): C = dropout(relu(op(A) op(B) + bias)) with the keep mask of
- *     (drop_p, seed) as in rlt_gemm_ex (drop_p = 0: no dropout), and bit (row, col) of
- *     relu_bits_out[row * (N/32) + col/32] = (C > 0), i.e. the element passed the ReLU and was kept;
+ *     (drop_p, seed) as in rlt_gemm_ex (drop_p = 0: no dropout), and the mask bit of element (row, col) = (C > 0), i.e.
+ *     the element passed the ReLU and was kept;
  *   mask_bits_in  != NULL: C = bit ? (op(A) op(B) + bias) * mask_scale : 0   (mask_scale = 1/(1-p); drop_p must be 0).
- * Exactly one of the two; N % 32 == 0; no split-K, no workspace.  The backward product then reads M*N/8 bytes of
- * mask instead of 4*M*N (10 GB at 1,228,800 x 2048). */
+ * Mask layout (private to this pair of calls): packed along ROWS - bit (row & 31) of word [(row >> 5) * N + col];
+ * rlt_gemm_bits_words(M, N) = ceil(M/32) * N words.  Exactly one of the two pointers; N % 32 == 0; no split-K, no
+ * workspace.  The backward product then reads M*N/8 bytes of mask instead of 4*M*N (10 GB at 1,228,800 x 2048). */
+size_t rlt_gemm_bits_words(int M, int N);
 int rlt_gemm_bits(int ta, int tb, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, int flags, float drop_p, uint32_t seed,

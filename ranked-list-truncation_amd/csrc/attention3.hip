@@ -519,9 +519,15 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     };
     issue(0, 0);
     __syncthreads();
+#if defined(RLT_EXP_SETPRIO)
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);        // experiment: static priority for the younger half of the workgroup
+#endif
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
+#if defined(RLT_EXP_IGLP)
+        __builtin_amdgcn_iglp_opt(RLT_EXP_IGLP);
+#endif
         if (wave_live) {
             const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
             const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
@@ -533,6 +539,28 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const uint16_t* dt_lo = dt_hi + T_elems<HD>();
             const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + 2 * QREC);
             const float* Es = Ls + KT;
+#if defined(RLT_EXP_PIPE2)
+            // experiment: the S / dP products of BOTH 32-query sub-tiles first, then the element-wise work and the dV / dK
+            // products per sub-tile (the scheduler may put sub-tile 1's products under sub-tile 0's VALU work)
+            f32x16 sc2[2], dp2[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + acc_row(r, hh);
+                    sc2[sub][r] = Ls[ql];
+                    dp2[sub][r] = DROP ? 0.f : Es[ql];
+                }
+                sc2[sub] = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc2[sub]);
+                dp2[sub] = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp2[sub]);
+            }
+#if RLT_EXP_PIPE2 == 2
+            __builtin_amdgcn_sched_barrier(0);       // all four products issued before any element-wise work
+#endif
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc = sc2[sub], dp = dp2[sub];
+#else
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 // the accumulators start at -lse[q] and -delta[q] (the aux block of the dO record holds them negated),
@@ -547,6 +575,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                 }
                 sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] - lse (Q carries scale*log2e)
                 dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key] (- delta)
+#endif
                 // queries beyond B need no mask: their columns of the transposed Q / dO images are zero, p is finite
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -32,7 +32,11 @@ struct GemmArgs {
     float drop_p; uint32_t drop_thr, seed;   // epilogue dropout on the output (after ReLU), keep -> /(1-p)
     float mask_scale;    // with `mask`: kept elements are multiplied by this (1/(1-p) of the forward dropout)
     int slab_xcd;        // split-K launched as a 1-D grid with K slabs pinned to XCDs (see decode_block)
-    uint32_t* bits_out;  // with RLT_GEMM_RELU: 1 bit per output element (C > 0), row-major, ldbits words per row
+    // 1-bit masks, packed along ROWS: bit (row & 31) of word [(row >> 5) * ldbits + col], ldbits = N.  In the MFMA
+    // accumulator layout a lane owns one column and 16 of the 32 rows of a block (the other 16 sit in lane ^ 32), so a
+    // 32-row x 32-column block is ONE coalesced 128-byte word store / load per wavefront (packed along columns it took a
+    // ballot and a one-lane store per accumulator register: 128 of each per wavefront and 256 x 256 tile)
+    uint32_t* bits_out;  // with RLT_GEMM_RELU: bit = (C > 0)
     const uint32_t* bits_in;   // epilogue mask from such bits: C = bit ? C * mask_scale : 0
     int ldbits;
 };
@@ -153,191 +157,173 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, int tid, const
 }
 
 // ---- shared epilogue: accumulator tiles -> C (or split-K slab), fused bias/ReLU/mask/dropout -------
-// The kernels issue their MFMAs with the operands SWAPPED (the B-tile fragment as the instruction's A operand), so
-// every 32x32 accumulator block holds C TRANSPOSED: lane l31 = ROW of C inside the block, register r = COLUMN
-// (r&3) + 8(r>>2) + 4hh.  Four consecutive registers are then four consecutive columns of one row: the epilogue stores
-// 16 bytes per lane (a wavefront instruction covers 32 rows x 32 B; four of them finish the rows' 128-B lines) where the
-// untransposed layout needed one 4-byte store per element - 128 store instructions per wavefront per 256x256 tile, and
-// the K = 256 products that write 10 GB were bound by issuing them.  The 1-bit ReLU masks fall out of the same layout:
-// a lane owns half the bits of its row's mask word (one cross-half shuffle, one store per row) and reads a row's
-// words with one load.
 // wavefront tile = 64 rows (2 MFMA blocks) x 32*NJ columns at (rbase, cbase); `interior`: the whole workgroup tile is
 // inside C
 template <bool V> struct BoolTag { static constexpr bool value = V; };
-__device__ __forceinline__ float4 f4(const f32x16& a, int q) { return make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]); }
-__device__ __forceinline__ float4 f4add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ uint32_t pos4(float4 v) {
-    return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-}
 template <int NJ>
 __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (&acc)[2][NJ], int rbase, int cbase,
                                                bool interior, int l31, int hh, int z) {
     const bool to_slab = g.slab != nullptr;
     float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
     const int ldo = to_slab ? g.N : g.ldc;
-    const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
-    // 16-byte stores need 16-byte aligned rows (every caller of the hot path has them; otherwise the element loop below)
-    const bool vec_ok = interior && (ldo & 3) == 0 && rlt_aligned16_dev(out) &&
-                        (to_slab || ((!g.bias || rlt_aligned16_dev(g.bias)) && (!g.bias2 || rlt_aligned16_dev(g.bias2))));
-    if (vec_ok && g.drop_p <= 0.f && !(g.mask && (relu || accum || g.bits_in || g.bits_out)) &&
-        !(g.bits_out && (!relu || accum || to_slab)) && !(g.bits_in && (relu || accum || to_slab))) {
-        // f(v, row, col0, dst, i, j, q) -> the float4 to store at row `row`, columns col0..col0+3
+    // interior tiles with one of the common epilogues: the bounds and mode tests are hoisted out of the per-element
+    // loop (tested per element they cost >1 ms of a K = 256 product that writes 10 GB)
+    // Addressing of the interior paths: the row base out + (rb + 32 i + dr) * ldo + cb + 32 j is WAVE-UNIFORM (rb, cb are
+    // made scalar with readfirstlane) and every lane adds the same 32-bit element offset 4 hh ldo + l31 to all of them, so
+    // a store is `global_store_dword v_off, v_data, s[base]` with the bases stepped on the scalar unit.  With the
+    // per-lane 64-bit address arithmetic the compiler generated before (rbase derived from threadIdx in VGPRs), the 128
+    // stores of a wavefront cost ~5 VALU instructions and two address registers each and the epilogue spilled.
+    const int rb = __builtin_amdgcn_readfirstlane(rbase), cb = __builtin_amdgcn_readfirstlane(cbase);
+    const int loff = 4 * hh * ldo + l31;
+    if (interior && g.drop_p <= 0.f) {
         auto tile = [&](auto f) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float4 bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int c0 = cbase + j * 32 + 8 * q + 4 * hh;
-                    if (!to_slab && g.bias) bv[q] = *reinterpret_cast<const float4*>(g.bias + c0);
-                    if (!to_slab && g.bias2) bv[q] = f4add4(bv[q], *reinterpret_cast<const float4*>(g.bias2 + c0));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = rbase + i * 32 + l31;
-                    float* rowp = out + (size_t)row * ldo + cbase + j * 32 + 4 * hh;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float4* dst = reinterpret_cast<float4*>(rowp + 8 * q);
-                        *dst = f(f4add4(f4(acc[i][j], q), bv[q]), row, cbase + j * 32 + 8 * q + 4 * hh, dst, i, j, q);
-                    }
-                }
-            }
-        };
-        if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) {
-            tile([](float4 v, int, int, const float4*, int, int, int) { return v; });
-            return;
-        }
-        if (accum && !relu && !g.mask && !g.bits_in) {
-            tile([](float4 v, int, int, const float4* d, int, int, int) { return f4add4(v, *d); });
-            return;
-        }
-        if (relu && !accum && !g.mask && !g.bits_in) {
-            // bits: this lane's 16 columns of the row's 32-column mask word, the other half comes from lane ^ 32
-            uint32_t w[2][NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) w[i][j] = 0u;
-            tile([&](float4 v, int, int, const float4*, int i, int j, int q) {
-                v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                w[i][j] |= pos4(v) << (8 * q + 4 * hh);
-                return v;
-            });
-            if (g.bits_out) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    uint32_t* wp = g.bits_out + (size_t)(rbase + i * 32 + l31) * g.ldbits + (cbase >> 5);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const uint32_t full = w[i][j] | (uint32_t)__shfl_xor((int)w[i][j], 32, 64);
-                        if (hh == (j & 1)) wp[j] = full;          // the two lane halves share the stores
-                    }
-                }
-            }
-            return;
-        }
-        if (g.bits_in) {
-            const float sc = g.mask_scale;
-            uint32_t w[2][NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t* wp = g.bits_in + (size_t)(rbase + i * 32 + l31) * g.ldbits + (cbase >> 5);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) w[i][j] = wp[j];
-            }
-            tile([&](float4 v, int, int, const float4*, int i, int j, int q) {
-                const uint32_t m = w[i][j] >> (8 * q + 4 * hh);
-                return make_float4((m & 1u) ? v.x * sc : 0.f, (m & 2u) ? v.y * sc : 0.f, (m & 4u) ? v.z * sc : 0.f, (m & 8u) ? v.w * sc : 0.f);
-            });
-            return;
-        }
-        if (g.mask && (g.ldmask & 3) == 0 && rlt_aligned16_dev(g.mask)) {
-            const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
-            tile([=](float4 v, int row, int col, const float4*, int, int, int) {
-                const float4 m = *reinterpret_cast<const float4*>(mk + (size_t)row * ldm + col);
-                return make_float4(m.x > 0.f ? v.x * sc : 0.f, m.y > 0.f ? v.y * sc : 0.f, m.z > 0.f ? v.z * sc : 0.f, m.w > 0.f ? v.w * sc : 0.f);
-            });
-            return;
-        }
-    }
-    // interior tiles of the FFN hidden product in train mode: bias + ReLU + dropout (+ the 1-bit mask of what
-    // survived both).  One row hash per lane and MFMA block; the column hashes of the two lane halves are wave-uniform
-    // (scalar unit)
-    if (vec_ok && g.drop_p > 0.f && relu && !accum && !g.mask && !g.bits_in && !to_slab) {
-        const float inv_keep = 1.f / (1.f - g.drop_p);
-        const uint32_t thr = g.drop_thr, seed = g.seed;
-        const int cb = __builtin_amdgcn_readfirstlane(cbase);
-        uint32_t hr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) hr[i] = rlt_row_hash(seed, (uint32_t)(rbase + i * 32 + l31));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            uint32_t w[2] = {0u, 0u};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c_lo = cb + j * 32 + 8 * q;
-                const int c0 = c_lo + 4 * hh;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + c0);
-                if (g.bias2) bv = f4add4(bv, *reinterpret_cast<const float4*>(g.bias2 + c0));
-                uint32_t hc[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select into one
-                    // per-lane hash on the VALU)
-                    const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_col_hash(seed, (uint32_t)(c_lo + e)));
-                    const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_col_hash(seed, (uint32_t)(c_lo + 4 + e)));
-                    hc[e] = hh ? h1 : h0;
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float4 v = f4add4(f4(acc[i][j], q), bv);
-                    v.x = rlt_keep_rc(hr[i], hc[0], thr) ? fmaxf(v.x, 0.f) * inv_keep : 0.f;
-                    v.y = rlt_keep_rc(hr[i], hc[1], thr) ? fmaxf(v.y, 0.f) * inv_keep : 0.f;
-                    v.z = rlt_keep_rc(hr[i], hc[2], thr) ? fmaxf(v.z, 0.f) * inv_keep : 0.f;
-                    v.w = rlt_keep_rc(hr[i], hc[3], thr) ? fmaxf(v.w, 0.f) * inv_keep : 0.f;
-                    w[i] |= pos4(v) << (8 * q + 4 * hh);
-                    *reinterpret_cast<float4*>(out + (size_t)(rbase + i * 32 + l31) * ldo + c0) = v;
-                }
-            }
-            if (g.bits_out) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t full = w[i] | (uint32_t)__shfl_xor((int)w[i], 32, 64);
-                    if (hh == (j & 1)) g.bits_out[(size_t)(rbase + i * 32 + l31) * g.ldbits + ((cb + j * 32) >> 5)] = full;
-                }
-            }
-        }
-        return;
-    }
-    // edge tiles and everything else: one element at a time
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = rbase + i * 32 + l31;
-            uint32_t word = 0u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = cbase + j * 32 + acc_row(r, hh);
-                if (row >= g.M || col >= g.N) continue;
+                const int col = cb + j * 32 + l31;
                 float bv = 0.f;
                 if (!to_slab) {
                     if (g.bias) bv += g.bias[col];
                     if (g.bias2) bv += g.bias2[col];
                 }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        float* base = out + (size_t)(rb + i * 32 + dr) * ldo + (cb + j * 32);       // scalar
+                        base[loff] = f(acc[i][j][r] + bv, rb + i * 32 + dr + 4 * hh, col, base + loff);
+                    }
+                }
+            }
+        };
+        const bool relu = g.flags & RLT_GEMM_RELU, accum = g.flags & RLT_GEMM_ACCUMULATE;
+        if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) { tile([](float v, int, int, const float*) { return v; }); return; }
+        if (relu && !accum && !g.mask && !g.bits_out && !g.bits_in) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
+        if (accum && !relu && !g.mask && !g.bits_in) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
+        if ((g.bits_out && relu || g.bits_in && !relu) && !accum && !g.mask && !to_slab) {
+            // 1-bit masks (packed along rows): one word per lane and 32 x 32 block, written / read once
+            const float sc = g.mask_scale;
+            auto body = [&](auto wr_tag) {
+            constexpr bool wr = decltype(wr_tag)::value;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = cb + j * 32 + l31;
+                float bv = 0.f;
+                if (g.bias) bv += g.bias[col];
+                if (g.bias2) bv += g.bias2[col];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const size_t widx = (size_t)((rb + i * 32) >> 5) * g.ldbits + (cb + j * 32);      // scalar
+                    uint32_t w = wr ? 0u : (g.bits_in + widx)[l31];
+                    if (!wr) w >>= 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r] + bv;
+                        if (wr) {
+                            v = fmaxf(v, 0.f);
+                            w |= (v > 0.f ? 1u : 0u) << dr;
+                        } else {
+                            v = ((w >> dr) & 1u) ? v * sc : 0.f;
+                        }
+                        (out + (size_t)(rb + i * 32 + dr) * ldo + (cb + j * 32))[loff] = v;
+                    }
+                    if (wr) {
+                        w <<= 4 * hh;
+                        const uint32_t full = w | (uint32_t)__shfl_xor((int)w, 32, 64);
+                        if (hh == 0) (g.bits_out + widx)[l31] = full;
+                    }
+                }
+            }
+            };
+            if (g.bits_out) body(BoolTag<true>{}); else body(BoolTag<false>{});
+            return;
+        }
+        if (g.mask && !relu && !accum && !g.bits_in && !g.bits_out) {
+            const float* mk = g.mask; const int ldm = g.ldmask; const float sc = g.mask_scale;
+            tile([=](float v, int row, int col, const float*) { return mk[(size_t)row * ldm + col] > 0.f ? v * sc : 0.f; });
+            return;
+        }
+    }
+    // interior tiles of the FFN hidden product in train mode: bias + ReLU + dropout (+ the 1-bit mask of what
+    // survived both).  Row hashes of the two half-wave rows are wave-uniform (scalar unit); one column hash per lane
+    if (interior && g.drop_p > 0.f && (g.flags & RLT_GEMM_RELU) && !(g.flags & RLT_GEMM_ACCUMULATE) && !g.mask && !g.bits_in &&
+        !to_slab) {
+        const float inv_keep = 1.f / (1.f - g.drop_p);
+        const uint32_t thr = g.drop_thr, seed = g.seed;
+        auto tile = [&](auto with_bits) {
+            uint32_t hc[NJ];
+            float bv[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = cb + j * 32 + l31;
+                hc[j] = rlt_col_hash(seed, (uint32_t)col);
+                bv[j] = 0.f;
+                if (g.bias) bv[j] += g.bias[col];
+                if (g.bias2) bv[j] += g.bias2[col];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint32_t w[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) w[j] = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row_lo = rb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    // readfirstlane keeps both hashes on the scalar unit (without it hipcc folds the select below into
+                    // one per-lane hash of row_lo + 4*hh on the VALU: 64 hashes and as many live registers per lane)
+                    const uint32_t h0 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)row_lo));
+                    const uint32_t h1 = __builtin_amdgcn_readfirstlane(rlt_row_hash(seed, (uint32_t)(row_lo + 4)));
+                    const uint32_t hr = hh ? h1 : h0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float v = fmaxf(acc[i][j][r] + bv[j], 0.f);
+                        v = rlt_keep_rc(hr, hc[j], thr) ? v * inv_keep : 0.f;
+                        if (decltype(with_bits)::value) w[j] |= (v > 0.f ? 1u : 0u) << acc_row(r, hh);
+                        (out + (size_t)row_lo * ldo + (cb + j * 32))[loff] = v;
+                    }
+                }
+                if (decltype(with_bits)::value) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const uint32_t full = w[j] | (uint32_t)__shfl_xor((int)w[j], 32, 64);
+                        if (hh == 0) (g.bits_out + (size_t)((rb + i * 32) >> 5) * g.ldbits + (cb + j * 32))[l31] = full;
+                    }
+                }
+            }
+        };
+        if (g.bits_out) tile(BoolTag<true>{}); else tile(BoolTag<false>{});
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = cbase + j * 32 + l31;
+        const bool col_ok = col < g.N;
+        float bv = 0.f;
+        if (!to_slab && col_ok) {
+            if (g.bias) bv += g.bias[col];
+            if (g.bias2) bv += g.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t widx = (size_t)((rbase + i * 32) >> 5) * g.ldbits + col;
+            const bool blk_ok = col_ok && rbase + i * 32 < g.M;
+            const uint32_t win = (!to_slab && g.bits_in && blk_ok) ? g.bits_in[widx] : 0u;
+            uint32_t wout = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + i * 32 + acc_row(r, hh);
+                if (row >= g.M || !col_ok) continue;
                 float v = acc[i][j][r];
                 float* dst = out + (size_t)row * ldo + col;
                 if (!to_slab) v = gemm_epilogue(g, v, bv, row, col, dst);
-                if (!to_slab && g.bits_in) v = ((g.bits_in[(size_t)row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? v * g.mask_scale : 0.f;
-                if (v > 0.f) word |= 1u << (col & 31);
+                if (!to_slab && g.bits_in) v = ((win >> acc_row(r, hh)) & 1u) ? v * g.mask_scale : 0.f;
+                wout |= (v > 0.f ? 1u : 0u) << acc_row(r, hh);
                 *dst = v;
             }
-            if (!to_slab && g.bits_out) {            // N % 32 == 0 (rlt_gemm_bits): a word's 32 columns are all in range
-                const uint32_t full = word | (uint32_t)__shfl_xor((int)word, 32, 64);
-                if (hh == 0 && row < g.M && cbase + j * 32 < g.N) g.bits_out[(size_t)row * g.ldbits + ((cbase + j * 32) >> 5)] = full;
+            if (!to_slab && g.bits_out) {          // rows beyond M keep a zero bit
+                const uint32_t full = wout | (uint32_t)__shfl_xor((int)wout, 32, 64);
+                if (hh == 0 && blk_ok) g.bits_out[widx] = full;
             }
         }
     }
@@ -374,7 +360,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float (*As)[BK * LDT] = reinterpret_cast<float (*)[BK * LDT]>(gsm);                    // [2][BK*LDT]
     float (*Bs)[BK * LDT] = reinterpret_cast<float (*)[BK * LDT]>(gsm + 2 * BK * LDT);     // [2][BK*LDT]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
 
@@ -432,11 +418,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
             const int kk = (2 * ks + hh) * LDT;
             const float a0 = a_[kk], a1 = a_[kk + 32];
             const float b0 = b_[kk], b1 = b_[kk + 32];
-            // operands swapped: the accumulators hold C transposed (write_output_t)
-            acc[0][0] = mfma32(b0, a0, acc[0][0]);
-            acc[0][1] = mfma32(b1, a0, acc[0][1]);
-            acc[1][0] = mfma32(b0, a1, acc[1][0]);
-            acc[1][1] = mfma32(b1, a1, acc[1][1]);
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
         }
         if (more) consume(k0 + BK, buf ^ 1);
         __syncthreads();
@@ -577,7 +562,7 @@ template <bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);        // [buf][A_hi | A_lo | B_hi | B_lo][TILE3]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     int bid, zslab;
@@ -644,10 +629,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    // operands swapped: the accumulators hold C transposed (write_output_t)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -741,7 +725,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     int bid, zslab;
@@ -820,10 +804,9 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
             if (step == 2) load_a(1, 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                // operands swapped: the accumulators hold C transposed (write_output_t)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[step & 1], al[ks][i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[step & 1], ah[ks][i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[step & 1], ah[ks][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[step & 1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[step & 1], acc[i][j], 0, 0, 0);
             }
             if (step >= 4 && do_stash) {
                 if (step == 4 && want_cs) {
@@ -1126,7 +1109,7 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     g.mask = relu_mask; g.ldmask = ldmask; g.colsum = colsum_a; g.cs_slab = nullptr;
-    g.bits_out = bits_out; g.bits_in = bits_in; g.ldbits = N / 32;
+    g.bits_out = bits_out; g.bits_in = bits_in; g.ldbits = N;
     g.mask_scale = mask_scale; g.drop_p = drop_p; g.drop_thr = rlt_drop_threshold(drop_p); g.seed = seed;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -1179,6 +1162,8 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
     return gemm_run(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, relu_mask, ldmask, mask_scale, colsum_a,
                     drop_p, seed, nullptr, nullptr, ws, ws_bytes, stream);
 }
+
+size_t rlt_gemm_bits_words(int M, int N) { return M > 0 && N > 0 ? (size_t)rlt_cdiv(M, 32) * N : 0; }
 
 int rlt_gemm_bits(int ta, int tb, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,

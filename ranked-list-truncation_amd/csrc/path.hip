@@ -29,7 +29,7 @@ inline int enc_dims(int S, int B, int E, int H, int FF, EncDims& d) {
 }
 
 // stash written by the forward and read by the backward, in this order (all regions 256-byte aligned):
-//   qkv (T,3E) | att (T,E) | lse (S,H,B) | proj (T,E) | st1 (T,2) | h1 (T,E) | hid (T,FF) | relu bits (T,FF/32) u32 |
+//   qkv (T,3E) | att (T,E) | lse (S,H,B) | proj (T,E) | st1 (T,2) | h1 (T,E) | hid (T,FF) | relu bits (ceil(T/32),FF) u32 |
 //   ff (T,E) | st2 (T,2) | attention tile records (rlt_list_attention_fwd_workspace bytes, split-bf16 mode only)
 struct EncStash {
     float *qkv, *att, *lse, *proj, *st1, *h1, *hid, *ff, *st2;
@@ -48,7 +48,7 @@ inline EncStash enc_stash(const EncDims& d, void* base) {
     s.st1 = c.take(T * 2 * f);
     s.h1 = c.take(T * d.E * f);
     s.hid = c.take(T * d.FF * f);
-    s.bits = d.bits ? c.take<uint32_t>(T * (d.FF / 32) * sizeof(uint32_t)) : nullptr;
+    s.bits = d.bits ? c.take<uint32_t>(rlt_gemm_bits_words((int)T, d.FF) * sizeof(uint32_t)) : nullptr;
     s.ff = c.take(T * d.E * f);
     s.st2 = c.take(T * 2 * f);
     s.images_bytes = rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD);

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "rlt_pair_softmax_bwd": (c_int, [P, P, c_int, c_int, c_float, c_uint32, P, P]),
     "rlt_bicut_loss": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
     "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_gemm_bits_words": (c_size_t, [c_int, c_int]),
     "rlt_gemm_bits": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_float, c_uint32,
                               P, P, c_float, P]),
     "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),

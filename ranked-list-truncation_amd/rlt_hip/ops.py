@@ -87,9 +87,21 @@ def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=
 def gemm_bits(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, bits_out=None, bits_in=None, mask_scale=1.0,
               drop_p=0.0, seed=0):
     """rlt_gemm_bits: ReLU (+ dropout) forward that also emits a 1-bit mask of the surviving elements (bits_out,
-    int32 (M, N/32)), or the masked backward product that consumes it (bits_in, mask_scale = 1/(1-p))."""
+    int32 (ceil(M/32), N): `alloc_relu_bits(M, N, device)`), or the masked backward product that consumes it (bits_in,
+    mask_scale = 1/(1-p))."""
     call("rlt_gemm_bits", ta, tb, M, Nn, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), flags, drop_p, seed,
          ptr(bits_out), ptr(bits_in), mask_scale, stream())
+
+
+def alloc_relu_bits(M, Nn, device):
+    """Buffer for the 1-bit mask of rlt_gemm_bits: packed along rows, bit (row & 31) of word [(row >> 5), col]."""
+    return torch.zeros(((M + 31) // 32, Nn), dtype=torch.int32, device=device)
+
+
+def unpack_relu_bits(bits, M):
+    """(ceil(M/32), N) int32 -> (M, N) bool (tests)."""
+    sh = torch.arange(32, dtype=torch.int32, device=bits.device).view(1, 32, 1)
+    return (((bits.unsqueeze(1) >> sh) & 1).reshape(-1, bits.shape[1])[:M]).bool()
 
 
 def colsum(X, ldx, T, Nn, out, accumulate=0, x_off=0):
@@ -340,7 +352,7 @@ class EncoderLayerKernelsFn(Function):
         if Fh % 32 == 0:
             # 1-bit mask (passed the ReLU and kept by the dropout) for the backward dH product, which then reads
             # T*Fh/8 bytes instead of the 4*T*Fh of `hid`
-            relu_bits = torch.empty((T, Fh // 32), dtype=torch.int32, device=x.device)
+            relu_bits = alloc_relu_bits(T, Fh, x.device)
             gemm_bits(0, 1, T, Fh, E, h1, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, bits_out=relu_bits,
                       drop_p=drop_p, seed=s_ffn)
         else:

@@ -65,7 +65,7 @@ def test_path_level_entry_points(native):
     stash = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0)
     rup = lambda n: (n + 255) // 256 * 256
     floats = rup(T * 3 * E * 4) + 4 * rup(T * E * 4) + rup(S * H * B * 4) + 2 * rup(T * 2 * 4) + rup(T * FF * 4)
-    bits = rup(T * FF // 8)
+    bits = rup(N.query("rlt_gemm_bits_words", T, FF) * 4)
     images = rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H))
     assert stash == floats + bits + images
     ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0)

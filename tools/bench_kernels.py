@@ -70,6 +70,25 @@ def gemms(T=4096 * 300):
         del A, Bm, C
 
 
+def gemm_bits(T=4096 * 300, E=256, Fh=2048):
+    """The FFN pair with the 1-bit mask: linear1 + ReLU forward (writes hid + mask) and the masked dH backward."""
+    x = torch.randn(T, E, device=dev)
+    w1 = torch.randn(Fh, E, device=dev) / 16
+    b1 = torch.randn(Fh, device=dev) / 10
+    hid = torch.empty(T, Fh, device=dev)
+    bits = ops.alloc_relu_bits(T, Fh, dev)
+    ms = timeit(lambda: ops.gemm_bits(0, 1, T, Fh, E, x, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU, bits_out=bits))
+    print(f"gemm_bits ffn1 fwd NT  {T}x{Fh}x{E}: {ms:8.3f} ms  {2.0 * T * Fh * E / ms / 1e9:7.1f} TF/s", flush=True)
+    dy = torch.randn(T, E, device=dev)
+    w2 = torch.randn(E, Fh, device=dev) / 16
+    ms = timeit(lambda: ops.gemm_bits(0, 0, T, Fh, E, dy, E, w2, Fh, hid, Fh, bits_in=bits))
+    print(f"gemm_bits dhid bwd NN  {T}x{Fh}x{E}: {ms:8.3f} ms  {2.0 * T * Fh * E / ms / 1e9:7.1f} TF/s", flush=True)
+    ms = timeit(lambda: ops.gemm(0, 1, T, Fh, E, x, E, w1, E, hid, Fh, bias=b1, flags=N.GEMM_RELU))
+    print(f"gemm      ffn1 relu NT {T}x{Fh}x{E}: {ms:8.3f} ms  {2.0 * T * Fh * E / ms / 1e9:7.1f} TF/s", flush=True)
+    ms = timeit(lambda: ops.gemm(0, 1, T, Fh, E, x, E, w1, E, hid, Fh))
+    print(f"gemm      ffn1 plain NT {T}x{Fh}x{E}: {ms:8.3f} ms  {2.0 * T * Fh * E / ms / 1e9:7.1f} TF/s", flush=True)
+
+
 def lstm(B=4096, S=300):
     T = S * B
     gates = torch.randn(T, 1024, device=dev) * 0.5

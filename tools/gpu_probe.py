@@ -99,11 +99,11 @@ def gemm():
     for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256), (512, 512, 128)]:
         A, W, bias = torch.randn(M, K), torch.randn(Nn, K), torch.randn(Nn)
         H = torch.empty(M, Nn, device=dev)
-        bits = torch.zeros(M, Nn // 32, dtype=torch.int32, device=dev)
+        bits = ops.alloc_relu_bits(M, Nn, dev)
         ops.gemm_bits(0, 1, M, Nn, K, A.to(dev), K, W.to(dev), K, H, Nn, bias=bias.to(dev), flags=N.GEMM_RELU, bits_out=bits)
         ref = torch.relu(A.double() @ W.double().t() + bias.double())
         report(f"gemm_bits relu fwd {M}x{Nn}x{K}", rel(H, ref), mfma_tol(1e-5))
-        unpacked = ((bits.cpu().unsqueeze(2) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(M, Nn).bool()
+        unpacked = ops.unpack_relu_bits(bits, M).cpu()
         report(f"gemm_bits mask bits {M}x{Nn}x{K}", float((unpacked != (H.cpu() > 0)).sum()), 0)
         dY, W2 = torch.randn(M, K), torch.randn(K, Nn)
         dH = torch.empty(M, Nn, device=dev)
@@ -120,7 +120,7 @@ def gemm():
         ops.gemm_bits(0, 1, M, Nn, K, A.to(dev), K, W.to(dev), K, Hd, Nn, bias=bias.to(dev), flags=N.GEMM_RELU, bits_out=bits,
                       drop_p=pd, seed=sd)
         report(f"gemm_bits relu+dropout fwd {M}x{Nn}x{K}", rel(Hd, H.double() * mk.double()), 1e-6)
-        unpacked = ((bits.cpu().unsqueeze(2) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(M, Nn).bool()
+        unpacked = ops.unpack_relu_bits(bits, M).cpu()
         report(f"gemm_bits relu+dropout bits {M}x{Nn}x{K}", float((unpacked != (Hd.cpu() > 0)).sum()), 0)
         report(f"gemm_bits dropout keep fraction {M}x{Nn}x{K}", abs(float((mk > 0).float().mean()) - (1 - pd)), 8e-3)
     X = torch.randn(5000, 300)
@@ -838,15 +838,14 @@ def scale_ops():
     Fh, E = 2048, 256
     A, W, bias = rn(T, E), rn(Fh, E) / 16, rn(Fh) / 10
     Hh = torch.empty(T, Fh, device=dev)
-    bits = torch.zeros(T, Fh // 32, dtype=torch.int32, device=dev)
+    bits = ops.alloc_relu_bits(T, Fh, dev)
     ops.gemm_bits(0, 1, T, Fh, E, A, E, W, E, Hh, Fh, bias=bias, flags=N.GEMM_RELU, bits_out=bits)
     worst, top, badbits = 0.0, 0.0, 0
-    shifts = torch.arange(32, dtype=torch.int32, device=dev)
     for lo, hi in _chunks(T, 65536):
         ref = torch.relu(A[lo:hi].double() @ W.double().t() + bias.double())
         worst = max(worst, float((Hh[lo:hi].double() - ref).abs().max()))
         top = max(top, float(ref.abs().max()))
-        un = ((bits[lo:hi].unsqueeze(2) >> shifts) & 1).reshape(hi - lo, Fh).bool()
+        un = ops.unpack_relu_bits(bits[lo // 32:hi // 32], hi - lo)
         badbits += int((un != (Hh[lo:hi] > 0)).sum())
     report(f"gemm_bits relu fwd {T}x{Fh}x{E} (all rows)", worst / top, mfma_tol(1e-5))
     report(f"gemm_bits mask bits {T}x{Fh}", float(badbits), 0)
