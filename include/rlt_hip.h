@@ -86,13 +86,17 @@ int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int 
 /* Training-step form (run.py:126 + :141-145 in ONE pass over p and labels): everything rlt_reward_loss_ex produces, plus
  * the cut metrics of rlt_cut_metrics_ex on the same rows while they are in LDS - k_out (B) int32 = argmax_j p + 1 (first
  * maximum), f1_out / dcg_out (B) float64 (DCG with `metric_penalty`, utils/metrics.py:27), sums[0..1] = their batch sums.
- * loss_out = sum(loss_per_list)/B from a float64 sum.  All outputs required except dp.  Two launches: the pass (a grid
- * sized to the chip striding over groups of 4 lists) and a one-workgroup fixed-order reduction.
+ * loss_out = (sum of the per-list terms)/B from a float64 sum.  All outputs required except dp.  Two launches: the pass
+ * (one ranked list per wavefront, a grid sized to the chip striding over the lists; every wavefront leaves its float64
+ * partial sums in ws) and a one-workgroup fixed-order reduction of those partials (deterministic).
+ * ws: rlt_loss_metrics_workspace(B) bytes.
  * Algorithmic bytes per list: read p, labels 8S, write dp 4S + 24 B of results (3.6 KB at S = 300). */
+size_t rlt_loss_metrics_workspace(int B);
 int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
                      int metric, float penalty, int kind, float tau, double metric_penalty,
                      float* loss_per_list, float* loss_out, float* dp,
-                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream);
+                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ multi-task terms (L7-L8)
  * utils/losses.py:99-141 (RerankLoss) and nn.BCELoss of :177,:187 (MtCutLoss).

@@ -200,7 +200,7 @@ __device__ __forceinline__ void write_output_t(const GemmArgs& g, const f32x16 (
         if (to_slab || (!relu && !accum && !g.mask && !g.bits_in)) { tile([](float v, int, int, const float*) { return v; }); return; }
         if (relu && !accum && !g.mask && !g.bits_out && !g.bits_in) { tile([](float v, int, int, const float*) { return fmaxf(v, 0.f); }); return; }
         if (accum && !relu && !g.mask && !g.bits_in) { tile([](float v, int, int, const float* d) { return v + *d; }); return; }
-        if ((g.bits_out && relu || g.bits_in && !relu) && !accum && !g.mask && !to_slab) {
+        if (((g.bits_out && relu) || (g.bits_in && !relu)) && !accum && !g.mask && !to_slab) {
             // 1-bit masks (packed along rows): one word per lane and 32 x 32 block, written / read once
             const float sc = g.mask_scale;
             auto body = [&](auto wr_tag) {

@@ -16,6 +16,15 @@ namespace {
 
 constexpr int LISTS_PER_WG = 4;
 
+// The pass is meant to be bound by its 3.6 KB of HBM traffic per list, which it is only if the arithmetic per position
+// stays around forty instructions: IEEE-exact fp32 division (~10 instructions each, 5-6 per position) and libm's
+// logf / expf (~20-30 each, 4 per position) made it VALU-bound at 1.5 TB/s.  Hardware reciprocal, log2 and exp2
+// (v_rcp_f32, v_log_f32, v_exp_f32: 1 ulp) are ~1e-7 relative per value - two orders below the 1e-5 the parity tests hold
+// on losses and the 1e-4 on gradients.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }   // ln x
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); } // e^x
+
 struct RewardArgs {
     const float* p;        // (B,S) or null
     const float* y;        // (B,S)
@@ -32,6 +41,7 @@ struct RewardArgs {
     double* f1_out;        // (B) F1@k, float64
     double* dcg_out;       // (B) DCG@k, float64 (metric penalty = mpenalty)
     double mpenalty;
+    double* partials;      // (grid * 4, 3): per-wavefront sums of loss, F1, DCG
 };
 
 // element j of a list lives at lds[(j / C) * STRIDE + j % C], STRIDE = C|1 (odd => conflict-free)
@@ -40,8 +50,12 @@ __device__ __forceinline__ int lds_slot(int j) { return (j / C) * (C | 1) + (j %
 
 // METRICS: the same pass also emits the cut position k = argmax_j p + 1 (first maximum) and F1@k / DCG@k in float64
 // (run.py:141-145 -> utils/metrics.py:15-38) - labels and p are already in LDS / registers, so the metric costs no
-// HBM traffic beyond its 20 B of results per list.  The grid is sized to the chip (launch_reward) and every
-// workgroup strides over groups of 4 lists.
+// HBM traffic beyond its 20 B of results per list - and per-wavefront partial sums of the loss and the two metrics
+// (a.partials, one record per wavefront of the grid) for the final reduction.
+// A wavefront owns a list from the first load to the last store: rows are read with coalesced 16-byte loads (lane =
+// 4 consecutive positions), turned through the wavefront's own LDS region so that a lane owns C CONSECUTIVE positions
+// for the scans, and written back the same way - no workgroup barrier, no index division.  The grid is sized to the
+// chip (launch_reward) and the wavefronts stride over the lists.
 template <int C, bool METRICS>
 __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     constexpr int STRIDE = C | 1;
@@ -49,52 +63,50 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     __shared__ float sp[LISTS_PER_WG * ROW];
     __shared__ float sy[LISTS_PER_WG * ROW];
     __shared__ double icoef[METRICS ? 64 * C : 1];      // 1 / log2(j + 2), float64 (utils/metrics.py:7)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.S;
     if (METRICS) {
         for (int j = tid; j < S; j += 256) icoef[j] = 1.0 / log2((double)(j + 2));
+        __syncthreads();
     }
-    const int ngroups = (a.B + LISTS_PER_WG - 1) / LISTS_PER_WG;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int b0 = grp * LISTS_PER_WG;
-    const int nl = min(LISTS_PER_WG, a.B - b0);
-    const size_t base = (size_t)b0 * S;
-    const int total = nl * S;
-
+    float* const wp = sp + wv * ROW;          // this wavefront's LDS rows
+    float* const wy = sy + wv * ROW;
+    const bool vec = (S & 3) == 0;
+    double part_loss = 0.0, part_f1 = 0.0, part_dcg = 0.0;
+    for (int b = blockIdx.x * LISTS_PER_WG + wv; b < a.B; b += gridDim.x * LISTS_PER_WG) {
+    const size_t base = (size_t)b * S;
     // ---- stage the rows in LDS (coalesced global reads) ------------------------------------
-    if ((S & 3) == 0) {
-        for (int e = tid * 4; e < total; e += 256 * 4) {
-            const float4 vy = *reinterpret_cast<const float4*>(a.y + base + e);
+    if (vec) {
+        for (int j = 4 * lane; j < S; j += 256) {
+            const float4 vy = *reinterpret_cast<const float4*>(a.y + base + j);
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.p) vp = *reinterpret_cast<const float4*>(a.p + base + e);
-            const int l = e / S, j = e - l * S;   // S % 4 == 0: the 4 elements stay in one row
+            if (a.p) vp = *reinterpret_cast<const float4*>(a.p + base + j);
             const float ys[4] = {vy.x, vy.y, vy.z, vy.w};
             const float ps[4] = {vp.x, vp.y, vp.z, vp.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int s = l * ROW + lds_slot<C>(j + i);
-                sy[s] = ys[i];
-                sp[s] = ps[i];
+                const int s = lds_slot<C>(j + i);
+                wy[s] = ys[i];
+                wp[s] = ps[i];
             }
         }
     } else {
-        for (int e = tid; e < total; e += 256) {
-            const int l = e / S, j = e - l * S;
-            const int s = l * ROW + lds_slot<C>(j);
-            sy[s] = a.y[base + e];
-            sp[s] = a.p ? a.p[base + e] : 0.f;
+        for (int j = lane; j < S; j += 64) {
+            const int s = lds_slot<C>(j);
+            wy[s] = a.y[base + j];
+            wp[s] = a.p ? a.p[base + j] : 0.f;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // LDS is in-order per wavefront: the reads below see the stores above
 
     float dpv[C];
     float rv[C], qv[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) { dpv[i] = 0.f; rv[i] = 0.f; qv[i] = 0.f; }
 
-    if (wv < nl) {
-        const float* ly = sy + wv * ROW + lane * STRIDE;
-        const float* lp = sp + wv * ROW + lane * STRIDE;
+    {
+        const float* ly = wy + lane * STRIDE;
+        const float* lp = wp + lane * STRIDE;
         float yv[C], pv[C];
         bool ok[C];
 #pragma unroll
@@ -114,14 +126,12 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
             const float incl = wave_scan_incl(run, lane);
             const float excl = incl - run;
             const float n_rel = __shfl(incl, 63, 64);
+            // p = c/k, r = c/N, F1 = 2pr/(p+r) (0 when c = 0 or N = 0) = 2c/(k+N) for c > 0
 #pragma unroll
             for (int i = 0; i < C; ++i) {
                 const float hits = excl + pre[i];
                 const float k = (float)(lane * C + i + 1);
-                const float prec = hits / k;
-                const float rec = (n_rel != 0.f) ? hits / n_rel : 0.f;
-                const float tot = prec + rec;
-                rv[i] = (tot != 0.f) ? (prec * rec * 2.f) / tot : 0.f;
+                rv[i] = (hits > 0.f) ? (2.f * hits) * fast_rcp(k + n_rel) : 0.f;
             }
         } else {
             // utils/metrics.py:93-101: prefix sum of (+1 | -1) / log2(j+2)
@@ -132,8 +142,8 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
                 const int j = lane * C + i;
                 float g = 0.f;
                 if (ok[i]) {
-                    const float cf = a.coef[j];
-                    g = (yv[i] == 1.f) ? 1.f / cf : (1.f / cf) * a.penalty;
+                    const float icf = fast_rcp(a.coef[j]);
+                    g = (yv[i] == 1.f) ? icf : icf * a.penalty;
                 }
                 run += g;
                 pre[i] = run;
@@ -147,14 +157,15 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
         float part = 0.f;
         if (a.kind != RLT_LOSS_EXPECT || a.q_out) {
             float zs = 0.f;
+            const float itau = 1.f / a.tau;
 #pragma unroll
             for (int i = 0; i < C; ++i) {
-                qv[i] = ok[i] ? expf(rv[i] / a.tau) : 0.f;
+                qv[i] = ok[i] ? fast_exp(rv[i] * itau) : 0.f;
                 zs += qv[i];
             }
-            const float z = wave_sum(zs);
+            const float iz = fast_rcp(wave_sum(zs));
 #pragma unroll
-            for (int i = 0; i < C; ++i) qv[i] = qv[i] / z;
+            for (int i = 0; i < C; ++i) qv[i] = qv[i] * iz;
         }
         // ---- loss terms and d/dp ---------------------------------------------------------------
         if (a.p) {
@@ -167,16 +178,16 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
                     term = -(p * r);
                     g = -r;
                 } else if (a.kind == RLT_LOSS_CE) {          // utils/losses.py:94-96
-                    term = -(logf(p) * q);
-                    g = -q / p;
+                    term = -(fast_log(p) * q);
+                    g = -q * fast_rcp(p);
                 } else if (a.kind == RLT_LOSS_KL) {          // utils/losses.py:230, kl_div(log p, q)
-                    const float qlq = (q > 0.f) ? q * logf(q) : 0.f;
-                    term = qlq - q * logf(p);
-                    g = -q / p;
+                    const float qlq = (q > 0.f) ? q * fast_log(q) : 0.f;
+                    term = qlq - q * fast_log(p);
+                    g = -q * fast_rcp(p);
                 } else {                                     // utils/losses.py:232-233, JS
-                    const float lm = logf((p + q) * 0.5f);
-                    const float lp_ = logf(p);
-                    const float qlq = (q > 0.f) ? q * logf(q) : 0.f;
+                    const float lm = fast_log((p + q) * 0.5f);
+                    const float lp_ = fast_log(p);
+                    const float qlq = (q > 0.f) ? q * fast_log(q) : 0.f;
                     const float plp = (p > 0.f) ? p * lp_ : 0.f;
                     term = 0.5f * ((qlq - q * lm) + (plp - p * lm));
                     g = 0.5f * (lp_ - lm);                   // gradient flows through log m AND the target p
@@ -185,13 +196,14 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
                 dpv[i] = g * a.gscale;
             }
             const float tot = wave_sum(part);
-            if (lane == 0 && a.loss_per_list) a.loss_per_list[b0 + wv] = tot;
+            if (lane == 0 && a.loss_per_list) a.loss_per_list[b] = tot;
+            part_loss += (double)tot;
         }
     }
     // ---- cut metrics of the same lists (METRICS) ---------------------------------------------------
-    if (METRICS && wv < nl) {
-        const float* ly = sy + wv * ROW + lane * STRIDE;
-        const float* lp = sp + wv * ROW + lane * STRIDE;
+    if (METRICS) {
+        const float* ly = wy + lane * STRIDE;
+        const float* lp = wp + lane * STRIDE;
         // first maximum, like np.argmax (run.py:141-142): per-lane scan in index order, then (value, index) reduction
         float best = -INFINITY;
         int bi = 0x7fffffff;
@@ -207,47 +219,57 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
         const int k = (bi == 0x7fffffff ? 0 : bi) + 1;
-        double hits = 0.0, n_rel = 0.0, dcg = 0.0;          // utils/metrics.py:15-38 in float64
+        // utils/metrics.py:15-38: the counts are small integers (exact in fp32), only the DCG sum needs float64
+        float hits_f = 0.f, nrel_f = 0.f;
+        double dcg = 0.0;
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int j = lane * C + i;
             if (j < S) {
-                const double t = (double)ly[i];
-                n_rel += t;
+                nrel_f += ly[i];
                 if (j < k) {
-                    hits += t;
+                    hits_f += ly[i];
                     dcg += ((ly[i] == 1.f) ? 1.0 : a.mpenalty) * icoef[j];
                 }
             }
         }
-        hits = wave_sum(hits);
-        n_rel = wave_sum(n_rel);
+        hits_f = wave_sum(hits_f);
+        nrel_f = wave_sum(nrel_f);
         dcg = wave_sum(dcg);
-        if (lane == 0) {
-            const double prec = hits / (double)k;
-            const double rec = (n_rel != 0.0) ? hits / n_rel : 0.0;
-            a.k_out[b0 + wv] = k;
-            a.f1_out[b0 + wv] = (prec + rec != 0.0) ? 2.0 * prec * rec / (prec + rec) : 0.0;
-            a.dcg_out[b0 + wv] = dcg;
+        {
+            // p = c/k, r = c/N, F1 = 2pr/(p+r) = 2c/(k+N) for c > 0 (0 when c = 0, which covers N = 0), float64
+            const double f1 = hits_f > 0.f ? 2.0 * (double)hits_f / ((double)k + (double)nrel_f) : 0.0;
+            if (lane == 0) {
+                a.k_out[b] = k;
+                a.f1_out[b] = f1;
+                a.dcg_out[b] = dcg;
+            }
+            part_f1 += f1;
+            part_dcg += dcg;
         }
     }
-    // ---- coalesced write-back through LDS ---------------------------------------------------------
+    // ---- coalesced write-back through the wavefront's LDS rows ---------------------------------------
     auto write_back = [&](float* dst, const float (&vals)[C]) {
-        __syncthreads();
-        if (wv < nl) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < C; ++i) sp[wv * ROW + lane * STRIDE + i] = vals[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < total; e += 256) {
-            const int l = e / S, j = e - l * S;
-            dst[base + e] = sp[l * ROW + lds_slot<C>(j)];
+        for (int i = 0; i < C; ++i) wp[lane * STRIDE + i] = vals[i];
+        __builtin_amdgcn_wave_barrier();
+        if (vec) {
+            for (int j = 4 * lane; j < S; j += 256)
+                *reinterpret_cast<float4*>(dst + base + j) =
+                    make_float4(wp[lds_slot<C>(j)], wp[lds_slot<C>(j + 1)], wp[lds_slot<C>(j + 2)], wp[lds_slot<C>(j + 3)]);
+        } else {
+            for (int j = lane; j < S; j += 64) dst[base + j] = wp[lds_slot<C>(j)];
         }
     };
     if (a.dp) write_back(a.dp, dpv);
     if (a.r_out) write_back(a.r_out, rv);
     if (a.q_out) write_back(a.q_out, qv);
-    __syncthreads();          // the next group's staging overwrites sp / sy
+    __builtin_amdgcn_wave_barrier();          // the next list's staging overwrites the rows
+    }
+    if (METRICS && lane == 0) {               // per-wavefront partial sums, fixed order (this wavefront's lists in turn)
+        double* rec = a.partials + 3 * ((size_t)blockIdx.x * LISTS_PER_WG + wv);
+        rec[0] = part_loss; rec[1] = part_f1; rec[2] = part_dcg;
     }
 }
 
@@ -265,13 +287,13 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* x, int n, f
     if (threadIdx.x == 0) out[0] = (float)(sm[0] * (double)scale);
 }
 
-// loss = sum(loss_per_list) / B in float32 from a float64 sum, sums = {sum F1, sum DCG} in float64: one workgroup,
-// fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void loss_metrics_final_kernel(const float* loss_per_list, const double* f1, const double* dcg,
-                                                                 int n, float scale, float* loss_out, double* sums) {
+// loss = sum(per-wavefront loss sums) / B in float32 from a float64 sum, sums = {sum F1, sum DCG} in float64: one workgroup
+// over the <= 8192 partial records of the pass, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void loss_metrics_final_kernel(const double* partials, int n, float scale, float* loss_out,
+                                                                 double* sums) {
     __shared__ double sm[3][256];
     double l = 0.0, x = 0.0, z = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { l += (double)loss_per_list[i]; x += f1[i]; z += dcg[i]; }
+    for (int i = threadIdx.x; i < n; i += 256) { l += partials[3 * i]; x += partials[3 * i + 1]; z += partials[3 * i + 2]; }
     sm[0][threadIdx.x] = l; sm[1][threadIdx.x] = x; sm[2][threadIdx.x] = z;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -289,10 +311,13 @@ __global__ __launch_bounds__(256) void loss_metrics_final_kernel(const float* lo
 // grid: one workgroup per group of 4 lists up to 8 workgroups per CU (256 CUs), beyond that the workgroups stride
 constexpr int REWARD_MAX_GRID = 256 * 8;
 
+int reward_grid(int B) {
+    const int groups = rlt_cdiv(B, LISTS_PER_WG);
+    return groups < REWARD_MAX_GRID ? groups : REWARD_MAX_GRID;
+}
 template <int C, bool METRICS>
 int launch_reward(const RewardArgs& a, hipStream_t st) {
-    const int groups = rlt_cdiv(a.B, LISTS_PER_WG);
-    const int grid = groups < REWARD_MAX_GRID ? groups : REWARD_MAX_GRID;
+    const int grid = reward_grid(a.B);
     hipLaunchKernelGGL((reward_loss_kernel<C, METRICS>), dim3(grid), dim3(256), 0, st, a);
     return RLT_LAUNCH_RESULT();
 }
@@ -531,7 +556,7 @@ int rlt_reward_loss_ex(const float* p, const float* labels, const float* dcg_coe
     int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
     if (rc) return rc;
     RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
-                 nullptr, nullptr, nullptr, -1.0};
+                 nullptr, nullptr, nullptr, -1.0, nullptr};
     hipStream_t st = rlt_stream(stream);
     rc = dispatch_reward(a, st);
     if (rc) return rc;
@@ -548,19 +573,25 @@ int rlt_reward_loss(const float* p, const float* labels, const float* dcg_coef, 
     return rlt_reward_loss_ex(p, labels, dcg_coef, B, S, metric, -1.f, kind, tau, loss_per_list, loss_out, dp, stream);
 }
 
+size_t rlt_loss_metrics_workspace(int B) {
+    return B > 0 ? (size_t)reward_grid(B) * LISTS_PER_WG * 3 * sizeof(double) : 0;      // one record per wavefront of the pass
+}
+
 int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
                      int metric, float penalty, int kind, float tau, double metric_penalty,
                      float* loss_per_list, float* loss_out, float* dp,
-                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums, void* stream) {
-    RLT_CHECK_ARG(p && loss_per_list && loss_out && k_out && f1_out && dcg_out && sums);
+                     int32_t* k_out, double* f1_out, double* dcg_out, double* sums,
+                     void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(p && loss_per_list && loss_out && k_out && f1_out && dcg_out && sums && ws);
     int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
     if (rc) return rc;
+    if (ws_bytes < rlt_loss_metrics_workspace(B)) return RLT_E_WORKSPACE;
     RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
-                 k_out, f1_out, dcg_out, metric_penalty};
+                 k_out, f1_out, dcg_out, metric_penalty, (double*)ws};
     hipStream_t st = rlt_stream(stream);
     rc = dispatch_reward_m<true>(a, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_metrics_final_kernel, dim3(1), dim3(256), 0, st, loss_per_list, f1_out, dcg_out, B,
+    hipLaunchKernelGGL(loss_metrics_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, reward_grid(B) * LISTS_PER_WG,
                        1.0f / (float)B, loss_out, sums);
     return RLT_LAUNCH_RESULT();
 }
@@ -571,7 +602,7 @@ int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int 
     int rc = reward_args_ok(nullptr, labels, dcg_coef, B, S, metric, RLT_LOSS_KL);
     if (rc) return rc;
     RewardArgs a{nullptr, labels, dcg_coef, nullptr, nullptr, r_out, q_out, B, S, metric, RLT_LOSS_KL, tau, 1.0f, penalty,
-                 nullptr, nullptr, nullptr, -1.0};
+                 nullptr, nullptr, nullptr, -1.0, nullptr};
     return dispatch_reward(a, rlt_stream(stream));
 }
 

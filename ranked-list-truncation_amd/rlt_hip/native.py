@@ -30,7 +30,8 @@ _SIGNATURES = {
     "rlt_reward_matrix": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
     "rlt_reward_loss_ex": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, P, P, P]),
     "rlt_reward_matrix_ex": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P]),
-    "rlt_loss_metrics": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_double, P, P, P, P, P, P, P, P]),
+    "rlt_loss_metrics_workspace": (c_size_t, [c_int]),
+    "rlt_loss_metrics": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_double, P, P, P, P, P, P, P, P, c_size_t, P]),
     "rlt_cut_metrics_ex": (c_int, [P, P, P, c_int, c_int, c_double, P, P, P, P, P]),
     "rlt_mt_terms_workspace": (c_size_t, [c_int, c_int]),
     "rlt_mt_terms": (c_int, [P, P, P, c_int, c_int, c_float, P, P, c_size_t, P]),

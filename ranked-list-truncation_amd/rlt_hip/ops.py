@@ -685,8 +685,10 @@ class RewardLossFn(Function):
                  ptr(per_list), ptr(loss), ptr(dp), stream())
             return loss.reshape(())
         k, f1, dcg, sums = _fused_metric_buffers(B, p.device)
+        ws_bytes = query("rlt_loss_metrics_workspace", B)
+        ws = workspace(ws_bytes, p.device)
         call("rlt_loss_metrics", ptr(p), ptr(labels), ptr(coef), B, S, metric, penalty, kind, tau, metric_penalty,
-             ptr(per_list), ptr(loss), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+             ptr(per_list), ptr(loss), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(ws), ws_bytes, stream())
         ctx.mark_non_differentiable(k, sums)
         return loss.reshape(()), k, sums
 
@@ -785,8 +787,10 @@ class MtCutLossFn(Function):
         dp = _empty((B, S), cut_p)
         if with_metrics:
             k, f1, dcg, sums = _fused_metric_buffers(B, dev)
+            lws_bytes = query("rlt_loss_metrics_workspace", B)
+            lws = workspace(lws_bytes, dev)
             call("rlt_loss_metrics", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, -1.0, N.LOSS_JS, tau, -1.0,
-                 ptr(per_list), ptr(cut), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+                 ptr(per_list), ptr(cut), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(lws), lws_bytes, stream())
         else:
             call("rlt_reward_loss", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, N.LOSS_JS, tau,
                  ptr(per_list), ptr(cut), ptr(dp), stream())

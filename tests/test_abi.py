@@ -51,7 +51,8 @@ def test_argument_errors_are_reported_not_crashed(native):
     assert lib.rlt_bicut_loss(None, None, 1, 1, 1, 0.65, 0.1, None, None, None, None) == -1
     assert native.query("rlt_narrow_dw_workspace", 1228800, 1024) > 0
     # the fused loss + metrics pass and the penalty forms
-    assert lib.rlt_loss_metrics(None, None, None, 1, 1, 0, -1.0, 3, 0.85, -1.0, None, None, None, None, None, None, None, None) == -1
+    assert lib.rlt_loss_metrics(None, None, None, 1, 1, 0, -1.0, 3, 0.85, -1.0, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert native.query("rlt_loss_metrics_workspace", 4096) == 1024 * 4 * 3 * 8
     assert lib.rlt_cut_metrics_ex(None, None, None, 1, 1, -1.0, None, None, None, None, None) == -1
 
 

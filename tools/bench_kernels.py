@@ -89,6 +89,36 @@ def gemm_bits(T=4096 * 300, E=256, Fh=2048):
     print(f"gemm      ffn1 plain NT {T}x{Fh}x{E}: {ms:8.3f} ms  {2.0 * T * Fh * E / ms / 1e9:7.1f} TF/s", flush=True)
 
 
+def loss(S=300):
+    """HBM-bound scan kernels: the fused reward-loss + cut-metrics pass (rlt_loss_metrics) against the separate kernels
+    it replaces; algorithmic bytes per list = read p, labels 8S + write dL/dp 4S + 24 B of results.
+    HIP-event times include the host's launch gaps at small batches: read the kernel durations from
+    `rocprofv3 --kernel-trace --stats -- python tools/bench_kernels.py loss`."""
+    for B in (4096, 65536, 262144):
+        g = torch.Generator(device=dev).manual_seed(B)
+        p = torch.softmax(torch.randn(B, S, device=dev, generator=g), 1).contiguous()
+        y = (torch.rand(B, S, device=dev, generator=g) < 0.1).float()
+        per_list, loss_out, dp = torch.empty(B, device=dev), torch.empty(1, device=dev), torch.empty(B, S, device=dev)
+        k = torch.empty(B, dtype=torch.int32, device=dev)
+        f1, dcg = torch.empty(B, dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.float64, device=dev)
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        wsb = N.query("rlt_loss_metrics_workspace", B)
+        ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
+        nbytes = B * (12.0 * S + 24)
+
+        def fused():
+            call("rlt_loss_metrics", ptr(p), ptr(y), None, B, S, N.METRIC_F1, -1.0, N.LOSS_JS, 0.85, -1.0, ptr(per_list), ptr(loss_out),
+                 ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(ws), wsb, stream())
+
+        def separate():
+            call("rlt_reward_loss", ptr(p), ptr(y), None, B, S, N.METRIC_F1, N.LOSS_JS, 0.85, ptr(per_list), ptr(loss_out), ptr(dp), stream())
+            call("rlt_cut_metrics", ptr(p), ptr(y), None, B, S, ptr(k), ptr(f1), ptr(dcg), ptr(sums), stream())
+        ms = timeit(fused, reps=50, warm=5)
+        print(f"loss+metrics fused (2 launches) B{B} S{S}: {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+        ms = timeit(separate, reps=50, warm=5)
+        print(f"loss, then metrics (4 launches) B{B} S{S}: {ms * 1e3:9.1f} us  {(nbytes + B * 8.0 * S) / ms / 1e6:8.1f} GB/s of its own bytes (p, labels read twice)", flush=True)
+
+
 def lstm(B=4096, S=300):
     T = S * B
     gates = torch.randn(T, 1024, device=dev) * 0.5
