@@ -118,6 +118,40 @@ def cpu_baseline(seq_len, vec_batch, loop_batch):
                                         f"{seq_len}, {loop_steps} steps after 1 warm-up"}}
 
 
+def hbm_kernel_roofline(S, dev, lists=65536, reps=30):
+    """The HBM-bound scan kernel of the path: fused reward loss (JS, F1) + d(loss)/dp + cut metrics in one
+    pass, one ranked list per wavefront.  ALGORITHMIC bytes per list = read p and labels 8S + write dL/dp 4S + 24 B of
+    results; HIP events on the launch stream around `reps` calls (two launches each: the pass and the final reduction)."""
+    from rlt_hip import native as N
+    g = torch.Generator(device=dev).manual_seed(3)
+    p = torch.softmax(torch.randn(lists, S, device=dev, generator=g), 1).contiguous()
+    y = (torch.rand(lists, S, device=dev, generator=g) < 0.1).float()
+    per_list, loss_out, dp = torch.empty(lists, device=dev), torch.empty(1, device=dev), torch.empty(lists, S, device=dev)
+    k = torch.empty(lists, dtype=torch.int32, device=dev)
+    f1, dcg = torch.empty(lists, dtype=torch.float64, device=dev), torch.empty(lists, dtype=torch.float64, device=dev)
+    sums = torch.empty(2, dtype=torch.float64, device=dev)
+    wsb = N.query("rlt_loss_metrics_workspace", lists)
+    ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
+
+    def run():
+        N.call("rlt_loss_metrics", N.ptr(p), N.ptr(y), None, lists, S, N.METRIC_F1, -1.0, N.LOSS_JS, 0.85, -1.0, N.ptr(per_list),
+               N.ptr(loss_out), N.ptr(dp), N.ptr(k), N.ptr(f1), N.ptr(dcg), N.ptr(sums), N.ptr(ws), wsb, N.stream())
+    for _ in range(3):
+        run()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    nbytes = lists * (12.0 * S + 24)
+    gbps = nbytes / us / 1e3
+    return {"kernel": "reward_loss_kernel<5,true> + loss_metrics_final_kernel (rlt_loss_metrics)", "bound": "hbm",
+            "lists": lists, "seq_len": S, "us_per_call": round(us, 2), "algorithmic_bytes": nbytes,
+            "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+
+
 def step_algorithmic_flops(model, B, S):
     """AttnCut fwd FLOPs per token = 3,676,672 + 1024*L (L = lists the attention spans); fwd+bwd = 3x."""
     assert model == "attncut"
@@ -391,6 +425,7 @@ def main():
                              "pmc_file_traffic_GB": None if step_traffic is None else round(step_traffic / 1e9, 1),
                              "pmc_file_hbm_GBps": None if step_traffic is None else round(step_traffic / sec / 1e9, 1),
                              "pmc_file_frac_of_hbm_peak": None if step_traffic is None else round(step_traffic / sec / PEAK_HBM_BPS, 4)}},
+            "hbm_kernel": hbm_kernel_roofline(S, dev) if world == 1 else None,
             "fp32_mode": fp32_mode,
             "train_state": {"loss": round(loss_v, 6), "f1": round(f1_v, 6), "dcg": round(dcg_v, 6)},
         }
