@@ -19,6 +19,10 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef RLT_LAZY_MAX
+#define RLT_LAZY_MAX 1
+#endif
+constexpr float LAZY_TH = 8.f;           // forward: the running-maximum reference moves when a tile exceeds it by > 2^8
 constexpr int LDT3 = 72;                 // bf16 elements per row of a transposed [d][64 rows] image (144 B)
 // rows of a transposed image: the HD rows of the tile, plus - where the 32-row MFMA operand has rows to spare (head
 // dim 16) - one row of ones: the product that forms O^T = V^T P^T then also delivers sum_k P[k][q] in its row HD, i.e.
@@ -293,7 +297,14 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#if RLT_LAZY_MAX
+    float m_run = 0.f, l_run = 0.f;          // m_run: the reference the scores are taken relative to (set by the first tile)
+    f32x16 c_m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c_m[r] = 0.f;
+#else
     float m_run = -INFINITY, l_run = 0.f;
+#endif
     // head dim 16 without dropout: the normaliser is row HD of O^T (T_rows above; with dropout P.V runs on the dropped P)
     constexpr bool LROW = T_rows<HD>() > HD && !DROP;
 
@@ -318,6 +329,46 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             const uint16_t* v_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
             const uint16_t* v_lo = v_hi + T_elems<HD>();
             f32x16 sc[2];
+#if RLT_LAZY_MAX
+            // Lazily rescaled running maximum: the score products start from accumulators holding -m_ref (a 16-register
+            // block, the MFMA's C operand), so they come out as s - m_ref with no subtraction per score, and m_ref moves -
+            // with the rescale of O and of the normaliser - only when a tile's maximum exceeds it by more than 2^LAZY_TH
+            // (first tile: always).  exp2(s - m_ref) <= 2^LAZY_TH then; O, the normaliser and the LSE carry the same
+            // reference, so the result is the same softmax.  Per tile this saves 32 subtractions and 16*DT multiplies.
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) sc[sub] = mma_rows<HD>(k_hi, k_lo, sub, l31, hh, qh, ql, c_m);   // S^T[key][q] - m_ref
+            if (t == nt - 1) {            // only the last tile can hold keys beyond B
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const bool move = t == 0 || tmax > LAZY_TH;
+            if (__any(move)) {            // wave-uniform branch; lanes that do not move shift by 0
+                const float shift = move ? tmax : 0.f;
+                const float alpha = rlt_exp2(-shift);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                l_run *= alpha;
+                m_run += shift;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c_m[r] = -m_run;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[sub][r] -= shift;
+            }
+            const float m_new = 0.f;      // the scores are already relative to m_run
+#else
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -343,6 +394,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#endif
             // per 32-key sub-tile: exponentiate, (drop), feed P.V - the second sub-tile's VALU work is issued while
             // the first sub-tile's MFMAs execute
             float psum = 0.f;
@@ -350,7 +402,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = rlt_exp2(sc[sub][r] - m_new);
+                    const float p = rlt_exp2(RLT_LAZY_MAX ? sc[sub][r] : sc[sub][r] - m_new);
                     sc[sub][r] = p;
                     if (!LROW) psum += p;
                 }
@@ -367,8 +419,13 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
                 }
                 mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
             }
+#if RLT_LAZY_MAX
+            if (!LROW) l_run += psum;
+            (void)m_new;
+#else
             if (!LROW) l_run = l_run * alpha + psum;
             m_run = m_new;
+#endif
         }
         __syncthreads();
     }

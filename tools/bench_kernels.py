@@ -55,6 +55,11 @@ def attention(B=4096, S=60, H=4, HD=64):
     print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
 
 
+def attention16():
+    """Choopy's shape (BASELINE configs[2]): 8192 lists, 8 heads x 16."""
+    attention(B=8192, S=20, H=8, HD=16)
+
+
 def gemms(T=4096 * 300):
     shapes = [("in_proj fwd NT", 0, 1, T, 768, 256), ("ffn1 fwd NT", 0, 1, T, 2048, 256), ("ffn2 fwd NT", 0, 1, T, 256, 2048),
               ("ffn1 dX NN", 0, 0, T, 256, 2048), ("ffn2 dX NN", 0, 0, T, 2048, 256),
