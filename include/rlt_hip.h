@@ -345,6 +345,18 @@ int rlt_bilstm_bwd(const float* x, int I, const rlt_lstm_layer_weights* w, const
                    void* stash, size_t stash_bytes, float* dx, const rlt_lstm_layer_grads* g,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* The same 2-layer stack for ANY hidden size (`encoding_size` of models/MMOECut.py:57,63; every other model and every
+ * BASELINE config uses 128, which runs on the persistent kernels above).  General form, built for coverage: one GEMM
+ * per layer for the input projection, one small GEMM per direction and one cell kernel per time step, the backward
+ * the same in reverse.  w[l].w_ih (4*hidden, in), w[l].w_hh (4*hidden, hidden), biases (4*hidden); layer 1 has
+ * 2*hidden inputs; h_out (S*B, 2*hidden).  rlt_bilstm_generic_bytes(stash != 0, ...) / (0, ...) size the two buffers. */
+size_t rlt_bilstm_generic_bytes(int stash, int S, int B, int I, int hidden);
+int rlt_bilstm_generic_fwd(const float* x, int I, int hidden, const rlt_lstm_layer_weights* w, int S, int B, float* h_out,
+                           void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, void* stream);
+int rlt_bilstm_generic_bwd(const float* x, int I, int hidden, const rlt_lstm_layer_weights* w, const float* h_out,
+                           const float* dh_out, int S, int B, void* stash, size_t stash_bytes, float* dx,
+                           const rlt_lstm_layer_grads* g, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ layout helpers
  * (B,S,F) user layout <-> (S*B,F) position-major */
 int rlt_to_position_major(const float* x_bsf, int B, int S, int F, float* x_sbf, void* stream);

@@ -12,8 +12,8 @@ class MOECut(nn.Module):
     def __init__(self, seq_len: int = 300, num_experts=3, num_tasks=3, input_size=3, encoding_size=128,
                  d_model=256, n_head=4, num_layers=1, dropout=0.2):
         super().__init__()
-        if encoding_size != 128:
-            raise ValueError("the HIP BiLSTM kernel is specialised for encoding_size=128")
+        if d_model != 2 * encoding_size:
+            raise ValueError(f"d_model ({d_model}) must equal 2 * encoding_size ({2 * encoding_size})")
         self.seq_len, self.expert_hidden, self.n_head, self.dropout = seq_len, d_model, n_head, dropout
         self.pre_encoding = C.bilstm_params(input_size, encoding_size)
         self.experts = nn.ModuleList([Expert(d_model, n_head, num_layers, dropout) for _ in range(num_experts)])

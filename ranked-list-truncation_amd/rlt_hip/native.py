@@ -92,6 +92,9 @@ _SIGNATURES = {
     "rlt_encoder_layer_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, P, P, c_size_t, P]),
     "rlt_bilstm_fwd": (c_int, [P, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, P]),
     "rlt_bilstm_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, P]),
+    "rlt_bilstm_generic_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_bilstm_generic_fwd": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, P]),
+    "rlt_bilstm_generic_bwd": (c_int, [P, c_int, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, P]),
 }
 OP_ENCODER_STASH, OP_ENCODER_FWD_WS, OP_ENCODER_BWD_WS, OP_BILSTM_STASH, OP_BILSTM_WS = 1, 2, 3, 4, 5
 ENCODER_FIELDS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "norm1_weight", "norm1_bias",

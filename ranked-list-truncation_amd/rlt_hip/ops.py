@@ -450,28 +450,37 @@ def encoder_ffn_hidden(y):
 
 # ------------------------------------------------------------------------------ 2-layer BiLSTM (H = 128)
 class BiLSTMFn(Function):
-    """nn.LSTM(input, 128, num_layers=2, batch_first=True, bidirectional=True) on position-major input x (S*B, I) ->
-    (S*B, 256), ONE tape node on the path-level entry points rlt_bilstm_fwd / _bwd (csrc/path.hip)."""
+    """nn.LSTM(input, hidden, num_layers=2, batch_first=True, bidirectional=True) on position-major input x (S*B, I) ->
+    (S*B, 2*hidden), ONE tape node on the path-level entry points: hidden 128 (what the reference hard-codes outside
+    MMOECut's `encoding_size` argument) on the persistent recurrence kernels (rlt_bilstm_fwd / _bwd, csrc/path.hip),
+    any other hidden size on the general step-by-step form (rlt_bilstm_generic_fwd / _bwd, csrc/lstm_generic.hip)."""
 
     @staticmethod
     def forward(ctx, x, S, B, *w):          # w: 16 tensors, per layer w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r
         T, I = x.shape
         if len(w) != 16:
             raise RuntimeError("BiLSTMFn takes the 16 parameters of a 2-layer bidirectional LSTM")
-        if w[0].shape[0] != 512 or w[1].shape != (512, 128):
-            raise RuntimeError("the HIP BiLSTM kernel is specialised for hidden_size=128 (as the reference hard-codes)")
-        if w[0].shape[1] != I or w[4].shape[1] != I or w[8].shape[1] != 256 or T != S * B:
+        Hd = w[1].shape[1]
+        if w[0].shape != (4 * Hd, I) or w[4].shape != (4 * Hd, I) or w[8].shape != (4 * Hd, 2 * Hd) or w[1].shape != (4 * Hd, Hd) or T != S * B:
             raise RuntimeError(f"BiLSTM input has {I} features x {T} rows; the layers were built for "
-                               f"{w[0].shape[1]} features and S*B = {S * B} rows")
-        stash_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, I, 0, 0, 0)
-        ws_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, I, 0, 0, 0)
+                               f"{w[0].shape[1]} features, hidden {Hd} and S*B = {S * B} rows")
+        fast = Hd == 128
+        if fast:
+            stash_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, I, 0, 0, 0)
+            ws_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, I, 0, 0, 0)
+        else:
+            stash_bytes = query("rlt_bilstm_generic_bytes", 1, S, B, I, Hd)
+            ws_bytes = query("rlt_bilstm_generic_bytes", 0, S, B, I, Hd)
         stash = N.byte_buffer(stash_bytes, x.device)
         ws = N.byte_buffer(ws_bytes, x.device)
-        h = _empty((T, 256), x)
+        h = _empty((T, 2 * Hd), x)
         wp = N.lstm_ptrs([w[0:8], w[8:16]])
-        _launch("bilstm_fwd", lambda: call("rlt_bilstm_fwd", ptr(x), I, wp, S, B, ptr(h), ptr(stash), stash_bytes,
-                                           ptr(ws), ws_bytes, stream()))
-        ctx.cfg = (S, B, I, stash_bytes, ws_bytes)
+        if fast:
+            _launch("bilstm_fwd", lambda: call("rlt_bilstm_fwd", ptr(x), I, wp, S, B, ptr(h), ptr(stash), stash_bytes,
+                                               ptr(ws), ws_bytes, stream()))
+        else:
+            call("rlt_bilstm_generic_fwd", ptr(x), I, Hd, wp, S, B, ptr(h), ptr(stash), stash_bytes, ptr(ws), ws_bytes, stream())
+        ctx.cfg = (S, B, I, Hd, stash_bytes, ws_bytes)
         ctx.stash = stash
         ctx.save_for_backward(x, h, *w)
         return h
@@ -481,14 +490,18 @@ class BiLSTMFn(Function):
         if ctx.stash is None:
             raise RuntimeError("BiLSTMFn.backward overwrites its stash in place and can run only once")
         x, h, *w = ctx.saved_tensors
-        S, B, I, stash_bytes, ws_bytes = ctx.cfg
+        S, B, I, Hd, stash_bytes, ws_bytes = ctx.cfg
         dh = N.f32c(dh)
         grads = [torch.empty_like(t) for t in w]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = N.byte_buffer(ws_bytes, x.device)
         wp, gp = N.lstm_ptrs([w[0:8], w[8:16]]), N.lstm_ptrs([grads[0:8], grads[8:16]])
-        _launch("bilstm_bwd", lambda: call("rlt_bilstm_bwd", ptr(x), I, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
-                                           ptr(dx), gp, ptr(ws), ws_bytes, stream()))
+        if Hd == 128:
+            _launch("bilstm_bwd", lambda: call("rlt_bilstm_bwd", ptr(x), I, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
+                                               ptr(dx), gp, ptr(ws), ws_bytes, stream()))
+        else:
+            call("rlt_bilstm_generic_bwd", ptr(x), I, Hd, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
+                 ptr(dx), gp, ptr(ws), ws_bytes, stream())
         ctx.stash = None
         return (dx, None, None, *grads)
 

@@ -81,6 +81,9 @@ def test_path_level_entry_points(native):
     assert lib.rlt_encoder_layer_bwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, None, None, 0, None) == -1
     assert lib.rlt_bilstm_fwd(None, 3, None, 1, 1, None, None, 0, None, 0, None) == -1
     assert lib.rlt_bilstm_bwd(None, 3, None, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
+    assert lib.rlt_bilstm_generic_fwd(None, 3, 64, None, 1, 1, None, None, 0, None, 0, None) == -1
+    assert lib.rlt_bilstm_generic_bwd(None, 3, 64, None, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
+    assert N.query("rlt_bilstm_generic_bytes", 1, 300, 8, 3, 64) == 2 * (rup(2400 * 512 * 4) + rup(2400 * 128 * 4)) + rup(2400 * 128 * 4)
 
 
 def test_models_mirror_reference_state_dict():

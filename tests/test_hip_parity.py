@@ -12,6 +12,8 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     heads       softmax / sigmoid / identity heads forward/backward vs fp64
     attention   list-axis attention forward/backward vs fp64 (B not multiple of any tile, HD 16/32/64)
     lstm        2-layer BiLSTM forward/backward vs nn.LSTM
+    lstm_generic  2-layer BiLSTM at hidden sizes other than 128 (MMOECut's encoding_size) vs nn.LSTM, and an
+                MMOECut(encoding_size=64, d_model=128) against the oracle
     embed_mmoe  Choopy embedding, MMOE gates and mixture forward/backward vs fp64
     dropout     the four dropout sites of the encoder layer against references built with the kernels'
                 own keep-masks; keep-rate statistics; eval() ignores dropout; reproducible under manual_seed
@@ -56,7 +58,7 @@ def probe():
 
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
-                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "path_level"]
+                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "path_level", "lstm_generic"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
 
 

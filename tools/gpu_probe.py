@@ -352,6 +352,55 @@ def lstm():
 
 
 @section
+def lstm_generic():
+    """Hidden sizes other than 128 (MMOECut's `encoding_size`, models/MMOECut.py:57,63): the general step-by-step form
+    against nn.LSTM, forward and backward."""
+    from models._common import ParamTree, bilstm
+    for (B, S, I, Hd) in [(5, 12, 3, 64), (33, 20, 7, 96), (8, 300, 3, 64), (3, 1, 3, 32)]:
+        torch.manual_seed(B + Hd)
+        ref = torch.nn.LSTM(I, Hd, num_layers=2, batch_first=True, bidirectional=True)
+        x, dh = torch.randn(B, S, I), torch.randn(B, S, 2 * Hd)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)[0]
+        yr.backward(dh)
+        pt = ParamTree(ref).to(dev)
+        xd = _pm(x).to(dev).requires_grad_(True)
+        yd = bilstm(xd, pt, S, B)
+        yd.backward(_pm(dh).to(dev))
+        report(f"bilstm generic fwd B{B} S{S} I{I} H{Hd}", rel(_unpm(yd, B, S), yr), 2e-5)
+        report(f"bilstm generic dx  B{B} S{S} I{I} H{Hd}", rel(_unpm(xd.grad, B, S), xr.grad), 1e-4)
+        for name, prm in ref.named_parameters():
+            report(f"bilstm generic d{name} B{B} S{S} H{Hd}", rel(getattr(pt, name).grad, prm.grad), 2e-4)
+    # a whole model on it: MMOECut(encoding_size=64, d_model=128) against the oracle
+    import models as hm
+    from oracle import losses as ol, metrics as omet, models as om
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from utils import losses as hl
+    from utils.metrics import Metric
+    kw = dict(seq_len=40, num_experts=3, num_tasks=3, encoding_size=64, d_model=128, n_head=4, dropout=0.0)
+    refm = om.MMOECut(**kw)
+    fill_state_dict(refm, 64)
+    hipm = hm.MMOECut(**kw)
+    hipm.load_state_dict(refm.state_dict())
+    hipm = hipm.to(dev)
+    x, y = synthetic_lists(6, 40, 3, 65)
+    refm.train(), hipm.train()
+    out_r, out_h = refm(x), hipm(x.to(dev))
+    crit_r = ol.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=3)
+    crit_h = hl.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=3)
+    lr_, lh_ = crit_r(out_r, y), crit_h(out_h, y.to(dev))
+    lr_.backward(), lh_.backward()
+    for i, (a, b) in enumerate(zip(out_h, out_r)):
+        report(f"mmoecut encoding_size=64 out{i}", float((a.detach().cpu() - b.detach()).abs().max()) / max(1.0, float(b.detach().abs().max())), 1e-5)
+    report("mmoecut encoding_size=64 loss", abs(float(lh_) - float(lr_)), 1e-5)
+    k_h, _f1, _dcg = Metric.evaluate(out_h[-1], y.to(dev))
+    report("mmoecut encoding_size=64 k mismatches", float((k_h.cpu().numpy() != omet.cut_positions(out_r[-1].detach().squeeze(2).numpy())).sum()), 0)
+    errs = _param_rel_l2(hipm, refm)
+    worst = max(errs, key=errs.get)
+    report(f"mmoecut encoding_size=64 grad rel-L2 worst ({worst})", errs[worst], 2e-3)
+
+
+@section
 def embed_mmoe():
     B, S = 6, 40
     score = torch.randn(B, S, 1)
