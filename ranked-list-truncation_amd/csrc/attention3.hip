@@ -19,6 +19,9 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef RLT_EXP_DQ_STAGES
+#define RLT_EXP_DQ_STAGES 2
+#endif
 #ifndef RLT_LAZY_MAX
 #define RLT_LAZY_MAX 1
 #endif
@@ -481,13 +484,23 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     f32x16 c_lse, c_del;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c_lse[r] = SEED ? -lse2 : 0.f; c_del[r] = DROP ? 0.f : -del; }
-    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-key hashes of the tile
+    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + RLT_EXP_DQ_STAGES * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     auto issue = [&](int t, int buf) {
         dma_copy<KREC>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
         dma_copy<Rec<HD>::RP>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
+#if RLT_EXP_DQ_STAGES == 1
+    // experiment: ONE tile stage (55 KB at head dim 64) so that two workgroups share a CU; each waits for its own tile,
+    // the other one computes meanwhile
+    for (int t = 0; t < nt; ++t) {
+        const int buf = 0;
+        issue(t, 0);
+        __syncthreads();
+        if (wave_live) {
+            const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+#else
     issue(0, 0);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
@@ -495,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
+#endif
             const uint16_t* kr_lo = kr_hi + rows_elems<HD>();
             const uint16_t* kt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
             const uint16_t* kt_lo = kt_hi + T_elems<HD>();
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 // two tile stages + the [2][KT] dropout hash table
 constexpr size_t HTAB = 2 * KT * sizeof(uint32_t);
 template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
-template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
+template <int HD> size_t dq3_smem() { return (size_t)RLT_EXP_DQ_STAGES * (2 * Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
 template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX) + HTAB; }
 
 template <int HD>
