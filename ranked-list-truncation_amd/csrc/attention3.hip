@@ -667,7 +667,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                 mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
             }
         }
+#if defined(RLT_EXP_NOBARRIER)
+        // timing experiment ONLY (results are wrong): every wavefront waits for its own DMA pieces, no workgroup barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         __syncthreads();
+#endif
     }
     if (!wave_live || key >= B) return;
     float* row = a.dqkv + ((size_t)s * B + key) * ld + h * HD;

@@ -81,7 +81,9 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if not torch.cuda.is_available():
             raise RuntimeError("run.py trains on the GPU through librlt_hip.so; there is no CPU fallback")
-        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        # RLT_RUN_DEVICE / RLT_DIST_BACKEND exist only to rehearse the data-parallel loop on a one-GPU box (several ranks
+        # on cuda:0 over gloo, as bench.py's RLT_BENCH_DEVICE does); real runs use one GPU per rank over RCCL
+        self.device = torch.device("cuda", int(os.environ.get("RLT_RUN_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
         torch.cuda.set_device(self.device)
 
         name = self.model_name
@@ -272,6 +274,7 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help="write a robust04-shaped synthetic set into --dataset-base first")
     p.add_argument('--use-conf', type=int, default=1, help="override lr/batch/dropout/wd/task weights from hyper_parameter_<dataset>.conf")
     p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--history-json', type=str, default=None, help="rank 0 writes the per-epoch train / test means and the best / best-5 figures here")
     p.add_argument('--tensorboard-dir', type=str, default=os.path.join(HERE, 'Tensorboard_summary', 'Truncation'),
                    help="scalars.jsonl (+ tensorboard event files when tensorboard is installed); '' disables")
     return p
@@ -301,8 +304,12 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RLT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.use_conf:
         args = apply_conf(args)
     if args.model_path is None:
@@ -319,6 +326,11 @@ def main(argv=None):
     logging.info('{}'.format(vars(args)))
     trainer = Trainer(args)
     result = trainer.run()
+    if args.history_json and trainer.rank == 0:
+        with open(args.history_json, "w") as f:
+            json.dump({"history": trainer.history, "best_f1": trainer.best_test_f1, "best_dcg": trainer.best_test_dcg,
+                       "best5_f1": trainer.best5_f1, "best5_dcg": trainer.best5_dcg, "best_epoch": trainer.best_epoch,
+                       "world": trainer.world}, f)
     if dist.is_initialized():
         dist.destroy_process_group()
     return result

@@ -31,6 +31,7 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     trainer_bookkeeping  run.py's Trainer vs the same loop on the oracle: per-epoch means, best / best-5, checkpointed
                 epoch and weights, scalar log
     path_level  rlt_encoder_layer_fwd/bwd (composed in the library) == the same launches driven from the host, bit for bit
+    trainer_dp  run.py with two ranks on this GPU (gloo rehearsal) vs the shard-wise oracle: ragged and empty shards
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
     models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
@@ -58,7 +59,7 @@ def probe():
 
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
-                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "path_level", "lstm_generic"]
+                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "path_level", "lstm_generic", "trainer_dp"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
 
 

@@ -1395,6 +1395,83 @@ def path_level():
         report(f"path-level B{B} S{S} E{E} p{p_drop}: weight grads", max(float((ga[n] - gb[n]).abs().max()) for n in ga), 0)
 
 
+
+@section
+def trainer_dp():
+    """run.py under torch.distributed with TWO ranks (both on this GPU, gloo - the rehearsal form) against the shard-wise
+    reference semantics written with the CPU oracle: every batch is cut by shard_bounds (ragged tails: 11 = 4+4+3 train
+    lists -> shards 2+1; 5 = 4+1 test lists -> shards 1+0, an EMPTY shard), each shard is one reference computation, loss /
+    gradient / logged means are weighted by the shards' list counts, one Adam step per batch."""
+    import json
+    import subprocess
+    import tempfile
+    from dataloader import BatchLoader, RankData, write_synthetic_robust04
+    from oracle import losses as ol, metrics as omet, models as om
+    from oracle.weights import fill_state_dict
+    from rlt_hip.parallel import shard_bounds
+    EPOCHS, BS, LR, WD, SEED, WORLD = 3, 4, 1e-4, 0.0025, 7, 2
+    run_py = os.path.join(REPO, "ranked-list-truncation_amd", "run.py")
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=11, n_test=5, seq_len=300, seed=9)
+        ref = om.AttnCut(input_size=3, dropout=0.0)
+        fill_state_dict(ref, 31)
+        ck = os.path.join(tmp, "init")
+        os.makedirs(ck)
+        torch.save(ref.state_dict(), os.path.join(ck, "attncut.pkl"))
+        hist = os.path.join(tmp, "hist.json")
+        env = dict(os.environ, RLT_DIST_BACKEND="gloo", RLT_RUN_DEVICE="0", RLT_PRECISION=N.get_precision())
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={WORLD}", "--master-addr", "127.0.0.1",
+               "--master-port", "29731", run_py, "--model-name", "attncut", "--dataset-base", tmp, "--epochs", str(EPOCHS), "--use-conf", "0",
+               "--batch-size", str(BS), "--criterion", "f1", "--dropout", "0.0", "--lr", str(LR), "--weight-decay", str(WD),
+               "--seed", str(SEED), "--ft", "1", "--model-path", os.path.join(ck, "attncut.pkl"), "--history-json", hist,
+               "--tensorboard-dir", ""]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        report("trainer_dp: 2-rank run.py exit status", float(res.returncode), 0)
+        if res.returncode != 0:
+            print(res.stderr[-3000:])
+            return
+        got = json.load(open(hist))
+        report("trainer_dp: world size seen by the Trainer", abs(got["world"] - WORLD), 0)
+        # ---- shard-wise reference on the oracle
+        opt = torch.optim.Adam(ref.parameters(), lr=LR, weight_decay=WD)
+        crit = ol.DivLoss(metric="f1", div_type="js", augmented=True)
+        rd = RankData("robust04", "drmm_tks", True, tmp)
+        tr = BatchLoader([(rd.getX_train(), rd.gety_train())], BS, True, None, SEED)
+        te = BatchLoader([(rd.getX_test(), rd.gety_test())], BS, True, None, SEED + 1)
+
+        def batch(x, y, train):
+            n = x.shape[0]
+            tot = np.zeros(3)
+            if train:
+                opt.zero_grad()
+            for r in range(WORLD):
+                lo, hi = shard_bounds(n, r, WORLD)
+                if hi == lo:
+                    continue
+                out = ref(x[lo:hi])
+                loss = crit(out, y[lo:hi])
+                if train:
+                    (loss * ((hi - lo) / n)).backward()
+                p = out.detach().squeeze(2).numpy()
+                k = omet.cut_positions(p)
+                tot += (hi - lo) * np.array([loss.item(), omet.Metric.f1(y[lo:hi].numpy(), k), omet.Metric.dcg(y[lo:hi].numpy(), k)])
+            if train:
+                opt.step()
+            return tot / n
+
+        for e in range(EPOCHS):
+            ref.train()
+            rows = [batch(x, y, True) for x, y in tr]
+            want_tr = np.mean(rows, axis=0)
+            ref.eval()
+            with torch.no_grad():
+                rows = [batch(x, y, False) for x, y in te]
+            want_te = np.mean(rows, axis=0)
+            for split, want in (("train", want_tr), ("test", want_te)):
+                g = np.array(got["history"][e][split])
+                report(f"trainer_dp epoch {e} {split} loss/F1/DCG", float(np.abs(g - want).max() / max(1.0, np.abs(want).max())), 1e-4)
+
+
 if __name__ == "__main__":
     want = [w for w in sys.argv[1:] if not w.startswith("--")]
     for w in sys.argv[1:]:
