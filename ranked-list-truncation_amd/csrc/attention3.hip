@@ -22,8 +22,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_EXP_DQ_STAGES
 #define RLT_EXP_DQ_STAGES 2
 #endif
-#ifndef RLT_LAZY_MAX
-#define RLT_LAZY_MAX 1
+#ifndef RLT_HD16_SMALL_MFMA
+#define RLT_HD16_SMALL_MFMA 1        // head dim 16: dV / dK products on v_mfma_f32_16x16x32_bf16 (0: the padded 32x32x16 form)
 #endif
 constexpr float LAZY_TH = 8.f;           // forward: the running-maximum reference moves when a tile exceeds it by > 2^8
 constexpr int LDT3 = 72;                 // bf16 elements per row of a transposed [d][64 rows] image (144 B)
@@ -67,6 +67,12 @@ __device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 
 // position of row `key` (0..63) inside a transposed image row: 16-blocks keep their place, inside a block
 // bits 2 and 3 are swapped (so that accumulator registers 8s..8s+7 of lane-half h are 8 consecutive slots)
 __device__ __forceinline__ constexpr int kpos(int key) { return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); }
+// the same for images consumed by v_mfma_f32_16x16x32_bf16 (head dim 16, dK+dV kernel): after the row exchange of mma_T16
+// k-group g = lane >> 4 of the B operand holds rows {0,16,4,20}[g] + (j&3) + 8(j>>2) of a 32-row block in element j, so
+// row q = b4 b3 b2 b1 b0 sits at position 16 b2 + 8 b4 + 4 b3 + b1b0 of the block
+__device__ __forceinline__ constexpr int kpos16(int key) {
+    return (key & ~28) | ((key & 4) << 2) | ((key & 16) >> 1) | ((key & 8) >> 1);
+}
 
 // ---- staging: a [64 rows][HD] fp32 tile -> registers (each thread: 4 consecutive rows x 4 consecutive d) ----
 template <int HD>
@@ -104,14 +110,15 @@ __device__ __forceinline__ void stage_store_rows(uint16_t* __restrict__ hi, uint
 }
 // transposed image: [d][LDT3] hi / lo, rows permuted by kpos
 template <int HD>
-__device__ __forceinline__ void stage_store_T(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int tid, const Stage<HD>& st) {
+__device__ __forceinline__ void stage_store_T(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int tid, const Stage<HD>& st,
+                                              bool perm16 = false) {
     const int rb = tid / (HD / 4), dq = tid % (HD / 4);
     if (!stage_active<HD>(tid)) return;
     const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
     const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
     const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
     const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
-    const int kp = kpos(4 * rb);
+    const int kp = perm16 ? kpos16(4 * rb) : kpos(4 * rb);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         uint2 h, l;
@@ -173,6 +180,50 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
     }
 }
 
+// Head dim 16: acc[half] (D[row = d][col = key of the 16-key half]) += transposed-image tile (A, 16 rows d, the 32 rows of
+// sub-tile `sub` in kpos16 order) x the accumulator registers w of a 32x32x16 product (B, rows of w = k) on
+// v_mfma_f32_16x16x32_bf16: M = 16 is the head dimension exactly, where the 32x32x16 form multiplies 16 rows of padding.
+// w has its column (key) on the lane and rows 8s..8s+7 (+4 for the upper lane half) in registers; the 16x16x32 B operand
+// wants, per 16-key half, all 32 rows spread over the four 16-lane groups: one v_permlane16_swap per packed register
+// pair moves registers 8..15 of lanes 0-15 / 32-47 to lanes 16-31 / 48-63 and registers 0..7 the other way.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma_T16(const uint16_t* __restrict__ thi, const uint16_t* __restrict__ tlo, int sub, int lane,
+                                        const f32x16& w, f32x4v (&acc)[2], f32x4v* ksum = nullptr) {
+    const float x[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
+    const float y[8] = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
+    bf16x8 xh, xl, yh, yl;
+    split8(x, xh, xl);
+    split8(y, yh, yl);
+    uint4 XH = __builtin_bit_cast(uint4, xh), XL = __builtin_bit_cast(uint4, xl);
+    uint4 YH = __builtin_bit_cast(uint4, yh), YL = __builtin_bit_cast(uint4, yl);
+    uint32_t* xhp = reinterpret_cast<uint32_t*>(&XH); uint32_t* xlp = reinterpret_cast<uint32_t*>(&XL);
+    uint32_t* yhp = reinterpret_cast<uint32_t*>(&YH); uint32_t* ylp = reinterpret_cast<uint32_t*>(&YL);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto rh = __builtin_amdgcn_permlane16_swap(xhp[i], yhp[i], false, false);
+        auto rl = __builtin_amdgcn_permlane16_swap(xlp[i], ylp[i], false, false);
+        xhp[i] = rh[0]; yhp[i] = rh[1];
+        xlp[i] = rl[0]; ylp[i] = rl[1];
+    }
+    const int off = (lane & 15) * LDT3 + sub * 32 + 8 * (lane >> 4);
+    const bf16x8 ah = as_frag(*reinterpret_cast<const uint4*>(thi + off));
+    const bf16x8 al = as_frag(*reinterpret_cast<const uint4*>(tlo + off));
+    const bf16x8 b0h = as_frag(XH), b0l = as_frag(XL), b1h = as_frag(YH), b1l = as_frag(YL);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b0h, acc[0], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b0l, acc[0], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b0h, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b1h, acc[1], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b1l, acc[1], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b1h, acc[1], 0, 0, 0);
+    if (ksum) {          // every row of ksum[half] += sum over the 32 k entries of w (hi + lo), per column: the softmax normaliser
+        const bf16x8 ones = as_frag(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+        ksum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0l, ksum[0], 0, 0, 0);
+        ksum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0h, ksum[0], 0, 0, 0);
+        ksum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1l, ksum[1], 0, 0, 0);
+        ksum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1h, ksum[1], 0, 0, 0);
+    }
+}
+
 template <int HD> constexpr int rows_elems() { return KT * (HD + 8); }     // one hi or lo rows image
 template <int HD> constexpr int T_elems() { return T_rows<HD>() * LDT3; }   // one hi or lo transposed image
 
@@ -222,6 +273,7 @@ struct PrepArgs {
     const float* lse; const float* delta;              // optional aux (dO records)
     uint8_t* out;                                       // records: [matrix][pair][tile]
     int S, B, H, nmat;
+    int perm16[3];                                      // transposed image of matrix m in kpos16 order (head dim 16: Q, dO)
 };
 
 template <int HD>
@@ -249,7 +301,7 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
         for (int i = 0; i < 4; ++i) { st.v[i].x *= mul; st.v[i].y *= mul; st.v[i].z *= mul; st.v[i].w *= mul; }
     }
     stage_store_rows<HD>(r_hi, r_lo, tid, st);
-    stage_store_T<HD>(t_hi, t_lo, tid, st);
+    stage_store_T<HD>(t_hi, t_lo, tid, st, a.perm16[m] != 0);
     if (T_rows<HD>() > HD && tid < KT) t_hi[HD * LDT3 + tid] = 0x3F80;      // bf16 1.0 (lo plane stays 0)
     if (a.lse && tid < KT) {
         const int q = tile * KT + tid, qc = min(q, a.B - 1);
@@ -300,16 +352,21 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-#if RLT_LAZY_MAX
     float m_run = 0.f, l_run = 0.f;          // m_run: the reference the scores are taken relative to (set by the first tile)
     f32x16 c_m;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c_m[r] = 0.f;
-#else
-    float m_run = -INFINITY, l_run = 0.f;
-#endif
-    // head dim 16 without dropout: the normaliser is row HD of O^T (T_rows above; with dropout P.V runs on the dropped P)
-    constexpr bool LROW = T_rows<HD>() > HD && !DROP;
+    // head dim 16: P.V on v_mfma_f32_16x16x32_bf16 (mma_T16), accumulators and normaliser per 16-query half
+    constexpr bool S16 = HD == 16 && RLT_HD16_SMALL_MFMA;
+    // padded 32x32x16 form at head dim 16 without dropout: the normaliser is row HD of O^T (T_rows above; with dropout
+    // P.V runs on the dropped P); 16x16x32 form without dropout: a ones-operand product sums P (LMFMA)
+    constexpr bool LROW = T_rows<HD>() > HD && !DROP && !S16;
+    constexpr bool LMFMA = S16 && !DROP;
+    f32x4v o16[2], l16[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o16[hf][r] = 0.f; l16[hf][r] = 0.f; }
 
     // dropout: hash of this lane's query once; hashes of a tile's keys in LDS, written while the tile is in flight
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);
@@ -332,7 +389,6 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             const uint16_t* v_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
             const uint16_t* v_lo = v_hi + T_elems<HD>();
             f32x16 sc[2];
-#if RLT_LAZY_MAX
             // Lazily rescaled running maximum: the score products start from accumulators holding -m_ref (a 16-register
             // block, the MFMA's C operand), so they come out as s - m_ref with no subtraction per score, and m_ref moves -
             // with the rescale of O and of the normaliser - only when a tile's maximum exceeds it by more than 2^LAZY_TH
@@ -357,10 +413,16 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             if (__any(move)) {            // wave-uniform branch; lanes that do not move shift by 0
                 const float shift = move ? tmax : 0.f;
                 const float alpha = rlt_exp2(-shift);
+                if (S16) {        // the 16x16 accumulators of a lane belong to queries (lane & 15) and 16 + (lane & 15)
+                    const float a0 = __shfl(alpha, lane & 15, 64), a1 = __shfl(alpha, 16 + (lane & 15), 64);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int r = 0; r < 4; ++r) { o16[0][r] *= a0; o16[1][r] *= a1; l16[0][r] *= a0; l16[1][r] *= a1; }
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                }
                 l_run *= alpha;
                 m_run += shift;
 #pragma unroll
@@ -370,34 +432,6 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[sub][r] -= shift;
             }
-            const float m_new = 0.f;      // the scores are already relative to m_run
-#else
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
-                sc[sub] = mma_rows<HD>(k_hi, k_lo, sub, l31, hh, qh, ql, sc[sub]);     // S^T[key][q], log2 domain
-            }
-            if (t == nt - 1) {            // only the last tile can hold keys beyond B
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
-            }
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = rlt_exp2(m_run - m_new);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-#endif
             // per 32-key sub-tile: exponentiate, (drop), feed P.V - the second sub-tile's VALU work is issued while
             // the first sub-tile's MFMAs execute
             float psum = 0.f;
@@ -405,9 +439,9 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = rlt_exp2(RLT_LAZY_MAX ? sc[sub][r] : sc[sub][r] - m_new);
+                    const float p = rlt_exp2(sc[sub][r]);
                     sc[sub][r] = p;
-                    if (!LROW) psum += p;
+                    if (!LROW && !LMFMA) psum += p;
                 }
                 if (DROP) {
                     const uint4* hk4 = reinterpret_cast<const uint4*>(htab + buf * KT + sub * 32 + 4 * hh);
@@ -420,19 +454,30 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
                         sc[sub][4 * gq + 3] = rlt_keep_rc(hq, hk.w, a.drop_thr) ? sc[sub][4 * gq + 3] * inv_keep : 0.f;
                     }
                 }
-                mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
+                if (S16) mma_T16(v_hi, v_lo, sub, lane, sc[sub], o16, LMFMA ? l16 : nullptr);   // O^T[d][q] (+ sum of P)
+                else mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);                        // O^T[d][q]
             }
-#if RLT_LAZY_MAX
-            if (!LROW) l_run += psum;
-            (void)m_new;
-#else
-            if (!LROW) l_run = l_run * alpha + psum;
-            m_run = m_new;
-#endif
+            if (!LROW && !LMFMA) l_run += psum;
         }
         __syncthreads();
     }
     if (!wave_live) return;
+    if (S16) {
+        // normaliser of this lane's own query (l31) and of the two queries its 16x16 accumulators belong to
+        const float l_own = LMFMA ? (l31 < 16 ? l16[0][0] : l16[1][0]) : l_run + __shfl_xor(l_run, 32, 64);
+        const float lq[2] = {LMFMA ? l16[0][0] : __shfl(l_own, lane & 15, 64), LMFMA ? l16[1][0] : __shfl(l_own, 16 + (lane & 15), 64)};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int qq = qt * QT3 + wv * 32 + 16 * hf + (lane & 15);
+            if (qq < B) {
+                const float inv = 1.f / lq[hf];
+                *reinterpret_cast<float4*>(a.o + ((size_t)s * B + qq) * E + h * HD + 4 * (lane >> 4)) =
+                    make_float4(o16[hf][0] * inv, o16[hf][1] * inv, o16[hf][2] * inv, o16[hf][3] * inv);
+            }
+        }
+        if (q < B && hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_own)) * LN2;
+        return;
+    }
     const float l_tot = LROW ? oacc[0][8] : l_run + __shfl_xor(l_run, 32, 64);   // register 8 = row 16 (20 for the upper lane half)
     if (q < B) {
         store_acc_T<HD>(a.o + ((size_t)s * B + q) * E + h * HD, hh, oacc, 1.f / l_tot);
@@ -475,6 +520,12 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    constexpr bool S16 = HD == 16 && RLT_HD16_SMALL_MFMA;         // dQ^T on v_mfma_f32_16x16x32_bf16 (mma_T16)
+    f32x4v dq16[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq16[hf][r] = 0.f;
     // the S and dP products start from accumulators holding -lse and -delta of this lane's query (two register
     // blocks kept for the whole kernel: the MFMA reads them as its C operand), so they come out as S - lse and
     // dP - delta without a subtraction per element.  With dropout delta is subtracted after the mask.  Where the 16
@@ -537,12 +588,24 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                         dp[r] = p * dpr;                                           // dS^T
                     }
                 }
-                mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);                     // dQ^T[d][q] += K^T dS^T
+                if (S16) mma_T16(kt_hi, kt_lo, sub, lane, dp, dq16);               // dQ^T[d][q] += K^T dS^T
+                else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
             }
         }
         __syncthreads();
     }
-    if (!wave_live || q >= B) return;
+    if (!wave_live) return;
+    if (S16) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int qq = qt * QT3 + wv * 32 + 16 * hf + (lane & 15);
+            if (qq < B)
+                *reinterpret_cast<float4*>(a.dqkv + ((size_t)s * B + qq) * ld + h * HD + 4 * (lane >> 4)) =
+                    make_float4(dq16[hf][0] * a.scale, dq16[hf][1] * a.scale, dq16[hf][2] * a.scale, dq16[hf][3] * a.scale);
+        }
+        return;
+    }
+    if (q >= B) return;
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
 }
 
@@ -580,6 +643,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    // head dim 16: the dV / dK products run on v_mfma_f32_16x16x32_bf16 (mma_T16), accumulators per 16-key half
+    f32x4v dk16[2], dv16[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dk16[hf][r] = 0.f; dv16[hf][r] = 0.f; }
 
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-query hashes of the tile
     const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 1u;
@@ -663,8 +732,13 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     }
                     sc[r] = p;
                 }
-                mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                     // dV^T[d][key] += dO^T P
-                mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                     // dK^T[d][key] += (c Q)^T dS
+                if (HD == 16 && RLT_HD16_SMALL_MFMA) {
+                    mma_T16(dt_hi, dt_lo, sub, lane, sc, dv16);                    // dV^T[d][key] += dO^T P
+                    mma_T16(qt_hi, qt_lo, sub, lane, dp, dk16);                    // dK^T[d][key] += (c Q)^T dS
+                } else {
+                    mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                 // dV^T[d][key] += dO^T P
+                    mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                 // dK^T[d][key] += (c Q)^T dS
+                }
             }
         }
 #if defined(RLT_EXP_NOBARRIER)
@@ -674,7 +748,20 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         __syncthreads();
 #endif
     }
-    if (!wave_live || key >= B) return;
+    if (!wave_live) return;
+    if (HD == 16 && RLT_HD16_SMALL_MFMA) {          // D[row = d = 4 (lane >> 4) + r][col = lane & 15]: one float4 per lane and 16-key half
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int kk = ktile * QT3 + wv * 32 + 16 * hf + (lane & 15);
+            if (kk < B) {
+                float* row16 = a.dqkv + ((size_t)s * B + kk) * ld + h * HD + 4 * (lane >> 4);
+                *reinterpret_cast<float4*>(row16 + E) = make_float4(dk16[hf][0] * LN2, dk16[hf][1] * LN2, dk16[hf][2] * LN2, dk16[hf][3] * LN2);
+                *reinterpret_cast<float4*>(row16 + 2 * E) = make_float4(dv16[hf][0], dv16[hf][1], dv16[hf][2], dv16[hf][3]);
+            }
+        }
+        return;
+    }
+    if (key >= B) return;
     float* row = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
     store_acc_T<HD>(row + E, hh, dk, LN2);          // the Q image carries c = scale*log2e: dK = ln2 * dS^T (cQ)
     store_acc_T<HD>(row + 2 * E, hh, dv, 1.f);
@@ -723,6 +810,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         p.src[0] = a.qkv; p.src[1] = a.qkv + E; p.src[2] = a.qkv + 2 * E;
         p.mul[0] = a.scale * LOG2E; p.mul[1] = 1.f; p.mul[2] = 1.f;
         p.ld = (size_t)3 * E; p.out = (uint8_t*)images; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 3;
+        p.perm16[0] = p.perm16[1] = p.perm16[2] = HD == 16 && RLT_HD16_SMALL_MFMA;   // head dim 16: every transposed image feeds mma_T16
         int rc = prepare3<HD>(p, st);
         if (rc) return rc;
     } else if (which == 3) {     // backward prepare: split dO (+ lse, delta)
@@ -730,6 +818,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         p.src[0] = a.dout; p.mul[0] = 1.f; p.ld = (size_t)a.H * HD;
         p.lse = a.lse; p.delta = a.delta;
         p.out = (uint8_t*)dimages; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 1;
+        p.perm16[0] = HD == 16 && RLT_HD16_SMALL_MFMA;       // dO^T likewise
         return prepare3<HD>(p, st);
     }
     return a.drop_p > 0.f ? launch3<HD, true>(which, g, st) : launch3<HD, false>(which, g, st);
