@@ -22,6 +22,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_EXP_DQ_STAGES
 #define RLT_EXP_DQ_STAGES 2
 #endif
+#ifndef RLT_ASM_DMA
+#define RLT_ASM_DMA 1         // dK+dV kernel: LDS-DMA issued as inline assembly (see dma_copy)
+#endif
+#ifndef RLT_STEPPED
+#define RLT_STEPPED 0         // fragment prefetch distance (matrix steps) of the stepped head-dim-64 tile bodies; 0 = compiler-scheduled
+#endif
 #ifndef RLT_HD16_SMALL_MFMA
 #define RLT_HD16_SMALL_MFMA 1        // head dim 16: dV / dK products on v_mfma_f32_16x16x32_bf16 (0: the padded 32x32x16 form)
 #endif
@@ -243,17 +249,36 @@ template <int HD> struct Rec {
 };
 constexpr int QT3 = 256;                  // rows owned by a workgroup of the split-bf16 kernels (8 wavefronts x 32)
 
-// LDS-DMA copy of NBYTES (multiple of 1 KiB) global -> LDS by the 8 wavefronts of the workgroup
-template <int NBYTES>
+// LDS-DMA copy of NBYTES (multiple of 1 KiB) global -> LDS by the 8 wavefronts of the workgroup.
+// ASM: issued as inline assembly.  For a global_load_lds it can see, hipcc's wait-count insertion treats every later
+// ds_read of the workgroup's LDS object as possibly aliasing the copy in flight: it waits with lgkmcnt(0) instead of a
+// counted lgkmcnt(N) after EVERY group of fragment reads, and it may put an s_waitcnt vmcnt(0) in the middle of the tile
+// body, i.e. wait there for the NEXT tile's copy.  The copy of tile t+1 goes to the other stage, so the only ordering
+// needed is dma_wait_barrier<true>() before that stage is read.  Measured (r02_notes.md): dK+dV kernel -2 %, forward
+// kernel +5 % (slower), dQ kernel +1 %; only the dK+dV kernel uses it.
+template <int NBYTES, bool ASM = false>
 __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane) {
     static_assert(NBYTES % 1024 == 0, "LDS-DMA pieces are 1 KiB per wavefront instruction");
 #pragma unroll
     for (int c = 0; c < (NBYTES / 1024 + 7) / 8; ++c) {
         const int chunk = wv + 8 * c;
-        if (chunk < NBYTES / 1024)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc + chunk * 1024 + lane * 16),
-                                             (void __attribute__((address_space(3)))*)(lds_dst + chunk * 1024), 16, 0, 0);
+        if (chunk < NBYTES / 1024) {
+            if constexpr (ASM) {
+                const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
+                const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+            } else {
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc + chunk * 1024 + lane * 16),
+                                                 (void __attribute__((address_space(3)))*)(lds_dst + chunk * 1024), 16, 0, 0);
+            }
+        }
     }
+}
+// every wavefront waits for its own pieces, then the workgroup barrier makes all pieces visible to all wavefronts
+template <bool ASM = false>
+__device__ __forceinline__ void dma_wait_barrier() {
+    if constexpr (ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // fragments of one row of a rows image straight from HBM (no VALU): frag[ks] covers d = 16ks + 8h + j
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    __syncthreads();
+    dma_wait_barrier<>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
@@ -459,7 +484,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             }
             if (!LROW && !LMFMA) l_run += psum;
         }
-        __syncthreads();
+        dma_wait_barrier<>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -548,12 +573,12 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     for (int t = 0; t < nt; ++t) {
         const int buf = 0;
         issue(t, 0);
-        __syncthreads();
+        dma_wait_barrier<>();
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
 #else
     issue(0, 0);
-    __syncthreads();
+    dma_wait_barrier<>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
             }
         }
-        __syncthreads();
+        dma_wait_barrier<>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -653,12 +678,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-query hashes of the tile
     const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 1u;
     auto issue = [&](int t, int buf) {
-        dma_copy<QREC>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<STAGE - QREC>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
+        dma_copy<QREC, (RLT_ASM_DMA != 0 && HD == 64)>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<STAGE - QREC, (RLT_ASM_DMA != 0 && HD == 64)>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    __syncthreads();
+    dma_wait_barrier<(RLT_ASM_DMA != 0 && HD == 64)>();
 #if defined(RLT_EXP_SETPRIO)
     if (wv >= 4) __builtin_amdgcn_s_setprio(1);        // experiment: static priority for the younger half of the workgroup
 #endif
@@ -679,6 +704,81 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const uint16_t* dt_lo = dt_hi + T_elems<HD>();
             const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + 2 * QREC);
             const float* Es = Ls + KT;
+#if RLT_STEPPED
+            if constexpr (HD == 64) {
+                // The 32 matrix steps of a tile (2 sub-tiles x {S, dP, dV, dK} x 4 fragment pairs, 3 MFMAs each) written as a
+                // software pipeline: the two LDS fragments of step i + RLT_STEPPED are read while step i multiplies, and a
+                // scheduling fence after every step (vector / scalar instructions may cross it, MFMAs and LDS reads may not)
+                // keeps hipcc from sinking the reads back next to their use, where every wait exposed the LDS latency.
+                bf16x8 fh[32], fl[32];
+                f32x16 sc2[2], dp2[2];
+                bf16x8 ph[2], pl[2], gh[2], gl[2];           // split P and dS of the current sub-tile (rows 8s..8s+7 of the block)
+                auto frag = [&](int i) {
+                    const int sub = i >> 4, prod = (i >> 2) & 3, k = i & 3;
+                    if (prod < 2) {
+                        const uint16_t* hi = prod == 0 ? qr_hi : dr_hi;
+                        const uint16_t* lo = prod == 0 ? qr_lo : dr_lo;
+                        const int off = (sub * 32 + l31) * (HD + 8) + 8 * hh + 16 * k;
+                        fh[i] = *reinterpret_cast<const bf16x8*>(hi + off);
+                        fl[i] = *reinterpret_cast<const bf16x8*>(lo + off);
+                    } else {
+                        const uint16_t* hi = prod == 2 ? dt_hi : qt_hi;
+                        const uint16_t* lo = prod == 2 ? dt_lo : qt_lo;
+                        const int off = ((k & 1) * 32 + l31) * LDT3 + sub * 32 + 16 * (k >> 1) + 8 * hh;   // k = 2 s + dt
+                        fh[i] = as_frag(*reinterpret_cast<const uint4*>(hi + off));
+                        fl[i] = as_frag(*reinterpret_cast<const uint4*>(lo + off));
+                    }
+                };
+                auto seed = [&](int sub) {                   // accumulators start at -lse[q] and -delta[q]
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = sub * 32 + acc_row(r, hh);
+                        sc2[sub][r] = Ls[ql];
+                        dp2[sub][r] = DROP ? 0.f : Es[ql];
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < RLT_STEPPED; ++i) frag(i);
+                seed(0);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int sub = i >> 4, prod = (i >> 2) & 3, k = i & 3;
+                    if (i + RLT_STEPPED < 32) frag(i + RLT_STEPPED);
+                    if (i == 12) seed(1);
+                    if (prod == 0) sc2[sub] = mfma3(fh[i], fl[i], kh[k], kl[k], sc2[sub]);           // S[q][key] - lse
+                    else if (prod == 1) dp2[sub] = mfma3(fh[i], fl[i], vh[k], vl[k], dp2[sub]);      // dP[q][key] (- delta)
+                    else if (prod == 2) dv[k & 1] = mfma3(fh[i], fl[i], ph[k >> 1], pl[k >> 1], dv[k & 1]);   // dV^T += dO^T P
+                    else dk[k & 1] = mfma3(fh[i], fl[i], gh[k >> 1], gl[k >> 1], dk[k & 1]);         // dK^T += (c Q)^T dS
+                    if (prod == 1 && k == 3) {               // S and dP of the sub-tile complete: P, dS and their bf16 splits
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ql = sub * 32 + acc_row(r, hh);
+                            float pr = rlt_exp2(sc2[sub][r]);
+                            float dpr = dp2[sub][r];
+                            if (DROP) {
+                                const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
+                                dpr = keep ? dpr * inv_keep : 0.f;
+                                dp2[sub][r] = pr * (dpr + Es[ql]);
+                                pr = keep ? pr * inv_keep : 0.f;
+                            } else {
+                                dp2[sub][r] = pr * dpr;
+                            }
+                            sc2[sub][r] = pr;
+                        }
+#pragma unroll
+                        for (int s8 = 0; s8 < 2; ++s8) {
+                            const float x[8] = {sc2[sub][8 * s8 + 0], sc2[sub][8 * s8 + 1], sc2[sub][8 * s8 + 2], sc2[sub][8 * s8 + 3],
+                                                sc2[sub][8 * s8 + 4], sc2[sub][8 * s8 + 5], sc2[sub][8 * s8 + 6], sc2[sub][8 * s8 + 7]};
+                            const float y[8] = {dp2[sub][8 * s8 + 0], dp2[sub][8 * s8 + 1], dp2[sub][8 * s8 + 2], dp2[sub][8 * s8 + 3],
+                                                dp2[sub][8 * s8 + 4], dp2[sub][8 * s8 + 5], dp2[sub][8 * s8 + 6], dp2[sub][8 * s8 + 7]};
+                            split8(x, ph[s8], pl[s8]);
+                            split8(y, gh[s8], gl[s8]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            } else {
+#endif
 #if defined(RLT_EXP_PIPE2)
             // experiment: the S / dP products of BOTH 32-query sub-tiles first, then the element-wise work and the dV / dK
             // products per sub-tile (the scheduler may put sub-tile 1's products under sub-tile 0's VALU work)
@@ -740,12 +840,15 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                 // dK^T[d][key] += (c Q)^T dS
                 }
             }
+#if RLT_STEPPED
+            }
+#endif
         }
 #if defined(RLT_EXP_NOBARRIER)
         // timing experiment ONLY (results are wrong): every wavefront waits for its own DMA pieces, no workgroup barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        __syncthreads();
+        dma_wait_barrier<(RLT_ASM_DMA != 0 && HD == 64)>();
 #endif
     }
     if (!wave_live) return;
