@@ -22,9 +22,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_EXP_DQ_STAGES
 #define RLT_EXP_DQ_STAGES 2
 #endif
-#ifndef RLT_DKV4
-#define RLT_DKV4 0            // head dim 64 dK+dV on the 4-wavefront (one per SIMD, 512-register) kernel
-#endif
 #ifndef RLT_ASM_DMA
 #define RLT_ASM_DMA 1         // dK+dV kernel: LDS-DMA issued as inline assembly (see dma_copy)
 #endif
@@ -259,12 +256,12 @@ constexpr int QT3 = 256;                  // rows owned by a workgroup of the sp
 // body, i.e. wait there for the NEXT tile's copy.  The copy of tile t+1 goes to the other stage, so the only ordering
 // needed is dma_wait_barrier<true>() before that stage is read.  Measured (r02_notes.md): dK+dV kernel -2 %, forward
 // kernel +5 % (slower), dQ kernel +1 %; only the dK+dV kernel uses it.
-template <int NBYTES, bool ASM = false, int NW = 8>
+template <int NBYTES, bool ASM = false>
 __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane) {
     static_assert(NBYTES % 1024 == 0, "LDS-DMA pieces are 1 KiB per wavefront instruction");
 #pragma unroll
-    for (int c = 0; c < (NBYTES / 1024 + NW - 1) / NW; ++c) {
-        const int chunk = wv + NW * c;
+    for (int c = 0; c < (NBYTES / 1024 + 7) / 8; ++c) {
+        const int chunk = wv + 8 * c;
         if (chunk < NBYTES / 1024) {
             if constexpr (ASM) {
                 const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
@@ -873,184 +870,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     store_acc_T<HD>(row + 2 * E, hh, dv, 1.f);
 }
 
-// ------------------------------------------------------------------------------------------ dK + dV, one wavefront per SIMD
-// Head dim 64.  The same 256-key workgroup tile and the same LDS stages as attn3_bwd_dkv_kernel, but FOUR wavefronts that
-// own 64 keys each (two 32-key blocks) and up to 512 registers: one wavefront per SIMD has the matrix pipe and the
-// vector issue to itself (two co-resident wavefronts of the 8-wavefront form ran as if serialised, r02_notes.md), and
-// every Q / dO fragment read from LDS feeds two MFMA groups instead of one.  With nobody to cover a stall the tile body
-// is the explicit software pipeline of the stepped form: the fragments of step i + DKV4_AHEAD are read while step i
-// multiplies, LDS-DMA goes out as inline assembly (counted LDS waits).
-#ifndef RLT_DKV4_AHEAD
-#define RLT_DKV4_AHEAD 2
-#endif
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn3_bwd_dkv4_kernel(Attn3Args g) {
-    const AttnArgs& a = g.a;
-    constexpr int HD = 64, AH = RLT_DKV4_AHEAD;
-    constexpr int QREC = Rec<HD>::RP + Rec<HD>::TP;
-    constexpr int STAGE = 2 * QREC + Rec<HD>::AUX;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD, npair = a.S * H;
-    const size_t ld = (size_t)3 * E;
-    const int nt = rlt_cdiv_dev(B, KT);
-    const int ntile = rlt_cdiv_dev(B, QT3);
-    int pair, ktile;
-    map_block(blockIdx.x, npair, ntile, pair, ktile);
-    const int s = pair / H, h = pair % H;
-    const int key0 = ktile * QT3 + wv * 64;                 // this wavefront's 64 keys = one 64-row record
-    const bool wave_live = key0 < B;
-    const uint32_t ps = pair_seed(a.seed, pair);
-    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-
-    bf16x8 kh[2][4], kl[2][4], vh[2][4], vl[2][4];
-    const int ktl = min(key0 >> 6, nt - 1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, ktl), kb * 32 + l31, hh, kh[kb], kl[kb]);
-        image_row_frags<HD>(record<HD>(g.img, 2, npair, nt, pair, ktl), kb * 32 + l31, hh, vh[kb], vl[kb]);
-    }
-    f32x16 dk[2][2], dv[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[kb][dt][r] = 0.f; dv[kb][dt][r] = 0.f; }
-
-    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);
-    uint32_t hk[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) hk[kb] = DROP ? rlt_col_hash(ps, (uint32_t)(key0 + kb * 32 + l31)) : 1u;
-    auto issue = [&](int t, int buf) {
-        dma_copy<QREC, true, 4>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<STAGE - QREC, true, 4>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);
-        if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
-    };
-    issue(0, 0);
-    dma_wait_barrier<true>();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
-        if (wave_live) {
-            const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
-            const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
-            const uint16_t* qt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
-            const uint16_t* qt_lo = qt_hi + T_elems<HD>();
-            const uint16_t* dr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC);
-            const uint16_t* dr_lo = dr_hi + rows_elems<HD>();
-            const uint16_t* dt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + QREC + Rec<HD>::RP);
-            const uint16_t* dt_lo = dt_hi + T_elems<HD>();
-            const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + 2 * QREC);
-            const float* Es = Ls + KT;
-            // 48 matrix steps per tile, per 32-query sub-tile: S x4 and dP x4 (each fragment pair feeds both key blocks),
-            // then dV x4, dK x4 for key block 0 and again for key block 1 (3 MFMAs per step): the bf16 splits of P and dS
-            // of only one key block are live at a time (the register budget: 128 VGPRs hold this wavefront's K and V
-            // fragments; MFMA results live in AGPRs), and the element-wise work of block 1 runs under the products of block 0.
-            bf16x8 fh[48], fl[48];
-            f32x16 sc[2], dp[2];                              // per key block, of the current 32-query sub-tile
-            bf16x8 ph[2][2], pl[2][2], gh[2][2], gl[2][2];    // split P and dS: [key block][rows 8s..8s+7 of the block]
-            auto frag = [&](int j) {
-                const int sub = j / 24, jj = j % 24, k = jj & 3;
-                const int prod = jj < 8 ? jj >> 2 : 2 + ((jj >> 2) & 1);          // 0 S, 1 dP, 2 dV, 3 dK
-                if (prod < 2) {
-                    const uint16_t* hi = prod == 0 ? qr_hi : dr_hi;
-                    const uint16_t* lo = prod == 0 ? qr_lo : dr_lo;
-                    const int off = (sub * 32 + l31) * (HD + 8) + 8 * hh + 16 * k;
-                    fh[j] = *reinterpret_cast<const bf16x8*>(hi + off);
-                    fl[j] = *reinterpret_cast<const bf16x8*>(lo + off);
-                } else {
-                    const uint16_t* hi = prod == 2 ? dt_hi : qt_hi;
-                    const uint16_t* lo = prod == 2 ? dt_lo : qt_lo;
-                    const int off = ((k & 1) * 32 + l31) * LDT3 + sub * 32 + 16 * (k >> 1) + 8 * hh;   // k = 2 s + dt
-                    fh[j] = as_frag(*reinterpret_cast<const uint4*>(hi + off));
-                    fl[j] = as_frag(*reinterpret_cast<const uint4*>(lo + off));
-                }
-            };
-            auto seed = [&](int sub) {                        // accumulators start at -lse[q] and -delta[q]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    sc[0][r] = sc[1][r] = Ls[ql];
-                    dp[0][r] = dp[1][r] = DROP ? 0.f : Es[ql];
-                }
-            };
-            auto elementwise = [&](int sub, int kb) {         // P, dS and their bf16 splits for one key block
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    float pr = rlt_exp2(sc[kb][r]);
-                    float dpr = dp[kb][r];
-                    if (DROP) {
-                        const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk[kb], a.drop_thr);
-                        dpr = keep ? dpr * inv_keep : 0.f;
-                        dp[kb][r] = pr * (dpr + Es[ql]);
-                        pr = keep ? pr * inv_keep : 0.f;
-                    } else {
-                        dp[kb][r] = pr * dpr;
-                    }
-                    sc[kb][r] = pr;
-                }
-#pragma unroll
-                for (int s8 = 0; s8 < 2; ++s8) {
-                    const float x[8] = {sc[kb][8 * s8 + 0], sc[kb][8 * s8 + 1], sc[kb][8 * s8 + 2], sc[kb][8 * s8 + 3],
-                                        sc[kb][8 * s8 + 4], sc[kb][8 * s8 + 5], sc[kb][8 * s8 + 6], sc[kb][8 * s8 + 7]};
-                    const float y[8] = {dp[kb][8 * s8 + 0], dp[kb][8 * s8 + 1], dp[kb][8 * s8 + 2], dp[kb][8 * s8 + 3],
-                                        dp[kb][8 * s8 + 4], dp[kb][8 * s8 + 5], dp[kb][8 * s8 + 6], dp[kb][8 * s8 + 7]};
-                    split8(x, ph[kb][s8], pl[kb][s8]);
-                    split8(y, gh[kb][s8], gl[kb][s8]);
-                }
-            };
-            auto step_rows = [&](int j) {                     // S / dP: one fragment pair, both key blocks
-                const int jj = j % 24, k = jj & 3;
-                if (j + AH < 48) frag(j + AH);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (jj < 4) sc[kb] = mfma3(fh[j], fl[j], kh[kb][k], kl[kb][k], sc[kb]);          // S[q][key] - lse
-                    else dp[kb] = mfma3(fh[j], fl[j], vh[kb][k], vl[kb][k], dp[kb]);                 // dP[q][key] (- delta)
-                }
-                __builtin_amdgcn_sched_barrier(0x6);
-            };
-            auto step_T = [&](int j, int kb) {                // dV / dK of one key block
-                const int jj = j % 24, k = jj & 3;
-                if (j + AH < 48) frag(j + AH);
-                if (((jj >> 2) & 1) == 0) dv[kb][k & 1] = mfma3(fh[j], fl[j], ph[kb][k >> 1], pl[kb][k >> 1], dv[kb][k & 1]);
-                else dk[kb][k & 1] = mfma3(fh[j], fl[j], gh[kb][k >> 1], gl[kb][k >> 1], dk[kb][k & 1]);
-                __builtin_amdgcn_sched_barrier(0x6);
-            };
-#pragma unroll
-            for (int j = 0; j < AH; ++j) frag(j);
-            seed(0);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) step_rows(sub * 24 + jj);
-                elementwise(sub, 0);
-#pragma unroll
-                for (int jj = 8; jj < 12; ++jj) step_T(sub * 24 + jj, 0);
-                elementwise(sub, 1);
-                if (sub == 0) seed(1);
-#pragma unroll
-                for (int jj = 12; jj < 16; ++jj) step_T(sub * 24 + jj, 0);
-#pragma unroll
-                for (int jj = 16; jj < 24; ++jj) step_T(sub * 24 + jj, 1);
-            }
-        }
-        dma_wait_barrier<true>();
-    }
-    if (!wave_live) return;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int key = key0 + kb * 32 + l31;
-        if (key < B) {
-            float* row = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
-            store_acc_T<HD>(row + E, hh, dk[kb], LN2);
-            store_acc_T<HD>(row + 2 * E, hh, dv[kb], 1.f);
-        }
-    }
-}
-
 // two tile stages + the [2][KT] dropout hash table
 constexpr size_t HTAB = 2 * KT * sizeof(uint32_t);
 template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
@@ -1075,11 +894,6 @@ int launch3(int which, const Attn3Args& g, hipStream_t st) {
         if ((rc = rlt_allow_lds(attn3_fwd_kernel<HD, DROP>, fwd3_smem<HD>()))) return rc;
         hipLaunchKernelGGL((attn3_fwd_kernel<HD, DROP>), dim3(grid), dim3(512), fwd3_smem<HD>(), st, g);
     } else if (which == 1) {
-        if constexpr (HD == 64 && RLT_DKV4 != 0) {
-            if ((rc = rlt_allow_lds(attn3_bwd_dkv4_kernel<DROP>, dkv3_smem<HD>()))) return rc;
-            hipLaunchKernelGGL((attn3_bwd_dkv4_kernel<DROP>), dim3(grid), dim3(256), dkv3_smem<HD>(), st, g);
-            return RLT_LAUNCH_RESULT();
-        }
         if ((rc = rlt_allow_lds(attn3_bwd_dkv_kernel<HD, DROP>, dkv3_smem<HD>()))) return rc;
         hipLaunchKernelGGL((attn3_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(512), dkv3_smem<HD>(), st, g);
     } else {
