@@ -7,7 +7,7 @@ On the GPU box:
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
 then
   python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv \
-         attn3_bwd_dkv_kernel "attncut b4096 s300 bf16x3" > profiles/r01_pmc_traffic.json
+         attn3_bwd_dkv_kernel "attncut b4096 s300 bf16x3" 6 > profiles/r02_pmc_traffic.json   # 6 = warm-up + steps + the 3 kernel-timing steps
 
 Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KB; on gfx950 FETCH_SIZE reports half
 of the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact."""
