@@ -138,6 +138,47 @@ def lstm(B=4096, S=300):
     print(f"bilstm_bwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
 
 
+def overlap(B=4096, S=300):
+    """Does a latency/HBM-bound persistent kernel (BiLSTM backward recurrence, 256 workgroups) share the chip with an
+    MFMA-bound weight-gradient product (TN, M=2048 N=256 K=T, 256 workgroups) issued on a second stream?"""
+    T = S * B
+    gates = torch.randn(T, 1024, device=dev) * 0.5
+    w = torch.randn(2, 512, 128, device=dev) / 12
+    h = torch.empty(T, 256, device=dev)
+    c = torch.empty(T, 256, device=dev)
+    dh = torch.randn(T, 256, device=dev)
+    call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), stream())
+    hid = torch.randn(T, 2048, device=dev)
+    dy = torch.randn(T, 256, device=dev)
+    dw = torch.empty(2048, 256, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def rec():
+        call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, stream())
+
+    def gemm_tn():
+        ops.gemm(1, 0, 2048, 256, T, hid, 2048, dy, 256, dw, 256)
+
+    def both():
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(s1):
+            s1.wait_event(ev)
+            rec()
+            e1 = torch.cuda.Event(); e1.record()
+        with torch.cuda.stream(s2):
+            s2.wait_event(ev)
+            gemm_tn()
+            gemm_tn()
+            e2 = torch.cuda.Event(); e2.record()
+        torch.cuda.current_stream().wait_event(e1)
+        torch.cuda.current_stream().wait_event(e2)
+
+    print(f"bilstm_bwd alone      : {timeit(rec, reps=3):8.3f} ms", flush=True)
+    print(f"2 x dW (TN) alone     : {timeit(lambda: (gemm_tn(), gemm_tn()), reps=3):8.3f} ms", flush=True)
+    print(f"both, two streams     : {timeit(both, reps=3):8.3f} ms", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attention", "gemms", "lstm"]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
