@@ -25,6 +25,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_ASM_DMA
 #define RLT_ASM_DMA 1         // dK+dV kernel: LDS-DMA issued as inline assembly (see dma_copy)
 #endif
+#ifndef RLT_ASM_DMA_HD16
+#define RLT_ASM_DMA_HD16 0    // also at head dims 16 / 32
+#endif
+#ifndef RLT_ASM_DMA_FWD
+#define RLT_ASM_DMA_FWD 1     // the same for the forward kernel
+#endif
+#ifndef RLT_ASM_DMA_DQ
+#define RLT_ASM_DMA_DQ 1      // ... and the dQ kernel
+#endif
+#ifndef RLT_STEPPED_PRIO
+#define RLT_STEPPED_PRIO 1    // wave priority of the MFMA bursts of the stepped tile body (0: no priority flips)
+#endif
 #ifndef RLT_STEPPED
 #define RLT_STEPPED 0         // fragment prefetch distance (matrix steps) of the stepped head-dim-64 tile bodies; 0 = compiler-scheduled
 #endif
@@ -254,8 +266,8 @@ constexpr int QT3 = 256;                  // rows owned by a workgroup of the sp
 // ds_read of the workgroup's LDS object as possibly aliasing the copy in flight: it waits with lgkmcnt(0) instead of a
 // counted lgkmcnt(N) after EVERY group of fragment reads, and it may put an s_waitcnt vmcnt(0) in the middle of the tile
 // body, i.e. wait there for the NEXT tile's copy.  The copy of tile t+1 goes to the other stage, so the only ordering
-// needed is dma_wait_barrier<true>() before that stage is read.  Measured (r02_notes.md): dK+dV kernel -2 %, forward
-// kernel +5 % (slower), dQ kernel +1 %; only the dK+dV kernel uses it.
+// needed is dma_wait_barrier<true>() before that stage is read.  Measured at head dim 64 (r02_notes.md): dK+dV kernel -2 %,
+// forward kernel -1.5 %, dQ kernel -1 % (with frags_ready() below; without it the forward kernel got 5 % slower).
 template <int NBYTES, bool ASM = false>
 __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane) {
     static_assert(NBYTES % 1024 == 0, "LDS-DMA pieces are 1 KiB per wavefront instruction");
@@ -273,6 +285,15 @@ __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __rest
             }
         }
     }
+}
+// Register fragments fetched from HBM before the tile loop must have ARRIVED before the loop: an empty asm statement
+// that consumes them makes hipcc wait here.  Otherwise it places the s_waitcnt vmcnt(N) at their first use inside the
+// loop, with N counting only the loads it knows of - the inline-assembly LDS-DMA pieces are not among them, so from
+// the second tile on that wait stalls the tile body until the NEXT tile's copy has landed.
+template <int N>
+__device__ __forceinline__ void frags_ready(const bf16x8 (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" :: "v"(f[i]));
 }
 // every wavefront waits for its own pieces, then the workgroup barrier makes all pieces visible to all wavefronts
 template <bool ASM = false>
@@ -339,6 +360,16 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     for (int i = tid; i < Rec<HD>::BYTES / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(rec)[i];
 }
 
+#if defined(RLT_STAMPS)
+// timeline instrumentation (variant builds only): s_memtime at tile start / before the tile barrier, per wavefront, for
+// the first 16 tiles of one workgroup; read back with rlt_debug_stamps()
+__device__ unsigned long long rlt_stamp_buf[8 * 16 * 2];
+#define RLT_STAMP(slot) do { if (blockIdx.x == gridDim.x / 2 && t < 16 && lane == 0) \
+    rlt_stamp_buf[(wv * 16 + t) * 2 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RLT_STAMP(slot) do {} while (0)
+#endif
+
 struct Attn3Args {
     AttnArgs a;
     const uint8_t* img;       // Q | K | V records
@@ -371,6 +402,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     {
         const int qtile = min(q >> 6, nt - 1);
         image_row_frags<HD>(record<HD>(g.img, 0, npair, nt, pair, qtile), q & 63, hh, qh, ql);   // Q pre-scaled by scale*log2e
+        frags_ready(qh); frags_ready(ql);
     }
     f32x16 oacc[DT];
 #pragma unroll
@@ -399,12 +431,12 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     auto issue = [&](int t, int buf) {
-        dma_copy<Rec<HD>::RP>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::TP>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
+        dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::TP, (RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    dma_wait_barrier<>();
+    dma_wait_barrier<(RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             }
             if (!LROW && !LMFMA) l_run += psum;
         }
-        dma_wait_barrier<>();
+        dma_wait_barrier<(RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -539,6 +571,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     image_row_frags<HD>(record<HD>(g.dimg, 0, npair, nt, pair, qtile), q & 63, hh, doh, dol);
     const float lse2 = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
     const float del = a.delta[((size_t)s * H + h) * B + qc];
+    frags_ready(qh); frags_ready(ql); frags_ready(doh); frags_ready(dol);
+    asm volatile("" :: "v"(lse2), "v"(del));
 
     f32x16 dq[DT];
 #pragma unroll
@@ -563,8 +597,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + RLT_EXP_DQ_STAGES * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     auto issue = [&](int t, int buf) {
-        dma_copy<KREC>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::RP>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
+        dma_copy<KREC, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
 #if RLT_EXP_DQ_STAGES == 1
@@ -573,12 +607,12 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     for (int t = 0; t < nt; ++t) {
         const int buf = 0;
         issue(t, 0);
-        dma_wait_barrier<>();
+        dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
 #else
     issue(0, 0);
-    dma_wait_barrier<>();
+    dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
@@ -617,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
             }
         }
-        dma_wait_barrier<>();
+        dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -663,6 +697,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     const int ktl = min(key >> 6, nt - 1);
     image_row_frags<HD>(record<HD>(g.img, 1, npair, nt, pair, ktl), key & 63, hh, kh, kl);
     image_row_frags<HD>(record<HD>(g.img, 2, npair, nt, pair, ktl), key & 63, hh, vh, vl);
+    frags_ready(kh); frags_ready(kl); frags_ready(vh); frags_ready(vl);
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -678,17 +713,18 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-query hashes of the tile
     const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 1u;
     auto issue = [&](int t, int buf) {
-        dma_copy<QREC, (RLT_ASM_DMA != 0 && HD == 64)>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<STAGE - QREC, (RLT_ASM_DMA != 0 && HD == 64)>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
+        dma_copy<QREC, (RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<STAGE - QREC, (RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    dma_wait_barrier<(RLT_ASM_DMA != 0 && HD == 64)>();
+    dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
 #if defined(RLT_EXP_SETPRIO)
     if (wv >= 4) __builtin_amdgcn_s_setprio(1);        // experiment: static priority for the younger half of the workgroup
 #endif
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
+        RLT_STAMP(0);
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
 #if defined(RLT_EXP_IGLP)
         __builtin_amdgcn_iglp_opt(RLT_EXP_IGLP);
@@ -706,27 +742,30 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const float* Es = Ls + KT;
 #if RLT_STEPPED
             if constexpr (HD == 64) {
-                // The 32 matrix steps of a tile (2 sub-tiles x {S, dP, dV, dK} x 4 fragment pairs, 3 MFMAs each) written as a
-                // software pipeline: the two LDS fragments of step i + RLT_STEPPED are read while step i multiplies, and a
-                // scheduling fence after every step (vector / scalar instructions may cross it, MFMAs and LDS reads may not)
-                // keeps hipcc from sinking the reads back next to their use, where every wait exposed the LDS latency.
+                // The 32 matrix steps of a tile (3 MFMAs each) as an explicit software pipeline over the two 32-query
+                // sub-tiles a, b:   [S_a dP_a] [S_b dP_b | E_a] [dV_a dK_a | E_b] [dV_b dK_b]
+                // E_x = exp, dS and the bf16 splits of sub-tile x, cut into per-step chunks of a few vector instructions that
+                // sit in the MFMA gaps of the OTHER sub-tile's products (left to itself hipcc keeps program order: the
+                // element-wise block runs between the products it separates and the matrix pipe idles meanwhile - measured
+                // tile time = MFMA cycles + vector issue cycles).  The LDS fragments of step i + RLT_STEPPED are read while
+                // step i multiplies; a full scheduling fence after every step pins all of it.
                 bf16x8 fh[32], fl[32];
                 f32x16 sc2[2], dp2[2];
-                bf16x8 ph[2], pl[2], gh[2], gl[2];           // split P and dS of the current sub-tile (rows 8s..8s+7 of the block)
-                auto frag = [&](int i) {
-                    const int sub = i >> 4, prod = (i >> 2) & 3, k = i & 3;
+                bf16x8 ph[2][2], pl[2][2], gh[2][2], gl[2][2];    // split P and dS: [sub-tile][rows 8s..8s+7 of the block]
+                auto frag = [&](int st) {
+                    const int sub = (st >> 3) & 1, prod = (st >> 4) * 2 + ((st >> 2) & 1), k = st & 3;
                     if (prod < 2) {
                         const uint16_t* hi = prod == 0 ? qr_hi : dr_hi;
                         const uint16_t* lo = prod == 0 ? qr_lo : dr_lo;
                         const int off = (sub * 32 + l31) * (HD + 8) + 8 * hh + 16 * k;
-                        fh[i] = *reinterpret_cast<const bf16x8*>(hi + off);
-                        fl[i] = *reinterpret_cast<const bf16x8*>(lo + off);
+                        fh[st] = *reinterpret_cast<const bf16x8*>(hi + off);
+                        fl[st] = *reinterpret_cast<const bf16x8*>(lo + off);
                     } else {
                         const uint16_t* hi = prod == 2 ? dt_hi : qt_hi;
                         const uint16_t* lo = prod == 2 ? dt_lo : qt_lo;
                         const int off = ((k & 1) * 32 + l31) * LDT3 + sub * 32 + 16 * (k >> 1) + 8 * hh;   // k = 2 s + dt
-                        fh[i] = as_frag(*reinterpret_cast<const uint4*>(hi + off));
-                        fl[i] = as_frag(*reinterpret_cast<const uint4*>(lo + off));
+                        fh[st] = as_frag(*reinterpret_cast<const uint4*>(hi + off));
+                        fl[st] = as_frag(*reinterpret_cast<const uint4*>(lo + off));
                     }
                 };
                 auto seed = [&](int sub) {                   // accumulators start at -lse[q] and -delta[q]
@@ -737,46 +776,73 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                         dp2[sub][r] = DROP ? 0.f : Es[ql];
                     }
                 };
+                auto ew = [&](int sub, int c) {              // chunk c of E_sub: registers 2c, 2c+1 of the score block
+#pragma unroll
+                    for (int r = 2 * c; r < 2 * c + 2; ++r) {
+                        const int ql = sub * 32 + acc_row(r, hh);
+                        float pr = rlt_exp2(sc2[sub][r]);
+                        float dpr = dp2[sub][r];
+                        if (DROP) {
+                            const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
+                            dpr = keep ? dpr * inv_keep : 0.f;
+                            dp2[sub][r] = pr * (dpr + Es[ql]);
+                            pr = keep ? pr * inv_keep : 0.f;
+                        } else {
+                            dp2[sub][r] = pr * dpr;
+                        }
+                        sc2[sub][r] = pr;
+                    }
+                };
+                auto split_half = [&](const f32x16& w, int s8, bf16x8& hi, bf16x8& lo) {
+                    const float x[8] = {w[8 * s8 + 0], w[8 * s8 + 1], w[8 * s8 + 2], w[8 * s8 + 3],
+                                        w[8 * s8 + 4], w[8 * s8 + 5], w[8 * s8 + 6], w[8 * s8 + 7]};
+                    split8(x, hi, lo);
+                };
 #pragma unroll
                 for (int i = 0; i < RLT_STEPPED; ++i) frag(i);
                 seed(0);
+                auto mm = [&](int st) {                      // the fragment reads of step st + RLT_STEPPED and the 3 MFMAs of step st
+                    const int sub = (st >> 3) & 1, prod = (st >> 4) * 2 + ((st >> 2) & 1), k = st & 3;
+                    if (st + RLT_STEPPED < 32) frag(st + RLT_STEPPED);
+                    if (prod == 0) sc2[sub] = mfma3(fh[st], fl[st], kh[k], kl[k], sc2[sub]);           // S[q][key] - lse
+                    else if (prod == 1) dp2[sub] = mfma3(fh[st], fl[st], vh[k], vl[k], dp2[sub]);      // dP[q][key] (- delta)
+                    else if (prod == 2) dv[k & 1] = mfma3(fh[st], fl[st], ph[sub][k >> 1], pl[sub][k >> 1], dv[k & 1]);   // dV^T += dO^T P
+                    else dk[k & 1] = mfma3(fh[st], fl[st], gh[sub][k >> 1], gl[sub][k >> 1], dk[k & 1]);                 // dK^T += (c Q)^T dS
+                };
+                auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+                // One product (4 steps, 12 MFMAs) is a burst at raised wave priority; the element-wise half-block that follows
+                // it runs at priority 0.  The two wavefronts of a SIMD share its vector issue port, arbitrated by priority, then
+                // age: at equal priority the older wavefront takes every slot it can use (timeline stamps, r02_notes.md:
+                // wavefronts 0-3 finish a tile in 6,400 cycles and wait 3,000 at the barrier, 4-7 need 8,950), and the matrix
+                // pipe idles whenever the older one issues vector work.  With the flips, a wavefront in its MFMA burst wins the
+                // port and its partner's vector work fills the slots between the MFMA issues.
+                auto burst = [&](int g) {
+                    __builtin_amdgcn_s_setprio(RLT_STEPPED_PRIO);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int sub = i >> 4, prod = (i >> 2) & 3, k = i & 3;
-                    if (i + RLT_STEPPED < 32) frag(i + RLT_STEPPED);
-                    if (i == 12) seed(1);
-                    if (prod == 0) sc2[sub] = mfma3(fh[i], fl[i], kh[k], kl[k], sc2[sub]);           // S[q][key] - lse
-                    else if (prod == 1) dp2[sub] = mfma3(fh[i], fl[i], vh[k], vl[k], dp2[sub]);      // dP[q][key] (- delta)
-                    else if (prod == 2) dv[k & 1] = mfma3(fh[i], fl[i], ph[k >> 1], pl[k >> 1], dv[k & 1]);   // dV^T += dO^T P
-                    else dk[k & 1] = mfma3(fh[i], fl[i], gh[k >> 1], gl[k >> 1], dk[k & 1]);         // dK^T += (c Q)^T dS
-                    if (prod == 1 && k == 3) {               // S and dP of the sub-tile complete: P, dS and their bf16 splits
+                    for (int st = 4 * g; st < 4 * g + 4; ++st) { mm(st); fence(); }
+                    __builtin_amdgcn_s_setprio(0);
+                };
+                auto ew_half = [&](int sub, int half) {      // registers 8 half .. 8 half + 7 of the block: P, dS and their splits
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ql = sub * 32 + acc_row(r, hh);
-                            float pr = rlt_exp2(sc2[sub][r]);
-                            float dpr = dp2[sub][r];
-                            if (DROP) {
-                                const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
-                                dpr = keep ? dpr * inv_keep : 0.f;
-                                dp2[sub][r] = pr * (dpr + Es[ql]);
-                                pr = keep ? pr * inv_keep : 0.f;
-                            } else {
-                                dp2[sub][r] = pr * dpr;
-                            }
-                            sc2[sub][r] = pr;
-                        }
-#pragma unroll
-                        for (int s8 = 0; s8 < 2; ++s8) {
-                            const float x[8] = {sc2[sub][8 * s8 + 0], sc2[sub][8 * s8 + 1], sc2[sub][8 * s8 + 2], sc2[sub][8 * s8 + 3],
-                                                sc2[sub][8 * s8 + 4], sc2[sub][8 * s8 + 5], sc2[sub][8 * s8 + 6], sc2[sub][8 * s8 + 7]};
-                            const float y[8] = {dp2[sub][8 * s8 + 0], dp2[sub][8 * s8 + 1], dp2[sub][8 * s8 + 2], dp2[sub][8 * s8 + 3],
-                                                dp2[sub][8 * s8 + 4], dp2[sub][8 * s8 + 5], dp2[sub][8 * s8 + 6], dp2[sub][8 * s8 + 7]};
-                            split8(x, ph[s8], pl[s8]);
-                            split8(y, gh[s8], gl[s8]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0x6);
-                }
+                    for (int c = 4 * half; c < 4 * half + 4; ++c) ew(sub, c);
+                    split_half(sc2[sub], half, ph[sub][half], pl[sub][half]);
+                    split_half(dp2[sub], half, gh[sub][half], gl[sub][half]);
+                    fence();
+                };
+                burst(0);                                    // S_a
+                seed(1);
+                fence();
+                burst(1);                                    // dP_a
+                burst(2);                                    // S_b
+                ew_half(0, 0);
+                burst(3);                                    // dP_b
+                ew_half(0, 1);
+                burst(4);                                    // dV_a
+                ew_half(1, 0);
+                burst(5);                                    // dK_a
+                ew_half(1, 1);
+                burst(6);                                    // dV_b
+                burst(7);                                    // dK_b
             } else {
 #endif
 #if defined(RLT_EXP_PIPE2)
@@ -844,11 +910,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             }
 #endif
         }
+        RLT_STAMP(1);
 #if defined(RLT_EXP_NOBARRIER)
         // timing experiment ONLY (results are wrong): every wavefront waits for its own DMA pieces, no workgroup barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        dma_wait_barrier<(RLT_ASM_DMA != 0 && HD == 64)>();
+        dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
 #endif
     }
     if (!wave_live) return;
@@ -928,6 +995,12 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
 }
 
 }  // namespace
+
+#if defined(RLT_STAMPS)
+extern "C" int rlt_debug_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rlt_stamp_buf), n * sizeof(unsigned long long));
+}
+#endif
 
 size_t rlt_attn3_images_bytes(int S, int B, int H, int HD, int nmat) {
     const size_t nt = (size_t)rlt_cdiv(B, KT);

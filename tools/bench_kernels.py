@@ -179,6 +179,28 @@ def overlap(B=4096, S=300):
     print(f"both, two streams     : {timeit(both, reps=3):8.3f} ms", flush=True)
 
 
+def stamps():
+    """Timeline of one dK+dV workgroup (library built with -DRLT_STAMPS): per wavefront and tile, cycles spent computing
+    (tile start -> before the barrier) and the start offsets relative to wavefront 0."""
+    import ctypes
+    attention()
+    buf = (ctypes.c_ulonglong * 256)()
+    fn = N.load().rlt_debug_stamps
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    rc = fn(buf, 256)
+    assert rc == 0, rc
+    v = list(buf)
+    t00 = v[0]
+    print("wave: per tile (start - wave0 tile0 start, compute cycles)")
+    for w in range(8):
+        row = []
+        for t in range(2, 10):
+            a, b = v[(w * 16 + t) * 2], v[(w * 16 + t) * 2 + 1]
+            row.append(f"{a - t00:7d}+{b - a:5d}")
+        print(f"  w{w}: " + "  ".join(row))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attention", "gemms", "lstm"]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
