@@ -34,11 +34,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_ASM_DMA_DQ
 #define RLT_ASM_DMA_DQ 1      // ... and the dQ kernel
 #endif
+#ifndef RLT_STEPPED_SPREAD
+#define RLT_STEPPED_SPREAD 1  // stepped tile body: LDS-DMA pieces of the next tile spread over the matrix steps
+#endif
+#ifndef RLT_SPREAD_EVERY
+#define RLT_SPREAD_EVERY 3    // one piece every so many matrix steps (10 pieces per wavefront and tile, 32 steps)
+#endif
 #ifndef RLT_STEPPED_PRIO
 #define RLT_STEPPED_PRIO 1    // wave priority of the MFMA bursts of the stepped tile body (0: no priority flips)
 #endif
 #ifndef RLT_STEPPED
-#define RLT_STEPPED 0         // fragment prefetch distance (matrix steps) of the stepped head-dim-64 tile bodies; 0 = compiler-scheduled
+#define RLT_STEPPED 2         // dK+dV, head dim 64: stepped tile body with this fragment prefetch distance (matrix steps); 0 = compiler-scheduled body
 #endif
 #ifndef RLT_HD16_SMALL_MFMA
 #define RLT_HD16_SMALL_MFMA 1        // head dim 16: dV / dK products on v_mfma_f32_16x16x32_bf16 (0: the padded 32x32x16 form)
@@ -286,6 +292,18 @@ __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __rest
         }
     }
 }
+// one piece (`c`-th 1 KiB chunk of this wavefront) of dma_copy, inline-assembly form: for tile bodies that spread the copy
+// of the next tile over their matrix steps
+template <int NBYTES>
+__device__ __forceinline__ void dma_piece(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane, int c) {
+    const int chunk = wv + 8 * c;
+    if (chunk < NBYTES / 1024) {
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
+        const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+    }
+}
+
 // Register fragments fetched from HBM before the tile loop must have ARRIVED before the loop: an empty asm statement
 // that consumes them makes hipcc wait here.  Otherwise it places the s_waitcnt vmcnt(N) at their first use inside the
 // loop, with N counting only the loads it knows of - the inline-assembly LDS-DMA pieces are not among them, so from
@@ -689,7 +707,11 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     map_block(blockIdx.x, npair, ntile, pair, ktile);
     const int s = pair / H, h = pair % H;
     const int key = ktile * QT3 + wv * 32 + l31;
+#if defined(RLT_EXP_HALFWAVES)
+    const bool wave_live = ktile * QT3 + wv * 32 < B && wv < 4;      // timing experiment: one working wavefront per SIMD
+#else
     const bool wave_live = ktile * QT3 + wv * 32 < B;
+#endif
     const uint32_t ps = pair_seed(a.seed, pair);
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
@@ -725,7 +747,15 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         RLT_STAMP(0);
+#if RLT_STEPPED && RLT_STEPPED_SPREAD
+        // stepped head-dim-64 body: the copy of tile t+1 is spread over the matrix steps (below); all 8 wavefronts issuing their
+        // ~10 pieces at the top of the tile cost every one of them ~1,500 cycles before the first MFMA (timeline stamps)
+        // (a wavefront without keys runs no matrix steps and issues its pieces here)
+        if (HD != 64 || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
+        else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
+#else
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
+#endif
 #if defined(RLT_EXP_IGLP)
         __builtin_amdgcn_iglp_opt(RLT_EXP_IGLP);
 #endif
@@ -801,8 +831,22 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #pragma unroll
                 for (int i = 0; i < RLT_STEPPED; ++i) frag(i);
                 seed(0);
+                const bool more = t + 1 < nt;
+                // piece pc (0..9) of this wavefront's share of the copy of tile t+1: 5 pieces of the Q record, 5 of the dO
+                // record; the record addresses are computed once per tile (address arithmetic inside the bursts cost 15 %)
+                const uint8_t* nq = record<HD>(g.img, 0, npair, nt, pair, min(t + 1, nt - 1));
+                const uint8_t* nd = record<HD>(g.dimg, 0, npair, nt, pair, min(t + 1, nt - 1));
+                uint8_t* nl = lds + (buf ^ 1) * STAGE;
+                auto next_piece = [&](int pc) {
+                    if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
+                    else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
+                };
                 auto mm = [&](int st) {                      // the fragment reads of step st + RLT_STEPPED and the 3 MFMAs of step st
                     const int sub = (st >> 3) & 1, prod = (st >> 4) * 2 + ((st >> 2) & 1), k = st & 3;
+#if RLT_STEPPED_SPREAD
+                    if (RLT_SPREAD_EVERY > 0 && st % (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) == 0 && st / (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) < 10 && more)
+                        next_piece(st / (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1));
+#endif
                     if (st + RLT_STEPPED < 32) frag(st + RLT_STEPPED);
                     if (prod == 0) sc2[sub] = mfma3(fh[st], fl[st], kh[k], kl[k], sc2[sub]);           // S[q][key] - lse
                     else if (prod == 1) dp2[sub] = mfma3(fh[st], fl[st], vh[k], vl[k], dp2[sub]);      // dP[q][key] (- delta)
@@ -821,6 +865,11 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #pragma unroll
                     for (int st = 4 * g; st < 4 * g + 4; ++st) { mm(st); fence(); }
                     __builtin_amdgcn_s_setprio(0);
+                    if (RLT_SPREAD_EVERY == 0 && more) {      // pieces behind the bursts, at priority 0
+                        next_piece(g);
+                        if (g < 2) next_piece(8 + g);
+                        fence();
+                    }
                 };
                 auto ew_half = [&](int sub, int half) {      // registers 8 half .. 8 half + 7 of the block: P, dS and their splits
 #pragma unroll
