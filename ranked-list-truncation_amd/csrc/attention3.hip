@@ -37,6 +37,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_STEPPED_SPREAD
 #define RLT_STEPPED_SPREAD 1  // stepped tile body: LDS-DMA pieces of the next tile spread over the matrix steps
 #endif
+#ifndef RLT_FWD_SPREAD
+#define RLT_FWD_SPREAD 0      // forward kernel, head dim 64: LDS-DMA pieces spread over the tile body (measured +2 %: off)
+#endif
+#ifndef RLT_DQ_SPREAD
+#define RLT_DQ_SPREAD 1       // dQ kernel likewise (measured -2 %)
+#endif
 #ifndef RLT_SPREAD_EVERY
 #define RLT_SPREAD_EVERY 3    // one piece every so many matrix steps (10 pieces per wavefront and tile, 32 steps)
 #endif
@@ -457,8 +463,22 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     dma_wait_barrier<(RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
+        // head dim 64: the 4-5 LDS-DMA pieces of a wavefront are spread over the tile body instead of all 8 wavefronts
+        // issuing everything before their first MFMA (see the dK+dV kernel); a wavefront without queries issues at the top
+        constexpr bool SPREAD = RLT_FWD_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_FWD != 0;
+        const bool more = t + 1 < nt;
+        if (!SPREAD || !wave_live) { if (more) issue(t + 1, buf ^ 1); }
+        else if (DROP && more && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
+        const uint8_t* nk = record<HD>(g.img, 1, npair, nt, pair, min(t + 1, nt - 1));
+        const uint8_t* nv = record<HD>(g.img, 2, npair, nt, pair, min(t + 1, nt - 1)) + Rec<HD>::RP;
+        uint8_t* nl = lds + (buf ^ 1) * STAGE;
+        auto piece = [&](int pc) {                    // 0..2: K rows image, 3..5: V transposed image
+            if (!SPREAD || !more) return;
+            if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nk, wv, lane, pc);
+            else dma_piece<Rec<HD>::TP>(nl + Rec<HD>::RP, nv, wv, lane, pc - 3);
+        };
         if (wave_live) {
+            piece(0);
             const uint16_t* k_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
             const uint16_t* k_lo = k_hi + rows_elems<HD>();
             const uint16_t* v_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
@@ -471,6 +491,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             // reference, so the result is the same softmax.  Per tile this saves 32 subtractions and 16*DT multiplies.
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) sc[sub] = mma_rows<HD>(k_hi, k_lo, sub, l31, hh, qh, ql, c_m);   // S^T[key][q] - m_ref
+            piece(1);
             if (t == nt - 1) {            // only the last tile can hold keys beyond B
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -507,6 +528,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[sub][r] -= shift;
             }
+            piece(2);
             // per 32-key sub-tile: exponentiate, (drop), feed P.V - the second sub-tile's VALU work is issued while
             // the first sub-tile's MFMAs execute
             float psum = 0.f;
@@ -529,8 +551,10 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
                         sc[sub][4 * gq + 3] = rlt_keep_rc(hq, hk.w, a.drop_thr) ? sc[sub][4 * gq + 3] * inv_keep : 0.f;
                     }
                 }
+                piece(3 + 2 * sub);
                 if (S16) mma_T16(v_hi, v_lo, sub, lane, sc[sub], o16, LMFMA ? l16 : nullptr);   // O^T[d][q] (+ sum of P)
                 else mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);                        // O^T[d][q]
+                if (sub == 0) piece(4);
             }
             if (!LROW && !LMFMA) l_run += psum;
         }
@@ -614,6 +638,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     for (int r = 0; r < 16; ++r) { c_lse[r] = SEED ? -lse2 : 0.f; c_del[r] = DROP ? 0.f : -del; }
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + RLT_EXP_DQ_STAGES * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+    // head dim 64: the 7-8 LDS-DMA pieces of a wavefront spread over the tile body (see the dK+dV kernel)
+    constexpr bool SPREAD = RLT_DQ_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_DQ != 0 && RLT_EXP_DQ_STAGES == 2;
     auto issue = [&](int t, int buf) {
         dma_copy<KREC, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
         dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
@@ -633,7 +659,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
+        if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
+        else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
 #endif
@@ -642,10 +669,22 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
             const uint16_t* kt_lo = kt_hi + T_elems<HD>();
             const uint16_t* vr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + KREC);
             const uint16_t* vr_lo = vr_hi + rows_elems<HD>();
+            const bool more = t + 1 < nt;
+            const uint8_t* nk = record<HD>(g.img, 1, npair, nt, pair, min(t + 1, nt - 1));
+            const uint8_t* nv = record<HD>(g.img, 2, npair, nt, pair, min(t + 1, nt - 1));
+            uint8_t* nl = lds + ((t & 1) ^ 1) * STAGE;
+            auto piece = [&](int pc) {                // 0..4: K record (rows + transposed), 5..7: V rows image
+                if (!SPREAD || !more) return;
+                if (pc < 5) dma_piece<KREC>(nl, nk, wv, lane, pc);
+                else dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 5);
+            };
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                piece(4 * sub);
                 f32x16 sc = mma_rows<HD>(kr_hi, kr_lo, sub, l31, hh, qh, ql, c_lse);      // S^T[key][q] - lse
+                piece(4 * sub + 1);
                 f32x16 dp = mma_rows<HD>(vr_hi, vr_lo, sub, l31, hh, doh, dol, c_del);    // dP^T[key][q] (- delta)
+                piece(4 * sub + 2);
                 if (t == nt - 1) {            // only the last tile can hold keys beyond B
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -665,6 +704,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                         dp[r] = p * dpr;                                           // dS^T
                     }
                 }
+                piece(4 * sub + 3);
                 if (S16) mma_T16(kt_hi, kt_lo, sub, lane, dp, dq16);               // dQ^T[d][q] += K^T dS^T
                 else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
             }
