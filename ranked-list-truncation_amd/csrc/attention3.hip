@@ -19,9 +19,6 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef RLT_EXP_DQ_STAGES
-#define RLT_EXP_DQ_STAGES 2
-#endif
 #ifndef RLT_ASM_DMA
 #define RLT_ASM_DMA 1         // dK+dV kernel: LDS-DMA issued as inline assembly (see dma_copy)
 #endif
@@ -636,25 +633,15 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     f32x16 c_lse, c_del;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c_lse[r] = SEED ? -lse2 : 0.f; c_del[r] = DROP ? 0.f : -del; }
-    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + RLT_EXP_DQ_STAGES * STAGE);          // dropout: per-key hashes of the tile
+    uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     // head dim 64: the 7-8 LDS-DMA pieces of a wavefront spread over the tile body (see the dK+dV kernel)
-    constexpr bool SPREAD = RLT_DQ_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_DQ != 0 && RLT_EXP_DQ_STAGES == 2;
+    constexpr bool SPREAD = RLT_DQ_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_DQ != 0;
     auto issue = [&](int t, int buf) {
         dma_copy<KREC, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
         dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
-#if RLT_EXP_DQ_STAGES == 1
-    // experiment: ONE tile stage (55 KB at head dim 64) so that two workgroups share a CU; each waits for its own tile,
-    // the other one computes meanwhile
-    for (int t = 0; t < nt; ++t) {
-        const int buf = 0;
-        issue(t, 0);
-        dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
-        if (wave_live) {
-            const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
-#else
     issue(0, 0);
     dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
     for (int t = 0; t < nt; ++t) {
@@ -663,7 +650,6 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
-#endif
             const uint16_t* kr_lo = kr_hi + rows_elems<HD>();
             const uint16_t* kt_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
             const uint16_t* kt_lo = kt_hi + T_elems<HD>();
@@ -747,11 +733,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     map_block(blockIdx.x, npair, ntile, pair, ktile);
     const int s = pair / H, h = pair % H;
     const int key = ktile * QT3 + wv * 32 + l31;
-#if defined(RLT_EXP_HALFWAVES)
-    const bool wave_live = ktile * QT3 + wv * 32 < B && wv < 4;      // timing experiment: one working wavefront per SIMD
-#else
     const bool wave_live = ktile * QT3 + wv * 32 < B;
-#endif
     const uint32_t ps = pair_seed(a.seed, pair);
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
@@ -781,9 +763,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     };
     issue(0, 0);
     dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
-#if defined(RLT_EXP_SETPRIO)
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);        // experiment: static priority for the younger half of the workgroup
-#endif
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         RLT_STAMP(0);
@@ -795,9 +774,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
 #else
         if (t + 1 < nt) issue(t + 1, buf ^ 1);
-#endif
-#if defined(RLT_EXP_IGLP)
-        __builtin_amdgcn_iglp_opt(RLT_EXP_IGLP);
 #endif
         if (wave_live) {
             const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
@@ -934,28 +910,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                 burst(7);                                    // dK_b
             } else {
 #endif
-#if defined(RLT_EXP_PIPE2)
-            // experiment: the S / dP products of BOTH 32-query sub-tiles first, then the element-wise work and the dV / dK
-            // products per sub-tile (the scheduler may put sub-tile 1's products under sub-tile 0's VALU work)
-            f32x16 sc2[2], dp2[2];
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = sub * 32 + acc_row(r, hh);
-                    sc2[sub][r] = Ls[ql];
-                    dp2[sub][r] = DROP ? 0.f : Es[ql];
-                }
-                sc2[sub] = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc2[sub]);
-                dp2[sub] = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp2[sub]);
-            }
-#if RLT_EXP_PIPE2 == 2
-            __builtin_amdgcn_sched_barrier(0);       // all four products issued before any element-wise work
-#endif
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 sc = sc2[sub], dp = dp2[sub];
-#else
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 // the accumulators start at -lse[q] and -delta[q] (the aux block of the dO record holds them negated),
@@ -970,7 +924,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                 }
                 sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] - lse (Q carries scale*log2e)
                 dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key] (- delta)
-#endif
                 // queries beyond B need no mask: their columns of the transposed Q / dO images are zero, p is finite
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1000,12 +953,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #endif
         }
         RLT_STAMP(1);
-#if defined(RLT_EXP_NOBARRIER)
-        // timing experiment ONLY (results are wrong): every wavefront waits for its own DMA pieces, no workgroup barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
-#endif
     }
     if (!wave_live) return;
     if (HD == 16 && RLT_HD16_SMALL_MFMA) {          // D[row = d = 4 (lane >> 4) + r][col = lane & 15]: one float4 per lane and 16-key half
@@ -1029,7 +977,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 // two tile stages + the [2][KT] dropout hash table
 constexpr size_t HTAB = 2 * KT * sizeof(uint32_t);
 template <int HD> size_t fwd3_smem() { return (size_t)2 * (Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
-template <int HD> size_t dq3_smem() { return (size_t)RLT_EXP_DQ_STAGES * (2 * Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
+template <int HD> size_t dq3_smem() { return (size_t)2 * (2 * Rec<HD>::RP + Rec<HD>::TP) + HTAB; }
 template <int HD> size_t dkv3_smem() { return (size_t)2 * (2 * (Rec<HD>::RP + Rec<HD>::TP) + Rec<HD>::AUX) + HTAB; }
 
 template <int HD>
