@@ -397,25 +397,39 @@ __global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ g
 #pragma unroll
     for (int u = 0; u < 8; ++u) { dc[u] = 0.f; dhrec[u] = 0.f; }
 
+    // Operands of a time step (the lane's 2 x 4 units): the stashed gates i,f,g,o, dL/dh_out and c_{t-1}.  None of them
+    // depends on the recurrence, so the set of step t-1 is fetched while step t runs its MFMAs and the partial-sum
+    // exchange (with the loads at the top of the step, every one of the S steps exposed a full HBM latency);
+    // c_t of step t-1 is c_{t-1} of step t and is kept.
+    struct StepIn { float4 gv[2][4], cp[2], dh[2]; };
+    auto tok_of = [&](int t) { return (size_t)(dir ? S - 1 - t : t) * B + (valid ? b : 0); };
+    auto fetch = [&](int t, StepIn& in) {
+        const size_t tok = tok_of(t), tokp = tok_of(t > 0 ? t - 1 : t);
+        const float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+#pragma unroll
+        for (int uh = 0; uh < 2; ++uh) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) in.gv[uh][g] = *reinterpret_cast<const float4*>(grow + g * HID + 4 * uh);
+            in.cp[uh] = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol + 4 * uh);   // step 0: unused (c_{-1} = 0)
+            in.dh[uh] = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol + 4 * uh);
+        }
+    };
+    StepIn cur;
+    float4 ctc[2];
+    fetch(S - 1, cur);
+#pragma unroll
+    for (int uh = 0; uh < 2; ++uh) ctc[uh] = *reinterpret_cast<const float4*>(cst + (tok_of(S - 1) * 2 + dir) * HID + ucol + 4 * uh);
+
     for (int t = S - 1; t >= 0; --t) {
-        const int s = dir ? S - 1 - t : t;
-        const size_t tok = (size_t)s * B + (valid ? b : 0);
-        const size_t tokp = (size_t)(t > 0 ? (dir ? s + 1 : s - 1) : s) * B + (valid ? b : 0);
-        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
+        float* grow = gates + tok_of(t) * (8 * HID) + dir * 4 * HID + ucol;
         bf16x8 dah[4], dal[4];
 #pragma unroll
         for (int uh = 0; uh < 2; ++uh) {
-            float4 gv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4*>(grow + g * HID + 4 * uh);
-            const float4 ct4 = *reinterpret_cast<const float4*>(cst + (tok * 2 + dir) * HID + ucol + 4 * uh);
-            const float4 cpl = *reinterpret_cast<const float4*>(cst + (tokp * 2 + dir) * HID + ucol + 4 * uh);
-            const float4 cp4 = t > 0 ? cpl : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 dh4 = *reinterpret_cast<const float4*>(d_hout + tok * (2 * HID) + dir * HID + ucol + 4 * uh);
-            const float* gf_ = reinterpret_cast<const float*>(&gv[0]);
-            const float* ct = reinterpret_cast<const float*>(&ct4);
+            const float* gf_ = reinterpret_cast<const float*>(&cur.gv[uh][0]);
+            const float* ct = reinterpret_cast<const float*>(&ctc[uh]);
+            const float4 cp4 = t > 0 ? cur.cp[uh] : make_float4(0.f, 0.f, 0.f, 0.f);      // (no select at fetch time: it would wait for the load)
             const float* cp = reinterpret_cast<const float*>(&cp4);
-            const float* dho = reinterpret_cast<const float*>(&dh4);
+            const float* dho = reinterpret_cast<const float*>(&cur.dh[uh]);
             float dA[16];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -440,8 +454,10 @@ __global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ g
                                     dA[8 * pgate + 4], dA[8 * pgate + 5], dA[8 * pgate + 6], dA[8 * pgate + 7]};
                 split8(x, dah[2 * pgate + uh], dal[2 * pgate + uh]);
             }
+            ctc[uh] = cur.cp[uh];                  // c_{t-1}: the cell state of the step that runs next
         }
         if (t == 0) break;
+        fetch(t - 1, cur);                         // in flight during the MFMAs and the exchange below
         float* pw = P + (size_t)(w * LISTS + l31) * LDP8 + 4 * hh;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
