@@ -20,16 +20,13 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_ASM_DMA
-#define RLT_ASM_DMA 1         // dK+dV kernel: LDS-DMA issued as inline assembly (see dma_copy)
+#define RLT_ASM_DMA 1         // head dim 64: LDS-DMA issued as inline assembly (see dma_copy)
 #endif
 #ifndef RLT_ASM_DMA_HD16
 #define RLT_ASM_DMA_HD16 0    // also at head dims 16 / 32
 #endif
-#ifndef RLT_ASM_DMA_FWD
-#define RLT_ASM_DMA_FWD 1     // the same for the forward kernel
-#endif
-#ifndef RLT_ASM_DMA_DQ
-#define RLT_ASM_DMA_DQ 1      // ... and the dQ kernel
+#ifndef RLT_SPREAD_HD16
+#define RLT_SPREAD_HD16 0     // head dims 16 / 32 (needs RLT_ASM_DMA_HD16): dQ and dK+dV kernels spread the pieces over the tile body
 #endif
 #ifndef RLT_STEPPED_SPREAD
 #define RLT_STEPPED_SPREAD 1  // stepped tile body: LDS-DMA pieces of the next tile spread over the matrix steps
@@ -277,6 +274,9 @@ constexpr int QT3 = 256;                  // rows owned by a workgroup of the sp
 // body, i.e. wait there for the NEXT tile's copy.  The copy of tile t+1 goes to the other stage, so the only ordering
 // needed is dma_wait_barrier<true>() before that stage is read.  Measured at head dim 64 (r02_notes.md): dK+dV kernel -2 %,
 // forward kernel -1.5 %, dQ kernel -1 % (with frags_ready() below; without it the forward kernel got 5 % slower).
+template <int HD> constexpr bool asm_dma() { return RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16 != 0); }
+template <int HD> constexpr bool spread_dma() { return asm_dma<HD>() && (HD == 64 || RLT_SPREAD_HD16 != 0); }
+
 template <int NBYTES, bool ASM = false>
 __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane) {
     static_assert(NBYTES % 1024 == 0, "LDS-DMA pieces are 1 KiB per wavefront instruction");
@@ -452,17 +452,17 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     auto issue = [&](int t, int buf) {
-        dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::TP, (RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
+        dma_copy<Rec<HD>::RP, asm_dma<HD>()>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::TP, asm_dma<HD>()>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    dma_wait_barrier<(RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+    dma_wait_barrier<asm_dma<HD>()>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         // head dim 64: the 4-5 LDS-DMA pieces of a wavefront are spread over the tile body instead of all 8 wavefronts
         // issuing everything before their first MFMA (see the dK+dV kernel); a wavefront without queries issues at the top
-        constexpr bool SPREAD = RLT_FWD_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_FWD != 0;
+        constexpr bool SPREAD = RLT_FWD_SPREAD != 0 && HD == 64 && asm_dma<HD>();
         const bool more = t + 1 < nt;
         if (!SPREAD || !wave_live) { if (more) issue(t + 1, buf ^ 1); }
         else if (DROP && more && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_ker
             }
             if (!LROW && !LMFMA) l_run += psum;
         }
-        dma_wait_barrier<(RLT_ASM_DMA_FWD != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+        dma_wait_barrier<asm_dma<HD>()>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -636,14 +636,14 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-key hashes of the tile
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     // head dim 64: the 7-8 LDS-DMA pieces of a wavefront spread over the tile body (see the dK+dV kernel)
-    constexpr bool SPREAD = RLT_DQ_SPREAD != 0 && HD == 64 && RLT_ASM_DMA_DQ != 0;
+    constexpr bool SPREAD = RLT_DQ_SPREAD != 0 && spread_dma<HD>();
     auto issue = [&](int t, int buf) {
-        dma_copy<KREC, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::RP, (RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
+        dma_copy<KREC, asm_dma<HD>()>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
+        dma_copy<Rec<HD>::RP, asm_dma<HD>()>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+    dma_wait_barrier<asm_dma<HD>()>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
             }
         }
-        dma_wait_barrier<(RLT_ASM_DMA_DQ != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+        dma_wait_barrier<asm_dma<HD>()>();
     }
     if (!wave_live) return;
     if (S16) {
@@ -757,24 +757,21 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
     uint32_t* htab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);          // dropout: per-query hashes of the tile
     const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 1u;
     auto issue = [&](int t, int buf) {
-        dma_copy<QREC, (RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
-        dma_copy<STAGE - QREC, (RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
+        dma_copy<QREC, asm_dma<HD>()>(lds + buf * STAGE, record<HD>(g.img, 0, npair, nt, pair, t), wv, lane);
+        dma_copy<STAGE - QREC, asm_dma<HD>()>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
-    dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+    dma_wait_barrier<asm_dma<HD>()>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         RLT_STAMP(0);
-#if RLT_STEPPED && RLT_STEPPED_SPREAD
-        // stepped head-dim-64 body: the copy of tile t+1 is spread over the matrix steps (below); all 8 wavefronts issuing their
-        // ~10 pieces at the top of the tile cost every one of them ~1,500 cycles before the first MFMA (timeline stamps)
-        // (a wavefront without keys runs no matrix steps and issues its pieces here)
-        if (HD != 64 || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
+        // The copy of tile t+1 is spread over the tile body (below): all 8 wavefronts issuing their ~10 pieces at the top of the
+        // tile cost every one of them ~1,500 cycles before the first MFMA (timeline stamps).  A wavefront without keys runs no
+        // matrix steps and issues its pieces here.
+        constexpr bool SPREAD = RLT_STEPPED_SPREAD != 0 && spread_dma<HD>() && (HD != 64 || RLT_STEPPED != 0);
+        if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
-#else
-        if (t + 1 < nt) issue(t + 1, buf ^ 1);
-#endif
         if (wave_live) {
             const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
             const uint16_t* qr_lo = qr_hi + rows_elems<HD>();
@@ -786,6 +783,17 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const uint16_t* dt_lo = dt_hi + T_elems<HD>();
             const float* Ls = reinterpret_cast<const float*>(lds + buf * STAGE + 2 * QREC);
             const float* Es = Ls + KT;
+            const bool more = SPREAD && t + 1 < nt;
+            // piece pc (0..9) of this wavefront's share of the copy of tile t+1: 5 pieces of the Q record, 5 of the dO
+            // record; the record addresses are computed once per tile (address arithmetic inside the bursts cost 15 %)
+            const uint8_t* nq = record<HD>(g.img, 0, npair, nt, pair, min(t + 1, nt - 1));
+            const uint8_t* nd = record<HD>(g.dimg, 0, npair, nt, pair, min(t + 1, nt - 1));
+            uint8_t* nl = lds + (buf ^ 1) * STAGE;
+            auto next_piece = [&](int pc) {
+                if (!more) return;
+                if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
+                else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
+            };
 #if RLT_STEPPED
             if constexpr (HD == 64) {
                 // The 32 matrix steps of a tile (3 MFMAs each) as an explicit software pipeline over the two 32-query
@@ -847,22 +855,10 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #pragma unroll
                 for (int i = 0; i < RLT_STEPPED; ++i) frag(i);
                 seed(0);
-                const bool more = t + 1 < nt;
-                // piece pc (0..9) of this wavefront's share of the copy of tile t+1: 5 pieces of the Q record, 5 of the dO
-                // record; the record addresses are computed once per tile (address arithmetic inside the bursts cost 15 %)
-                const uint8_t* nq = record<HD>(g.img, 0, npair, nt, pair, min(t + 1, nt - 1));
-                const uint8_t* nd = record<HD>(g.dimg, 0, npair, nt, pair, min(t + 1, nt - 1));
-                uint8_t* nl = lds + (buf ^ 1) * STAGE;
-                auto next_piece = [&](int pc) {
-                    if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
-                    else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
-                };
                 auto mm = [&](int st) {                      // the fragment reads of step st + RLT_STEPPED and the 3 MFMAs of step st
                     const int sub = (st >> 3) & 1, prod = (st >> 4) * 2 + ((st >> 2) & 1), k = st & 3;
-#if RLT_STEPPED_SPREAD
-                    if (RLT_SPREAD_EVERY > 0 && st % (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) == 0 && st / (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) < 10 && more)
+                    if (RLT_SPREAD_EVERY > 0 && st % (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) == 0 && st / (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1) < 10)
                         next_piece(st / (RLT_SPREAD_EVERY > 0 ? RLT_SPREAD_EVERY : 1));
-#endif
                     if (st + RLT_STEPPED < 32) frag(st + RLT_STEPPED);
                     if (prod == 0) sc2[sub] = mfma3(fh[st], fl[st], kh[k], kl[k], sc2[sub]);           // S[q][key] - lse
                     else if (prod == 1) dp2[sub] = mfma3(fh[st], fl[st], vh[k], vl[k], dp2[sub]);      // dP[q][key] (- delta)
@@ -881,7 +877,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #pragma unroll
                     for (int st = 4 * g; st < 4 * g + 4; ++st) { mm(st); fence(); }
                     __builtin_amdgcn_s_setprio(0);
-                    if (RLT_SPREAD_EVERY == 0 && more) {      // pieces behind the bursts, at priority 0
+                    if (RLT_SPREAD_EVERY == 0) {              // pieces behind the bursts, at priority 0
                         next_piece(g);
                         if (g < 2) next_piece(8 + g);
                         fence();
@@ -922,8 +918,11 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     sc[r] = Ls[ql];
                     dp[r] = DROP ? 0.f : Es[ql];
                 }
+                next_piece(5 * sub);
                 sc = mma_rows<HD>(qr_hi, qr_lo, sub, l31, hh, kh, kl, sc);       // S[q][key] - lse (Q carries scale*log2e)
+                next_piece(5 * sub + 1);
                 dp = mma_rows<HD>(dr_hi, dr_lo, sub, l31, hh, vh, vl, dp);       // dP[q][key] (- delta)
+                next_piece(5 * sub + 2);
                 // queries beyond B need no mask: their columns of the transposed Q / dO images are zero, p is finite
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -940,11 +939,14 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     }
                     sc[r] = p;
                 }
+                next_piece(5 * sub + 3);
                 if (HD == 16 && RLT_HD16_SMALL_MFMA) {
                     mma_T16(dt_hi, dt_lo, sub, lane, sc, dv16);                    // dV^T[d][key] += dO^T P
+                    next_piece(5 * sub + 4);
                     mma_T16(qt_hi, qt_lo, sub, lane, dp, dk16);                    // dK^T[d][key] += (c Q)^T dS
                 } else {
                     mma_T<HD>(dt_hi, dt_lo, sub, l31, hh, sc, dv);                 // dV^T[d][key] += dO^T P
+                    next_piece(5 * sub + 4);
                     mma_T<HD>(qt_hi, qt_lo, sub, l31, hh, dp, dk);                 // dK^T[d][key] += (c Q)^T dS
                 }
             }
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
 #endif
         }
         RLT_STAMP(1);
-        dma_wait_barrier<(RLT_ASM_DMA != 0 && (HD == 64 || RLT_ASM_DMA_HD16))>();
+        dma_wait_barrier<asm_dma<HD>()>();
     }
     if (!wave_live) return;
     if (HD == 16 && RLT_HD16_SMALL_MFMA) {          // D[row = d = 4 (lane >> 4) + r][col = lane & 15]: one float4 per lane and 16-key half
