@@ -721,7 +721,22 @@ __device__ __forceinline__ void store3b(uint16_t* __restrict__ Thi, uint16_t* __
     for (int part = 0; part < 4; ++part) store3b_part<KC>(Thi, Tlo, tid, st, part);
 }
 
-template <bool TA, bool TB>
+#if defined(RLT_STAMPS)
+// timeline instrumentation (variant builds only): s_memtime at four points of one workgroup of gemm3b_kernel, per wavefront
+__device__ unsigned long long rlt_gemm_stamp_buf[8 * 4];
+#define RLT_GSTAMP(slot) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) \
+    rlt_gemm_stamp_buf[(threadIdx.x >> 6) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RLT_GSTAMP(slot) do {} while (0)
+#endif
+
+// PERSIST (no split-K, A stored [M][K], at least two K tiles, more tiles than workgroups): gridDim.x workgroups walk the
+// tiles id, id + gridDim.x, ... as ONE stream of K tiles - the operand tiles of the next output tile are fetched and
+// stashed during the last K tiles of the current one, and its epilogue stores go out while those loads are in flight.
+// One workgroup per output tile paid the pipeline start-up (two exposed HBM latencies, ~6,000 cycles) and ran its first
+// K tiles against cold loads for every tile: at K = 256 (8 K tiles) that was 57,000 cycles per tile for 24,600 of
+// MFMA work (timeline stamps, profiles/r02_notes.md).
+template <bool TA, bool TB, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
     int bid, zslab;
     decode_block(g, bid, zslab);                     // g.tiles_* count 256-wide tiles here
     const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
-    const int m0 = tm * BM2, n0 = tn * BN2;
+    int m0 = tm * BM2, n0 = tn * BN2;
     const int kbeg = zslab * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
@@ -771,6 +786,20 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
     // whole multiply, the two wavefronts of a SIMD (same workgroup, in lock-step between the barriers) both sit in their
     // MFMA phase, then both in their VALU phase, and the two pipes take turns.  The global loads of tile t+2 follow the
     // last use of each staging register (A after step 5, B after step 7): a full iteration of latency cover.
+    // tile of the stream after the current one (PERSIST)
+    int vid = blockIdx.x, nm0 = m0, nn0 = n0;
+    bool has_next = false;
+    auto decode_next = [&]() {
+        const int nwg = g.tiles_m * g.tiles_n;
+        vid += gridDim.x;
+        has_next = PERSIST && vid < nwg;
+        if (has_next) {
+            const int q = nwg >> 3, r = nwg & 7, xcd = vid & 7, jj = vid >> 3;          // decode_block's XCD-aware remap
+            const int nb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jj;
+            const int ntm = nb / g.tiles_n;
+            nm0 = ntm * BM2; nn0 = (nb - ntm * g.tiles_n) * BN2;
+        }
+    };
     auto multiply = [&](int buf, int t, int nt_) {
         const uint16_t* pa = lds + buf * 4 * PL2 + (wm * 64 + pl) * 32;
         const uint16_t* pb = lds + buf * 4 * PL2 + 2 * PL2 + (wn * 128 + pl) * 32;
@@ -779,8 +808,11 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
         // consumes): with the loads behind a branch hipcc merges the outstanding-load counts of both paths and waits
         // for the loads it has just issued (vmcnt(3..0) at every staging step instead of vmcnt(7..4)), which exposed
         // one full memory latency per 32-wide K step
-        const bool do_stash = t + 1 < nt_;
-        const int kf = kbeg + min(t + 2, nt_ - 1) * BK3;
+        const bool do_stash = t + 1 < nt_ || has_next;
+        // K tile t+2 of the stream: of this output tile, or K tile t+2-nt of the next one
+        const bool wrap = PERSIST && has_next && t + 2 >= nt_;
+        const int kf = kbeg + (wrap ? t + 2 - nt_ : min(t + 2, nt_ - 1)) * BK3;
+        const int fm0 = wrap ? nm0 : m0, fn0 = wrap ? nn0 : n0;
         bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
         auto load_a = [&](int ks, int slot) {
             const int co = 8 * ((2 * ks + hh) ^ sw);
@@ -821,21 +853,38 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
                     store3b_part<TB>(nb + 2 * PL2, nb + 3 * PL2, tid, sb, 2 * (step - 6) + 1);
                 }
             }
-            if (step == 5) load3b<!TA>(g.A, g.lda, m0, kf, tid, sa);
-            if (step == 7) load3b<TB>(g.B, g.ldb, n0, kf, tid, sb);
+            if (step == 5) load3b<!TA>(g.A, g.lda, fm0, kf, tid, sa);
+            if (step == 7) load3b<TB>(g.B, g.ldb, fn0, kf, tid, sb);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     const int nt = (kend - kbeg) / BK3;
+    RLT_GSTAMP(0);
     fetch(0);
     stash(0);
     fetch(min(1, nt - 1));                             // unconditional, like the fetches in multiply()
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        multiply(t & 1, t, nt);                        // tile t; stashes tile t+1 (in registers), fetches tile t+2
-        __syncthreads();
+    RLT_GSTAMP(1);
+    if (PERSIST) decode_next();
+    int u = 0;                                         // K tiles of the stream so far (LDS buffer parity)
+    while (true) {
+        for (int t = 0; t < nt; ++t, ++u) {
+            multiply(u & 1, t, nt);                    // K tile t; stashes the next K tile of the stream (in registers), fetches the one after
+            __syncthreads();
+        }
+        RLT_GSTAMP(2);
+        write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
+        RLT_GSTAMP(3);
+        if (!PERSIST || !has_next) break;
+        m0 = nm0; n0 = nn0;
+        decode_next();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
     if (want_cs) {                                     // 8 threads (tid = 8*mb + kb) hold partial sums of columns 4*mb..+3
         float4* red = reinterpret_cast<float4*>(gsm);
         red[tid] = csum;
@@ -863,9 +912,19 @@ bool gemm_big_ok(const GemmArgs& g, bool ta, bool tb) {
 template <bool TA, bool TB>
 int launch_gemm3b(GemmArgs g, int ns, hipStream_t st) {
     const size_t shm = (size_t)2 * 4 * PL2 * sizeof(uint16_t);
+    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
+    if constexpr (!TA && TB) {      // NT only: measured -6 % at K = 256, -2 % at K = 2048; the NN form got SLOWER (K = 2048: +20 %)
+        static const int persist_wgs = [] { const char* e = getenv("RLT_GEMM_PERSIST"); return e ? atoi(e) : 256; }();   // 0: off
+        const long long tiles = (long long)g.tiles_m * g.tiles_n;
+        if (persist_wgs > 0 && ns == 1 && g.K / BK3 >= 2 && tiles > persist_wgs && persist_wgs % 8 == 0) {
+            int rc = rlt_allow_lds(gemm3b_kernel<TA, TB, true>, shm);
+            if (rc) return rc;
+            hipLaunchKernelGGL((gemm3b_kernel<TA, TB, true>), dim3(persist_wgs), dim3(512), shm, st, g);
+            return RLT_LAUNCH_RESULT();
+        }
+    }
     int rc = rlt_allow_lds(gemm3b_kernel<TA, TB>, shm);
     if (rc) return rc;
-    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
     dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     hipLaunchKernelGGL((gemm3b_kernel<TA, TB>), grid, dim3(512), shm, st, g);
     return RLT_LAUNCH_RESULT();
@@ -989,6 +1048,12 @@ int choose_split(int M, int N, int K) {
     if (want >= 8) want = want / 8 * 8;       // whole groups of 8 slabs: one slab per XCD and round (decode_block)
     return (int)(want < 1 ? 1 : want);
 }
+
+#if defined(RLT_STAMPS)
+extern "C" int rlt_debug_gemm_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rlt_gemm_stamp_buf), n * sizeof(unsigned long long));
+}
+#endif
 
 // ---- column sums (bias gradients) ------------------------------------------------------------------
 constexpr int CS_ROWS_PER_WG = 512;

@@ -201,6 +201,27 @@ def stamps():
         print(f"  w{w}: " + "  ".join(row))
 
 
+def gemm_stamps(T=4096 * 300):
+    """Timeline of one gemm3b workgroup (library built with -DRLT_STAMPS): prologue / K loop / epilogue cycles per wavefront."""
+    import ctypes
+    fn = N.load().rlt_debug_gemm_stamps
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    for name, ta, tb, M, Nn, K in [("ffn1 fwd NT", 0, 1, T, 2048, 256), ("ffn2 fwd NT", 0, 1, T, 256, 2048), ("ffn2 dX NN", 0, 0, T, 2048, 256)]:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((Nn, K) if tb else (K, Nn), device=dev)
+        C = torch.empty(M, Nn, device=dev)
+        ms = timeit(lambda: ops.gemm(ta, tb, M, Nn, K, A, A.shape[1], Bm, Bm.shape[1], C, Nn))
+        buf = (ctypes.c_ulonglong * 32)()
+        assert fn(buf, 32) == 0
+        v = list(buf)
+        print(f"gemm {name} {M}x{Nn}x{K}: {ms:.3f} ms; per wavefront (prologue, K loop, epilogue) cycles:")
+        for w in range(8):
+            s0, s1, s2, s3 = v[4 * w:4 * w + 4]
+            print(f"   w{w}: {s1 - s0:6d} {s2 - s1:7d} {s3 - s2:6d}")
+        del A, Bm, C
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attention", "gemms", "lstm"]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
