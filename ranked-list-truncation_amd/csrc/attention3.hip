@@ -28,6 +28,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_SPREAD_HD16
 #define RLT_SPREAD_HD16 0     // head dims 16 / 32 (needs RLT_ASM_DMA_HD16): dQ and dK+dV kernels spread the pieces over the tile body
 #endif
+#ifndef RLT_DKV_TRREAD
+#define RLT_DKV_TRREAD 1      // stepped dK+dV body: transposed operands by ds_read_b64_tr_b16 from the rows images (no transposed images copied)
+#endif
 #ifndef RLT_STEPPED_SPREAD
 #define RLT_STEPPED_SPREAD 1  // stepped tile body: LDS-DMA pieces of the next tile spread over the matrix steps
 #endif
@@ -38,7 +41,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RLT_DQ_SPREAD 1       // dQ kernel likewise (measured -2 %)
 #endif
 #ifndef RLT_SPREAD_EVERY
-#define RLT_SPREAD_EVERY 3    // one piece every so many matrix steps (10 pieces per wavefront and tile, 32 steps)
+#define RLT_SPREAD_EVERY 4    // one piece every so many matrix steps (7 pieces per wavefront and tile with RLT_DKV_TRREAD, 32 steps)
 #endif
 #ifndef RLT_STEPPED_PRIO
 #define RLT_STEPPED_PRIO 1    // wave priority of the MFMA bursts of the stepped tile body (0: no priority flips)
@@ -71,6 +74,17 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
     lo.y = pk2(c - __builtin_bit_cast(float, hi.y << 16), d - __builtin_bit_cast(float, hi.y & 0xffff0000u));
 }
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major (lane i of the
+// group gets column i of the 4 rows); every lane's address 8-byte aligned, EXEC all ones (cdna_hip_programming.md T10)
+typedef short v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4s tr_read(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 cat_frag(v4s a, v4s b) {
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 // 8 fp32 -> hi / lo bf16x8 fragments
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -789,9 +803,16 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const uint8_t* nq = record<HD>(g.img, 0, npair, nt, pair, min(t + 1, nt - 1));
             const uint8_t* nd = record<HD>(g.dimg, 0, npair, nt, pair, min(t + 1, nt - 1));
             uint8_t* nl = lds + (buf ^ 1) * STAGE;
+            // TRREAD (stepped head-dim-64 body): the dV / dK products take their A operands from the ROWS images with
+            // ds_read_b64_tr_b16, so the transposed images are not copied at all: 37 pieces per tile instead of 73
+            constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64;
             auto next_piece = [&](int pc) {
                 if (!more) return;
-                if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
+                if (TRREAD) {         // 0..2: Q rows image, 3..5: dO rows image, 6: the aux block (-lse, -delta) behind the dO images
+                    if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nq, wv, lane, pc);
+                    else if (pc < 6) dma_piece<Rec<HD>::RP>(nl + QREC, nd, wv, lane, pc - 3);
+                    else if (pc == 6) dma_piece<Rec<HD>::AUX>(nl + 2 * QREC, nd + QREC, wv, lane, 0);
+                } else if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
                 else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
             };
 #if RLT_STEPPED
@@ -814,6 +835,20 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                         const int off = (sub * 32 + l31) * (HD + 8) + 8 * hh + 16 * k;
                         fh[st] = *reinterpret_cast<const bf16x8*>(hi + off);
                         fl[st] = *reinterpret_cast<const bf16x8*>(lo + off);
+                    } else if (TRREAD) {
+                        // A[d][k-slot j] = X[query][d] read transposed from the rows image: k = 2 s + dt; the 16-lane group
+                        // (lane >> 4) covers d = 32 dt + 16 (group & 1) + (lane & 15); its lane 4q + p supplies the address of
+                        // row q, columns 4p..4p+3 of the 4 x 16 block and receives column (lane & 15).  The k slots of lane half
+                        // hh are queries 16 s + 4 hh + {0..3} (first read) and + 8 (second read): the rows the B operand
+                        // (registers 8s..8s+7 of the score block) holds.
+                        const uint16_t* hi = prod == 2 ? dr_hi : qr_hi;
+                        const uint16_t* lo = prod == 2 ? dr_lo : qr_lo;
+                        const int qrow = sub * 32 + 16 * (k >> 1) + 4 * hh + ((lane & 15) >> 2);
+                        const int off = qrow * (HD + 8) + 32 * (k & 1) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                        const v4s h0 = tr_read(hi + off), h1 = tr_read(hi + off + 8 * (HD + 8));
+                        const v4s l0 = tr_read(lo + off), l1 = tr_read(lo + off + 8 * (HD + 8));
+                        fh[st] = cat_frag(h0, h1);
+                        fl[st] = cat_frag(l0, l1);
                     } else {
                         const uint16_t* hi = prod == 2 ? dt_hi : qt_hi;
                         const uint16_t* lo = prod == 2 ? dt_lo : qt_lo;
