@@ -138,6 +138,11 @@ def lstm(B=4096, S=300):
     print(f"bilstm_bwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
 
 
+def lstm_small():
+    for B in (32, 64, 256):
+        lstm(B=B)
+
+
 def overlap(B=4096, S=300):
     """Does a latency/HBM-bound persistent kernel (BiLSTM backward recurrence, 256 workgroups) share the chip with an
     MFMA-bound weight-gradient product (TN, M=2048 N=256 K=T, 256 workgroups) issued on a second stream?"""
