@@ -417,7 +417,7 @@ __device__ __forceinline__ const uint8_t* record(const uint8_t* img, int m, int 
 
 // ------------------------------------------------------------------------------------------ forward
 template <int HD, bool DROP>
-__global__ __launch_bounds__(512, (DROP && HD == 64 ? 4 : 2)) void attn3_fwd_kernel(Attn3Args g) {
+__global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
     constexpr int STAGE = Rec<HD>::RP + Rec<HD>::TP;                        // K rows pair | V transposed pair
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         // The copy of tile t+1 is spread over the tile body (below): all 8 wavefronts issuing their ~10 pieces at the top of the
         // tile cost every one of them ~1,500 cycles before the first MFMA (timeline stamps).  A wavefront without keys runs no
         // matrix steps and issues its pieces here.
-        constexpr bool SPREAD = RLT_STEPPED_SPREAD != 0 && spread_dma<HD>() && (HD != 64 || RLT_STEPPED != 0);
+        constexpr bool SPREAD = RLT_STEPPED_SPREAD != 0 && spread_dma<HD>() && (HD != 64 || (RLT_STEPPED != 0 && !DROP));
         if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
         if (wave_live) {
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             uint8_t* nl = lds + (buf ^ 1) * STAGE;
             // TRREAD (stepped head-dim-64 body): the dV / dK products take their A operands from the ROWS images with
             // ds_read_b64_tr_b16, so the transposed images are not copied at all: 37 pieces per tile instead of 73
-            constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64;
+            constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64 && !DROP;
             auto next_piece = [&](int pc) {
                 if (!more) return;
                 if (TRREAD) {         // 0..2: Q rows image, 3..5: dO rows image, 6: the aux block (-lse, -delta) behind the dO images
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                 else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
             };
 #if RLT_STEPPED
-            if constexpr (HD == 64) {
+            if constexpr (HD == 64 && !DROP) {     // (with dropout the stepped body is 18 % slower than the compiler-scheduled one: 6.55 vs 5.57 ms)
                 // The 32 matrix steps of a tile (3 MFMAs each) as an explicit software pipeline over the two 32-query
                 // sub-tiles a, b:   [S_a dP_a] [S_b dP_b | E_a] [dV_a dK_a | E_b] [dV_b dK_b]
                 // E_x = exp, dS and the bf16 splits of sub-tile x, cut into per-step chunks of a few vector instructions that

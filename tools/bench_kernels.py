@@ -31,7 +31,7 @@ def timeit(fn, reps=3, warm=1):
     return a.elapsed_time(b) / reps
 
 
-def attention(B=4096, S=60, H=4, HD=64):
+def attention(B=4096, S=60, H=4, HD=64, drop=0.0):
     E = H * HD
     T = S * B
     qkv = torch.randn(T, 3 * E, device=dev)
@@ -45,14 +45,22 @@ def attention(B=4096, S=60, H=4, HD=64):
     images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
     wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD)
     ws = torch.empty(wb // 4 + 4, device=dev)
-    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 0, ptr(out), ptr(lse), ptr(images), ib, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop, 7, ptr(out), ptr(lse), ptr(images), ib, stream()))
     print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * unit / ms:7.1f} TF/s", flush=True)
     ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, stream()))
     print(f"attn_bwd_prep B{B} S{S} HD{HD}: {ms:8.3f} ms", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), stream()))
     print(f"attn_bwd_dkv  B{B} S{S} HD{HD}: {ms:8.3f} ms  {8 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 0, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), stream()))
     print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
+
+
+def attention_drop():
+    """AttnCut's conf dropout (0.4) and Choopy's (0.2)."""
+    print("dropout 0.4:", flush=True)
+    attention(drop=0.4)
+    print("dropout 0.2, head dim 16:", flush=True)
+    attention(B=8192, S=20, H=8, HD=16, drop=0.2)
 
 
 def attention16():
