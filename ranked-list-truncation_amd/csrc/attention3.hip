@@ -28,6 +28,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_SPREAD_HD16
 #define RLT_SPREAD_HD16 0     // head dims 16 / 32 (needs RLT_ASM_DMA_HD16): dQ and dK+dV kernels spread the pieces over the tile body
 #endif
+#ifndef RLT_DQ_STEPPED
+#define RLT_DQ_STEPPED 1      // dQ kernel, head dim 64, no dropout: stepped tile body
+#endif
+#ifndef RLT_DQ_TRREAD
+#define RLT_DQ_TRREAD 1       // ... with K^T read transposed from the K rows image (K^T image not copied)
+#endif
+#ifndef RLT_DQ_SPREAD_EVERY
+#define RLT_DQ_SPREAD_EVERY 3 // ... one LDS-DMA piece every so many of its 24 matrix steps
+#endif
 #ifndef RLT_DKV_TRREAD
 #define RLT_DKV_TRREAD 1      // stepped dK+dV body: transposed operands by ds_read_b64_tr_b16 from the rows images (no transposed images copied)
 #endif
@@ -673,11 +682,102 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
             const uint8_t* nk = record<HD>(g.img, 1, npair, nt, pair, min(t + 1, nt - 1));
             const uint8_t* nv = record<HD>(g.img, 2, npair, nt, pair, min(t + 1, nt - 1));
             uint8_t* nl = lds + ((t & 1) ^ 1) * STAGE;
+            // stepped body (head dim 64, no dropout; see the dK+dV kernel): K^T by ds_read_b64_tr_b16 from the K rows image
+            constexpr bool STEPPED = RLT_DQ_STEPPED != 0 && HD == 64 && !DROP && SPREAD;
+            constexpr bool TRREAD = STEPPED && RLT_DQ_TRREAD != 0;
             auto piece = [&](int pc) {                // 0..4: K record (rows + transposed), 5..7: V rows image
                 if (!SPREAD || !more) return;
-                if (pc < 5) dma_piece<KREC>(nl, nk, wv, lane, pc);
+                if (TRREAD) {                         // 0..2: K rows image, 3..5: V rows image
+                    if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nk, wv, lane, pc);
+                    else if (pc < 6) dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 3);
+                } else if (pc < 5) dma_piece<KREC>(nl, nk, wv, lane, pc);
                 else dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 5);
             };
+            if constexpr (STEPPED) {
+                // 24 matrix steps per tile over the two 32-key sub-tiles a, b:  [S_a dP_a] [S_b dP_b | E_a] [dQ_a | E_b] [dQ_b]
+                bf16x8 fh[24], fl[24];
+                f32x16 sc2[2], dp2[2];
+                bf16x8 gh[2][2], gl[2][2];            // split dS^T: [sub-tile][rows 8s..8s+7 of the block]
+                const bool last = t == nt - 1;
+                auto frag = [&](int st) {
+                    const int k = st & 3;
+                    if (st < 16) {
+                        const int sub = st >> 3;
+                        const uint16_t* hi = (st & 4) ? vr_hi : kr_hi;
+                        const uint16_t* lo = (st & 4) ? vr_lo : kr_lo;
+                        const int off = (sub * 32 + l31) * (HD + 8) + 8 * hh + 16 * k;
+                        fh[st] = *reinterpret_cast<const bf16x8*>(hi + off);
+                        fl[st] = *reinterpret_cast<const bf16x8*>(lo + off);
+                    } else if (TRREAD) {              // A[d][k slot] = K[key][d], k = 2 s + dt (mapping as in the dK+dV kernel)
+                        const int sub = (st - 16) >> 2;
+                        const int krow = sub * 32 + 16 * (k >> 1) + 4 * hh + ((lane & 15) >> 2);
+                        const int off = krow * (HD + 8) + 32 * (k & 1) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                        const v4s h0 = tr_read(kr_hi + off), h1 = tr_read(kr_hi + off + 8 * (HD + 8));
+                        const v4s l0 = tr_read(kr_lo + off), l1 = tr_read(kr_lo + off + 8 * (HD + 8));
+                        fh[st] = cat_frag(h0, h1);
+                        fl[st] = cat_frag(l0, l1);
+                    } else {
+                        const int sub = (st - 16) >> 2;
+                        const int off = ((k & 1) * 32 + l31) * LDT3 + sub * 32 + 16 * (k >> 1) + 8 * hh;
+                        fh[st] = as_frag(*reinterpret_cast<const uint4*>(kt_hi + off));
+                        fl[st] = as_frag(*reinterpret_cast<const uint4*>(kt_lo + off));
+                    }
+                };
+                auto mm = [&](int st) {
+                    const int k = st & 3;
+                    if (st % RLT_DQ_SPREAD_EVERY == 0) piece(st / RLT_DQ_SPREAD_EVERY);
+                    if (st + 2 < 24) frag(st + 2);
+                    if (st < 16) {
+                        const int sub = st >> 3;
+                        if (st & 4) dp2[sub] = mfma3(fh[st], fl[st], doh[k], dol[k], k == 0 ? c_del : dp2[sub]);    // dP^T[key][q] - delta
+                        else sc2[sub] = mfma3(fh[st], fl[st], qh[k], ql[k], k == 0 ? c_lse : sc2[sub]);             // S^T[key][q] - lse
+                    } else {
+                        const int sub = (st - 16) >> 2;
+                        dq[k & 1] = mfma3(fh[st], fl[st], gh[sub][k >> 1], gl[sub][k >> 1], dq[k & 1]);             // dQ^T[d][q] += K^T dS^T
+                    }
+                };
+                auto ew = [&](int sub, int c) {       // registers 2c, 2c+1 of the score block: dS^T = P (dP - delta)
+#pragma unroll
+                    for (int r = 2 * c; r < 2 * c + 2; ++r) {
+                        const bool oob = last && t * KT + sub * 32 + acc_row(r, hh) >= B;      // only the last tile can hold keys beyond B
+                        const float pr = oob ? 0.f : rlt_exp2(sc2[sub][r]);
+                        dp2[sub][r] = pr * dp2[sub][r];
+                    }
+                };
+                auto split_half = [&](int sub, int s8) {
+                    const f32x16& w = dp2[sub];
+                    const float x[8] = {w[8 * s8 + 0], w[8 * s8 + 1], w[8 * s8 + 2], w[8 * s8 + 3],
+                                        w[8 * s8 + 4], w[8 * s8 + 5], w[8 * s8 + 6], w[8 * s8 + 7]};
+                    split8(x, gh[sub][s8], gl[sub][s8]);
+                };
+                auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+                auto burst = [&](int b4) {
+                    __builtin_amdgcn_s_setprio(RLT_STEPPED_PRIO);
+#pragma unroll
+                    for (int st = 4 * b4; st < 4 * b4 + 4; ++st) { mm(st); fence(); }
+                    __builtin_amdgcn_s_setprio(0);
+                };
+                frag(0); frag(1);
+                burst(0);                             // S_a
+                burst(1);                             // dP_a
+                burst(2);                             // S_b
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ew(0, c);
+                split_half(0, 0);
+                fence();
+                burst(3);                             // dP_b
+#pragma unroll
+                for (int c = 4; c < 8; ++c) ew(0, c);
+                split_half(0, 1);
+                fence();
+                burst(4);                             // dQ_a
+#pragma unroll
+                for (int c = 0; c < 8; ++c) ew(1, c);
+                split_half(1, 0);
+                split_half(1, 1);
+                fence();
+                burst(5);                             // dQ_b
+            } else {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 piece(4 * sub);
@@ -707,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 piece(4 * sub + 3);
                 if (S16) mma_T16(kt_hi, kt_lo, sub, lane, dp, dq16);               // dQ^T[d][q] += K^T dS^T
                 else mma_T<HD>(kt_hi, kt_lo, sub, l31, hh, dp, dq);
+            }
             }
         }
         dma_wait_barrier<asm_dma<HD>()>();
