@@ -52,9 +52,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_SPREAD_EVERY
 #define RLT_SPREAD_EVERY 4    // one piece every so many matrix steps (7 pieces per wavefront and tile with RLT_DKV_TRREAD, 32 steps)
 #endif
-#ifndef RLT_STEPPED_PRIO
-#define RLT_STEPPED_PRIO 1    // wave priority of the MFMA bursts of the stepped tile body (0: no priority flips)
-#endif
 #ifndef RLT_STEPPED
 #define RLT_STEPPED 2         // dK+dV, head dim 64: stepped tile body with this fragment prefetch distance (matrix steps); 0 = compiler-scheduled body
 #endif
@@ -328,6 +325,16 @@ __device__ __forceinline__ void dma_piece(uint8_t* lds_dst, const uint8_t* __res
         const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
     }
+}
+
+// branch-free form: the chunk index is clamped (a wavefront beyond the end re-copies the last chunk: the same bytes to the
+// same place), so that a tile body that issues pieces stays ONE basic block (sched_group_barrier patterns need that)
+template <int NBYTES>
+__device__ __forceinline__ void dma_piece_clamped(uint8_t* lds_dst, const uint8_t* __restrict__ gsrc, int wv, int lane, int c) {
+    const int chunk = min(wv + 8 * c, NBYTES / 1024 - 1);
+    const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
+    const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
 }
 
 // Register fragments fetched from HBM before the tile loop must have ARRIVED before the loop: an empty asm statement
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 };
                 auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
                 auto burst = [&](int b4) {
-                    __builtin_amdgcn_s_setprio(RLT_STEPPED_PRIO);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int st = 4 * b4; st < 4 * b4 + 4; ++st) { mm(st); fence(); }
                     __builtin_amdgcn_s_setprio(0);
@@ -908,8 +915,12 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             // ds_read_b64_tr_b16, so the transposed images are not copied at all: 37 pieces per tile instead of 73
             constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64 && !DROP;
             auto next_piece = [&](int pc) {
-                if (!more) return;
-                if (TRREAD) {         // 0..2: Q rows image, 3..5: dO rows image, 6: the aux block (-lse, -delta) behind the dO images
+                if (!more && !(TRREAD && true)) return;
+                if (TRREAD && true) {   // the same, branch-free (the last tile re-copies itself into the idle stage)
+                    if (pc < 3) dma_piece_clamped<Rec<HD>::RP>(nl, nq, wv, lane, pc);
+                    else if (pc < 6) dma_piece_clamped<Rec<HD>::RP>(nl + QREC, nd, wv, lane, pc - 3);
+                    else if (pc == 6) dma_piece_clamped<Rec<HD>::AUX>(nl + 2 * QREC, nd + QREC, wv, lane, 0);
+                } else if (TRREAD) {  // 0..2: Q rows image, 3..5: dO rows image, 6: the aux block (-lse, -delta) behind the dO images
                     if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nq, wv, lane, pc);
                     else if (pc < 6) dma_piece<Rec<HD>::RP>(nl + QREC, nd, wv, lane, pc - 3);
                     else if (pc == 6) dma_piece<Rec<HD>::AUX>(nl + 2 * QREC, nd + QREC, wv, lane, 0);
@@ -966,28 +977,6 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                         dp2[sub][r] = DROP ? 0.f : Es[ql];
                     }
                 };
-                auto ew = [&](int sub, int c) {              // chunk c of E_sub: registers 2c, 2c+1 of the score block
-#pragma unroll
-                    for (int r = 2 * c; r < 2 * c + 2; ++r) {
-                        const int ql = sub * 32 + acc_row(r, hh);
-                        float pr = rlt_exp2(sc2[sub][r]);
-                        float dpr = dp2[sub][r];
-                        if (DROP) {
-                            const bool keep = rlt_keep_rc(htab[buf * KT + ql], hk, a.drop_thr);
-                            dpr = keep ? dpr * inv_keep : 0.f;
-                            dp2[sub][r] = pr * (dpr + Es[ql]);
-                            pr = keep ? pr * inv_keep : 0.f;
-                        } else {
-                            dp2[sub][r] = pr * dpr;
-                        }
-                        sc2[sub][r] = pr;
-                    }
-                };
-                auto split_half = [&](const f32x16& w, int s8, bf16x8& hi, bf16x8& lo) {
-                    const float x[8] = {w[8 * s8 + 0], w[8 * s8 + 1], w[8 * s8 + 2], w[8 * s8 + 3],
-                                        w[8 * s8 + 4], w[8 * s8 + 5], w[8 * s8 + 6], w[8 * s8 + 7]};
-                    split8(x, hi, lo);
-                };
 #pragma unroll
                 for (int i = 0; i < RLT_STEPPED; ++i) frag(i);
                 seed(0);
@@ -1001,45 +990,72 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
                     else if (prod == 2) dv[k & 1] = mfma3(fh[st], fl[st], ph[sub][k >> 1], pl[sub][k >> 1], dv[k & 1]);   // dV^T += dO^T P
                     else dk[k & 1] = mfma3(fh[st], fl[st], gh[sub][k >> 1], gl[sub][k >> 1], dk[k & 1]);                 // dK^T += (c Q)^T dS
                 };
-                auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-                // One product (4 steps, 12 MFMAs) is a burst at raised wave priority; the element-wise half-block that follows
-                // it runs at priority 0.  The two wavefronts of a SIMD share its vector issue port, arbitrated by priority, then
-                // age: at equal priority the older wavefront takes every slot it can use (timeline stamps, r02_notes.md:
-                // wavefronts 0-3 finish a tile in 6,400 cycles and wait 3,000 at the barrier, 4-7 need 8,950), and the matrix
-                // pipe idles whenever the older one issues vector work.  With the flips, a wavefront in its MFMA burst wins the
-                // port and its partner's vector work fills the slots between the MFMA issues.
-                auto burst = [&](int g) {
-                    __builtin_amdgcn_s_setprio(RLT_STEPPED_PRIO);
+                // Measured with one working wavefront per SIMD (r02_notes.md): the 262 vector instructions of a tile cost
+                // their full ~1,050 cycles on top of the 3,072 MFMA cycles when they sit in blocks between the products,
+                // ~500 in this form.  Every step carries a fixed unit of the element-wise work whose inputs are ready -
+                // 4 exp, or 4 multiplies, plus half of a split8 (12 instructions) - and a sched_group_barrier pattern puts
+                // a third of it behind each of the step's three MFMAs (~5 vector instructions per MFMA gap).
+                //   exp(S_a) under dP_a (steps 4..7); dS_a = P dP under S_b; exp(S_b) under dP_b; dS_b under dV_a;
+                //   the splits of P_a, dS_a, P_b, dS_b follow their inputs by two steps; all done by step 21.
+                uint2 qh_[2][2][2][2], ql_[2][2][2][2];      // [matrix P/dS][sub-tile][half][quarter] -> hi / lo of 4 values
+                auto unit_exp = [&](int sub, int c) {        // registers 4c..4c+3: P = exp2(S - lse)
 #pragma unroll
-                    for (int st = 4 * g; st < 4 * g + 4; ++st) { mm(st); fence(); }
-                    __builtin_amdgcn_s_setprio(0);
-                    if (RLT_SPREAD_EVERY == 0) {              // pieces behind the bursts, at priority 0
-                        next_piece(g);
-                        if (g < 2) next_piece(8 + g);
-                        fence();
-                    }
+                    for (int r = 4 * c; r < 4 * c + 4; ++r) sc2[sub][r] = rlt_exp2(sc2[sub][r]);
                 };
-                auto ew_half = [&](int sub, int half) {      // registers 8 half .. 8 half + 7 of the block: P, dS and their splits
+                auto unit_mul = [&](int sub, int c) {        // dS = P (dP - delta)
 #pragma unroll
-                    for (int c = 4 * half; c < 4 * half + 4; ++c) ew(sub, c);
-                    split_half(sc2[sub], half, ph[sub][half], pl[sub][half]);
-                    split_half(dp2[sub], half, gh[sub][half], gl[sub][half]);
-                    fence();
+                    for (int r = 4 * c; r < 4 * c + 4; ++r) dp2[sub][r] = sc2[sub][r] * dp2[sub][r];
                 };
-                burst(0);                                    // S_a
-                seed(1);
-                fence();
-                burst(1);                                    // dP_a
-                burst(2);                                    // S_b
-                ew_half(0, 0);
-                burst(3);                                    // dP_b
-                ew_half(0, 1);
-                burst(4);                                    // dV_a
-                ew_half(1, 0);
-                burst(5);                                    // dK_a
-                ew_half(1, 1);
-                burst(6);                                    // dV_b
-                burst(7);                                    // dK_b
+                auto unit_split = [&](int m, int sub, int qd) {   // quarter qd (registers 4qd..4qd+3) of P (m = 0) or dS (m = 1)
+                    const f32x16& w = m ? dp2[sub] : sc2[sub];
+                    split4(w[4 * qd], w[4 * qd + 1], w[4 * qd + 2], w[4 * qd + 3], qh_[m][sub][qd >> 1][qd & 1], ql_[m][sub][qd >> 1][qd & 1]);
+                };
+                auto operand = [&](int m, int sub, int half, bf16x8& hi, bf16x8& lo) {
+                    hi = as_frag(make_uint4(qh_[m][sub][half][0].x, qh_[m][sub][half][0].y, qh_[m][sub][half][1].x, qh_[m][sub][half][1].y));
+                    lo = as_frag(make_uint4(ql_[m][sub][half][0].x, ql_[m][sub][half][0].y, ql_[m][sub][half][1].x, ql_[m][sub][half][1].y));
+                };
+                auto pattern = [] {                          // one step: (MFMA, 5 VALU) x 3, the LDS reads first
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // unit per step (issue cycles: exp unit 32, multiply unit 17, split quarter 52; budget 3 x 24 per step):
+                //   4..7 exp_a | 8..11 mul_a + split P_a | 12..15 split dS_a | 16 exp_b | 17..19 exp_b + mul_b |
+                //   20 mul_b + split P_b | 21..23 split P_b | 24..27 split dS_b
+#pragma unroll
+                for (int st = 0; st < 4; ++st) { mm(st); if (st == 3) seed(1); pattern(); }                           // S_a
+#pragma unroll
+                for (int st = 4; st < 8; ++st) { mm(st); unit_exp(0, st - 4); pattern(); }                            // dP_a
+#pragma unroll
+                for (int st = 8; st < 12; ++st) { mm(st); unit_mul(0, st - 8); unit_split(0, 0, st - 8); pattern(); } // S_b
+#pragma unroll
+                for (int st = 12; st < 16; ++st) { mm(st); unit_split(1, 0, st - 12); pattern(); }                    // dP_b
+                operand(0, 0, 0, ph[0][0], pl[0][0]); operand(0, 0, 1, ph[0][1], pl[0][1]);
+#pragma unroll
+                for (int st = 16; st < 20; ++st) {                                                                    // dV_a
+                    mm(st); unit_exp(1, st - 16);
+                    if (st > 16) unit_mul(1, st - 17);
+                    pattern();
+                }
+                operand(1, 0, 0, gh[0][0], gl[0][0]); operand(1, 0, 1, gh[0][1], gl[0][1]);
+#pragma unroll
+                for (int st = 20; st < 24; ++st) {                                                                    // dK_a
+                    mm(st);
+                    if (st == 20) unit_mul(1, 3);
+                    unit_split(0, 1, st - 20);
+                    pattern();
+                }
+                operand(0, 1, 0, ph[1][0], pl[1][0]); operand(0, 1, 1, ph[1][1], pl[1][1]);
+#pragma unroll
+                for (int st = 24; st < 28; ++st) { mm(st); unit_split(1, 1, st - 24); pattern(); }                    // dV_b
+                operand(1, 1, 0, gh[1][0], gl[1][0]); operand(1, 1, 1, gh[1][1], gl[1][1]);
+#pragma unroll
+                for (int st = 28; st < 32; ++st) { mm(st); pattern(); }                                               // dK_b
             } else {
 #endif
 #pragma unroll
