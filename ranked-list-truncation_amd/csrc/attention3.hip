@@ -53,7 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RLT_SPREAD_EVERY 4    // one piece every so many matrix steps (7 pieces per wavefront and tile with RLT_DKV_TRREAD, 32 steps)
 #endif
 #ifndef RLT_STEPPED
-#define RLT_STEPPED 2         // dK+dV, head dim 64: stepped tile body with this fragment prefetch distance (matrix steps); 0 = compiler-scheduled body
+#define RLT_STEPPED 1         // dK+dV, head dim 64: stepped tile body with this fragment prefetch distance (matrix steps; 1 measured best: 4.63 vs 4.69 ms at 2); 0 = compiler-scheduled body
 #endif
 #ifndef RLT_HD16_SMALL_MFMA
 #define RLT_HD16_SMALL_MFMA 1        // head dim 16: dV / dK products on v_mfma_f32_16x16x32_bf16 (0: the padded 32x32x16 form)
