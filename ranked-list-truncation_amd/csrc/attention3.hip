@@ -693,10 +693,10 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
             constexpr bool STEPPED = RLT_DQ_STEPPED != 0 && HD == 64 && !DROP && SPREAD;
             constexpr bool TRREAD = STEPPED && RLT_DQ_TRREAD != 0;
             auto piece = [&](int pc) {                // 0..4: K record (rows + transposed), 5..7: V rows image
-                if (!SPREAD || !more) return;
-                if (TRREAD) {                         // 0..2: K rows image, 3..5: V rows image
-                    if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nk, wv, lane, pc);
-                    else if (pc < 6) dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 3);
+                if (!SPREAD || (!more && !TRREAD)) return;      // (with TRREAD the last tile re-copies itself into the idle stage)
+                if (TRREAD) {                         // 0..2: K rows image, 3..5: V rows image; branch-free (see dma_piece_clamped)
+                    if (pc < 3) dma_piece_clamped<Rec<HD>::RP>(nl, nk, wv, lane, pc);
+                    else if (pc < 6) dma_piece_clamped<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 3);
                 } else if (pc < 5) dma_piece<KREC>(nl, nk, wv, lane, pc);
                 else dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 5);
             };
@@ -705,7 +705,6 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                 bf16x8 fh[24], fl[24];
                 f32x16 sc2[2], dp2[2];
                 bf16x8 gh[2][2], gl[2][2];            // split dS^T: [sub-tile][rows 8s..8s+7 of the block]
-                const bool last = t == nt - 1;
                 auto frag = [&](int st) {
                     const int k = st & 3;
                     if (st < 16) {
@@ -743,47 +742,61 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
                         dq[k & 1] = mfma3(fh[st], fl[st], gh[sub][k >> 1], gl[sub][k >> 1], dq[k & 1]);             // dQ^T[d][q] += K^T dS^T
                     }
                 };
-                auto ew = [&](int sub, int c) {       // registers 2c, 2c+1 of the score block: dS^T = P (dP - delta)
+                // element-wise work as fixed per-step units behind the MFMAs (see the dK+dV kernel):
+                //   4..7 exp_a | 8..11 mul_a | 12..15 split dS_a + exp_b | 16 mul_b | 17..19 mul_b + split dS_b | 20 split dS_b
+                // No mask for keys beyond B in the last tile: their K rows are zero (prepare pass), so whatever finite dS^T they
+                // get is multiplied by zero in K^T dS^T.
+                uint2 qh_[2][2][2], ql_[2][2][2];     // [sub-tile][half][quarter] -> hi / lo of 4 values of dS^T
+                auto unit_exp = [&](int sub, int c) {
 #pragma unroll
-                    for (int r = 2 * c; r < 2 * c + 2; ++r) {
-                        const bool oob = last && t * KT + sub * 32 + acc_row(r, hh) >= B;      // only the last tile can hold keys beyond B
-                        const float pr = oob ? 0.f : rlt_exp2(sc2[sub][r]);
-                        dp2[sub][r] = pr * dp2[sub][r];
-                    }
+                    for (int r = 4 * c; r < 4 * c + 4; ++r) sc2[sub][r] = rlt_exp2(sc2[sub][r]);
                 };
-                auto split_half = [&](int sub, int s8) {
+                auto unit_mul = [&](int sub, int c) {
+#pragma unroll
+                    for (int r = 4 * c; r < 4 * c + 4; ++r) dp2[sub][r] = sc2[sub][r] * dp2[sub][r];
+                };
+                auto unit_split = [&](int sub, int qd) {
                     const f32x16& w = dp2[sub];
-                    const float x[8] = {w[8 * s8 + 0], w[8 * s8 + 1], w[8 * s8 + 2], w[8 * s8 + 3],
-                                        w[8 * s8 + 4], w[8 * s8 + 5], w[8 * s8 + 6], w[8 * s8 + 7]};
-                    split8(x, gh[sub][s8], gl[sub][s8]);
+                    split4(w[4 * qd], w[4 * qd + 1], w[4 * qd + 2], w[4 * qd + 3], qh_[sub][qd >> 1][qd & 1], ql_[sub][qd >> 1][qd & 1]);
                 };
-                auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-                auto burst = [&](int b4) {
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int st = 4 * b4; st < 4 * b4 + 4; ++st) { mm(st); fence(); }
-                    __builtin_amdgcn_s_setprio(0);
+                auto operand = [&](int sub, int half) {
+                    gh[sub][half] = as_frag(make_uint4(qh_[sub][half][0].x, qh_[sub][half][0].y, qh_[sub][half][1].x, qh_[sub][half][1].y));
+                    gl[sub][half] = as_frag(make_uint4(ql_[sub][half][0].x, ql_[sub][half][0].y, ql_[sub][half][1].x, ql_[sub][half][1].y));
+                };
+                auto pattern = [] {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 };
                 frag(0); frag(1);
-                burst(0);                             // S_a
-                burst(1);                             // dP_a
-                burst(2);                             // S_b
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ew(0, c);
-                split_half(0, 0);
-                fence();
-                burst(3);                             // dP_b
+                for (int st = 0; st < 4; ++st) { mm(st); pattern(); }                                   // S_a
 #pragma unroll
-                for (int c = 4; c < 8; ++c) ew(0, c);
-                split_half(0, 1);
-                fence();
-                burst(4);                             // dQ_a
+                for (int st = 4; st < 8; ++st) { mm(st); unit_exp(0, st - 4); pattern(); }              // dP_a
 #pragma unroll
-                for (int c = 0; c < 8; ++c) ew(1, c);
-                split_half(1, 0);
-                split_half(1, 1);
-                fence();
-                burst(5);                             // dQ_b
+                for (int st = 8; st < 12; ++st) { mm(st); unit_mul(0, st - 8); pattern(); }             // S_b
+#pragma unroll
+                for (int st = 12; st < 16; ++st) { mm(st); unit_split(0, st - 12); unit_exp(1, st - 12); pattern(); }   // dP_b
+                operand(0, 0); operand(0, 1);
+#pragma unroll
+                for (int st = 16; st < 20; ++st) {                                                      // dQ_a
+                    mm(st); unit_mul(1, st - 16);
+                    if (st > 16) unit_split(1, st - 17);
+                    pattern();
+                }
+#pragma unroll
+                for (int st = 20; st < 24; ++st) {                                                      // dQ_b
+                    if (st == 20) operand(1, 0);
+                    if (st == 22) operand(1, 1);
+                    mm(st);
+                    if (st == 20) unit_split(1, 3);
+                    pattern();
+                }
             } else {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
