@@ -371,6 +371,7 @@ struct PrepArgs {
     uint8_t* out;                                       // records: [matrix][pair][tile]
     int S, B, H, nmat;
     int perm16[3];                                      // transposed image of matrix m in kpos16 order (head dim 16: Q, dO)
+    int skip_t[3];                                      // matrix m: no transposed image (its bytes of the record stay unwritten)
 };
 
 template <int HD>
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
         for (int i = 0; i < 4; ++i) { st.v[i].x *= mul; st.v[i].y *= mul; st.v[i].z *= mul; st.v[i].w *= mul; }
     }
     stage_store_rows<HD>(r_hi, r_lo, tid, st);
-    stage_store_T<HD>(t_hi, t_lo, tid, st, a.perm16[m] != 0);
+    const bool skip_t = a.skip_t[m] != 0;
+    if (!skip_t) stage_store_T<HD>(t_hi, t_lo, tid, st, a.perm16[m] != 0);
     if (T_rows<HD>() > HD && tid < KT) t_hi[HD * LDT3 + tid] = 0x3F80;      // bf16 1.0 (lo plane stays 0)
     if (a.lse && tid < KT) {
         const int q = tile * KT + tid, qc = min(q, a.B - 1);
@@ -408,7 +410,8 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(a.out + (((size_t)m * a.S * a.H + pair) * nt + tile) * Rec<HD>::BYTES);
-    for (int i = tid; i < Rec<HD>::BYTES / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(rec)[i];
+    for (int i = tid; i < Rec<HD>::BYTES / 16; i += 256)
+        if (!skip_t || i < Rec<HD>::RP / 16 || i >= (Rec<HD>::RP + Rec<HD>::TP) / 16) dst[i] = reinterpret_cast<const uint4*>(rec)[i];
 }
 
 #if defined(RLT_STAMPS)
@@ -1185,6 +1188,11 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         p.mul[0] = a.scale * LOG2E; p.mul[1] = 1.f; p.mul[2] = 1.f;
         p.ld = (size_t)3 * E; p.out = (uint8_t*)images; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 3;
         p.perm16[0] = p.perm16[1] = p.perm16[2] = HD == 16 && RLT_HD16_SMALL_MFMA;   // head dim 16: every transposed image feeds mma_T16
+        // head dim 64 without dropout: the stepped dK+dV and dQ bodies read Q^T and K^T transposed from the rows images
+        // (ds_read_b64_tr_b16), so those two images are not written (V^T is: the forward kernel's P.V operand)
+        constexpr bool TR_ALL = HD == 64 && RLT_STEPPED != 0 && RLT_DKV_TRREAD != 0 && RLT_STEPPED_SPREAD != 0 &&
+                                RLT_DQ_STEPPED != 0 && RLT_DQ_TRREAD != 0 && RLT_DQ_SPREAD != 0 && spread_dma<HD>();
+        p.skip_t[0] = p.skip_t[1] = TR_ALL && a.drop_p == 0.f;
         int rc = prepare3<HD>(p, st);
         if (rc) return rc;
     } else if (which == 3) {     // backward prepare: split dO (+ lse, delta)
