@@ -552,8 +552,9 @@ size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
     return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0);
 }
 
-int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
-                                   const void* images, void* ws, size_t ws_bytes, void* stream) {
+// drop_p < 0: unknown (the stand-alone entry point), the dO records get both images
+static int bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+                       const void* images, void* ws, size_t ws_bytes, float drop_p, void* stream) {
     RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0);
     RLT_CHECK_SHAPE(hd_ok(HD));
     const bool split = attn_mode(HD) == 1 && images;
@@ -565,7 +566,13 @@ int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const fl
     if (!split) return RLT_LAUNCH_RESULT();
     AttnArgs a{};
     a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.S = S; a.B = B; a.H = H;
+    a.drop_p = drop_p;
     return rlt_attn3_run(3, a, HD, nullptr, (uint8_t*)ws + delta_bytes(S, B, H), st);
+}
+
+int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+                                   const void* images, void* ws, size_t ws_bytes, void* stream) {
+    return bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, -1.f, stream);
 }
 
 static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
@@ -602,7 +609,8 @@ int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* 
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
                            void* ws, size_t ws_bytes, void* stream) {
-    int rc = rlt_list_attention_bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, stream);
+    RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+    int rc = bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, drop_p, stream);     // knows whether dO^T is needed
     if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
     if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
     return rc;
