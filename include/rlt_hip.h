@@ -241,7 +241,10 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
  */
 /* In the split-bf16 mode the forward first writes Q (pre-scaled), K and V as pre-split bf16 hi/lo tile
  * records (64-row tiles in the kernels' LDS layout) into `images` (rlt_list_attention_fwd_workspace bytes; 0 in
- * fp32 mode, then `images` may be NULL); the caller keeps `images` for the backward pass. */
+ * fp32 mode, then `images` may be NULL); the caller keeps `images` for the backward pass.  The records are written
+ * for the dropout rate of THIS call (without dropout the head-dim-64 backward kernels read the transposed operands
+ * straight from the row images and the transposed images of Q and K are not written): the backward entry points must
+ * be given the same drop_p and seed as the forward call whose `images` they use. */
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD);
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* images, size_t images_bytes, void* stream);
