@@ -28,6 +28,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RLT_SPREAD_HD16
 #define RLT_SPREAD_HD16 0     // head dims 16 / 32 (needs RLT_ASM_DMA_HD16): dQ and dK+dV kernels spread the pieces over the tile body
 #endif
+#ifndef RLT_FWD_TRV
+#define RLT_FWD_TRV 1         // forward kernel, head dim 64: V^T by transposed reads from the V rows image (no transposed image of V)
+#endif
 #ifndef RLT_DQ_STEPPED
 #define RLT_DQ_STEPPED 1      // dQ kernel, head dim 64, no dropout: stepped tile body
 #endif
@@ -220,6 +223,30 @@ __device__ __forceinline__ void mma_T(const uint16_t* __restrict__ thi, const ui
             const uint4 ah = *reinterpret_cast<const uint4*>(thi + off);
             const uint4 al = *reinterpret_cast<const uint4*>(tlo + off);
             acc[dt] = mfma3(as_frag(ah), as_frag(al), wh, wl, acc[dt]);
+        }
+    }
+}
+
+// The same product with the A operand read TRANSPOSED from a rows image [row][HD + 8] (ds_read_b64_tr_b16): the 16-lane
+// group (lane >> 4) covers d = 32 dt + 16 (group & 1) + (lane & 15); the k slots of lane half hh are rows 16 s + 4 hh + {0..3}
+// and + 8 of the 32-row sub-tile - the rows registers 8s..8s+7 of w hold.  No transposed image of the matrix is needed.
+template <int HD>
+__device__ __forceinline__ void mma_Ttr(const uint16_t* __restrict__ rhi, const uint16_t* __restrict__ rlo, int sub, int lane,
+                                        const f32x16& w, f32x16 (&acc)[(HD + 31) / 32]) {
+    constexpr int DT = (HD + 31) / 32;
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float x[8] = {w[8 * s + 0], w[8 * s + 1], w[8 * s + 2], w[8 * s + 3], w[8 * s + 4], w[8 * s + 5], w[8 * s + 6], w[8 * s + 7]};
+        bf16x8 wh, wl;
+        split8(x, wh, wl);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * (HD + 8) + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const bf16x8 ah = cat_frag(tr_read(rhi + off), tr_read(rhi + off + 8 * (HD + 8)));
+            const bf16x8 al = cat_frag(tr_read(rlo + off), tr_read(rlo + off + 8 * (HD + 8)));
+            acc[dt] = mfma3(ah, al, wh, wl, acc[dt]);
         }
     }
 }
@@ -440,6 +467,10 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
     const AttnArgs& a = g.a;
     constexpr int DT = (HD + 31) / 32;
     constexpr int STAGE = Rec<HD>::RP + Rec<HD>::TP;                        // K rows pair | V transposed pair
+    // TRV (head dim 64): P.V takes V^T by transposed reads from the V ROWS image, which is copied in place of the transposed
+    // image (same size at head dim 64); the prepare pass then writes no transposed image of V either
+    constexpr bool TRV = RLT_FWD_TRV != 0 && HD == 64;
+    static_assert(!TRV || Rec<HD>::RP <= Rec<HD>::TP, "the V rows image must fit the stage slot of the transposed image");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
@@ -486,7 +517,8 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     auto issue = [&](int t, int buf) {
         dma_copy<Rec<HD>::RP, asm_dma<HD>()>(lds + buf * STAGE, record<HD>(g.img, 1, npair, nt, pair, t), wv, lane);
-        dma_copy<Rec<HD>::TP, asm_dma<HD>()>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
+        if (TRV) dma_copy<Rec<HD>::RP, asm_dma<HD>()>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
+        else dma_copy<Rec<HD>::TP, asm_dma<HD>()>(lds + buf * STAGE + Rec<HD>::RP, record<HD>(g.img, 2, npair, nt, pair, t) + Rec<HD>::RP, wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
     issue(0, 0);
@@ -495,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
         const int buf = t & 1;
         // head dim 64: the 4-5 LDS-DMA pieces of a wavefront are spread over the tile body instead of all 8 wavefronts
         // issuing everything before their first MFMA (see the dK+dV kernel); a wavefront without queries issues at the top
-        constexpr bool SPREAD = RLT_FWD_SPREAD != 0 && HD == 64 && asm_dma<HD>();
+        constexpr bool SPREAD = RLT_FWD_SPREAD != 0 && HD == 64 && asm_dma<HD>() && !TRV;
         const bool more = t + 1 < nt;
         if (!SPREAD || !wave_live) { if (more) issue(t + 1, buf ^ 1); }
         else if (DROP && more && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
@@ -512,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
             const uint16_t* k_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
             const uint16_t* k_lo = k_hi + rows_elems<HD>();
             const uint16_t* v_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + Rec<HD>::RP);
-            const uint16_t* v_lo = v_hi + T_elems<HD>();
+            const uint16_t* v_lo = v_hi + (TRV ? rows_elems<HD>() : T_elems<HD>());
             f32x16 sc[2];
             // Lazily rescaled running maximum: the score products start from accumulators holding -m_ref (a 16-register
             // block, the MFMA's C operand), so they come out as s - m_ref with no subtraction per score, and m_ref moves -
@@ -583,6 +615,7 @@ __global__ __launch_bounds__(512, 2) void attn3_fwd_kernel(Attn3Args g) {
                 }
                 piece(3 + 2 * sub);
                 if (S16) mma_T16(v_hi, v_lo, sub, lane, sc[sub], o16, LMFMA ? l16 : nullptr);   // O^T[d][q] (+ sum of P)
+                else if (TRV) mma_Ttr<HD>(v_hi, v_lo, sub, lane, sc[sub], oacc);                // O^T[d][q], V^T read transposed
                 else mma_T<HD>(v_hi, v_lo, sub, l31, hh, sc[sub], oacc);                        // O^T[d][q]
                 if (sub == 0) piece(4);
             }
@@ -1193,6 +1226,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         constexpr bool TR_ALL = HD == 64 && RLT_STEPPED != 0 && RLT_DKV_TRREAD != 0 && RLT_STEPPED_SPREAD != 0 &&
                                 RLT_DQ_STEPPED != 0 && RLT_DQ_TRREAD != 0 && RLT_DQ_SPREAD != 0 && spread_dma<HD>();
         p.skip_t[0] = p.skip_t[1] = TR_ALL && a.drop_p == 0.f;
+        p.skip_t[2] = HD == 64 && RLT_FWD_TRV != 0;          // V^T: only the forward kernel's P.V used it
         int rc = prepare3<HD>(p, st);
         if (rc) return rc;
     } else if (which == 3) {     // backward prepare: split dO (+ lse, delta)
