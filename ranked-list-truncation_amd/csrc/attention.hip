@@ -562,10 +562,13 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
     hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
-    if (!split) return RLT_LAUNCH_RESULT();
-    AttnArgs a{};
+    if (!split) {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
+        return RLT_LAUNCH_RESULT();
+    }
+    AttnArgs a{};       // split-bf16 mode: the pass that writes the dO records computes delta from the tiles it has in registers
     a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.S = S; a.B = B; a.H = H;
+    a.o = const_cast<float*>(out);
     a.drop_p = drop_p;
     return rlt_attn3_run(3, a, HD, nullptr, (uint8_t*)ws + delta_bytes(S, B, H), st);
 }

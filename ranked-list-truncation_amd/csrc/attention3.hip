@@ -395,6 +395,7 @@ __device__ __forceinline__ void image_row_frags(const uint8_t* __restrict__ rec,
 struct PrepArgs {
     const float* src[3]; size_t ld; float mul[3];      // up to 3 matrices (row-major tiles of HD columns), scale factors
     const float* lse; const float* delta;              // optional aux (dO records)
+    const float* o; float* delta_out;                  // dO records: delta = rowsum(dO * O) is computed here (and written out)
     uint8_t* out;                                       // records: [matrix][pair][tile]
     int S, B, H, nmat;
     int perm16[3];                                      // transposed image of matrix m in kpos16 order (head dim 16: Q, dO)
@@ -420,6 +421,31 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     const float* base = a.src[m] + (size_t)s * a.B * a.ld + h * HD;
     Stage<HD> st;
     stage_load<HD>(base, a.ld, tile * KT, a.B, tid, st);
+    if (a.o) {
+        // delta[q] = sum_d dO[q][d] * O[q][d] of this head, from the tile already in registers (a separate pass over dO and O
+        // did this before): the HD/4 threads of a 4-row block reduce their partial dot products by shuffles
+        Stage<HD> so;
+        stage_load<HD>(a.o + (size_t)s * a.B * a.ld + h * HD, a.ld, tile * KT, a.B, tid, so);
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        if (stage_active<HD>(tid)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                part[i] = st.v[i].x * so.v[i].x + st.v[i].y * so.v[i].y + st.v[i].z * so.v[i].z + st.v[i].w * so.v[i].w;
+        }
+#pragma unroll
+        for (int off = 1; off < HD / 4; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[i] += __shfl_xor(part[i], off, 64);
+        if (stage_active<HD>(tid) && tid % (HD / 4) == 0) {
+            const int rb = tid / (HD / 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tile * KT + 4 * rb + i;
+                aux[KT + 4 * rb + i] = q < a.B ? -part[i] : 0.f;
+                if (q < a.B) a.delta_out[((size_t)s * a.H + h) * a.B + q] = part[i];
+            }
+        }
+    }
     if (stage_active<HD>(tid)) {
         const float mul = a.mul[m];
 #pragma unroll
@@ -431,9 +457,9 @@ __global__ __launch_bounds__(256) void attn3_prepare_kernel(PrepArgs a) {
     if (T_rows<HD>() > HD && tid < KT) t_hi[HD * LDT3 + tid] = 0x3F80;      // bf16 1.0 (lo plane stays 0)
     if (a.lse && tid < KT) {
         const int q = tile * KT + tid, qc = min(q, a.B - 1);
-        const float l = a.lse[((size_t)s * a.H + h) * a.B + qc], e = a.delta[((size_t)s * a.H + h) * a.B + qc];
+        const float l = a.lse[((size_t)s * a.H + h) * a.B + qc];
         aux[tid] = q < a.B ? -l * LOG2E : 0.f;          // negated: both seed MFMA accumulators (S - lse, dP - delta)
-        aux[KT + tid] = q < a.B ? -e : 0.f;
+        if (!a.o) aux[KT + tid] = q < a.B ? -a.delta[((size_t)s * a.H + h) * a.B + qc] : 0.f;
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(a.out + (((size_t)m * a.S * a.H + pair) * nt + tile) * Rec<HD>::BYTES);
@@ -1233,6 +1259,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         PrepArgs p{};
         p.src[0] = a.dout; p.mul[0] = 1.f; p.ld = (size_t)a.H * HD;
         p.lse = a.lse; p.delta = a.delta;
+        p.o = a.o; p.delta_out = const_cast<float*>(a.delta);     // with a.o set: delta is computed by the prepare pass
         p.out = (uint8_t*)dimages; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 1;
         p.perm16[0] = HD == 16 && RLT_HD16_SMALL_MFMA;       // dO^T likewise
         // dO^T is read transposed from the rows image by the stepped dK+dV body; the caller says so with drop_p == 0
