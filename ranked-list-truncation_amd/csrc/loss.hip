@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
 #pragma unroll
     for (int i = 0; i < C; ++i) { dpv[i] = 0.f; rv[i] = 0.f; qv[i] = 0.f; }
 
+    float yv[C], pv[C];                        // this lane's C consecutive positions (also used by the metrics below)
     {
         const float* ly = wy + lane * STRIDE;
         const float* lp = wp + lane * STRIDE;
-        float yv[C], pv[C];
         bool ok[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) {
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     }
     // ---- cut metrics of the same lists (METRICS) ---------------------------------------------------
     if (METRICS) {
-        const float* ly = wy + lane * STRIDE;
-        const float* lp = wp + lane * STRIDE;
+        const float* ly = yv;                  // (registers: the rows were read from LDS once, above)
+        const float* lp = pv;
         // first maximum, like np.argmax (run.py:141-142): per-lane scan in index order, then (value, index) reduction
         float best = -INFINITY;
         int bi = 0x7fffffff;
