@@ -53,7 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RLT_DQ_SPREAD 1       // dQ kernel likewise (measured -2 %)
 #endif
 #ifndef RLT_SPREAD_EVERY
-#define RLT_SPREAD_EVERY 4    // one piece every so many matrix steps (7 pieces per wavefront and tile with RLT_DKV_TRREAD, 32 steps)
+#define RLT_SPREAD_EVERY 6    // one piece every so many matrix steps (5 pieces per wavefront and tile with RLT_DKV_TRREAD, 32 steps)
 #endif
 #ifndef RLT_STEPPED
 #define RLT_STEPPED 1         // dK+dV, head dim 64: stepped tile body with this fragment prefetch distance (matrix steps; 1 measured best: 4.63 vs 4.69 ms at 2); 0 = compiler-scheduled body
@@ -958,6 +958,20 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         dma_copy<STAGE - QREC, asm_dma<HD>()>(lds + buf * STAGE + QREC, record<HD>(g.dimg, 0, npair, nt, pair, t), wv, lane);   // whole dO record
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_row_hash(ps, (uint32_t)(t * KT + tid));
     };
+    // TRREAD (stepped head-dim-64 body): the dV / dK products take their A operands from the ROWS images with
+    // ds_read_b64_tr_b16, so the transposed images are not copied at all.  The 37 chunks of a tile - Q rows image 18, dO rows
+    // image 18, aux block 1 - are ONE list dealt to the 8 wavefronts, 5 slots each (3 of the 40 re-copy the aux chunk);
+    // source and destination follow from the chunk id by selects: branch-free, so that the tile body stays one basic block.
+    constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64 && !DROP;
+    auto deal_piece = [&](const uint8_t* nq, const uint8_t* nd, uint8_t* nl, int pc) {
+        constexpr int NR = Rec<HD>::RP / 1024;
+        const int id = min(wv + 8 * pc, 2 * NR);
+        const bool isq = id < NR, isaux = id == 2 * NR;
+        const int ch = isq ? id : id - NR;
+        const uint8_t* src = (isq ? nq : nd) + (isaux ? QREC : ch * 1024) + lane * 16;
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)nl + (isq ? 0 : QREC) + (isaux ? QREC : ch * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+    };
     issue(0, 0);
     dma_wait_barrier<asm_dma<HD>()>();
     for (int t = 0; t < nt; ++t) {
@@ -967,7 +981,14 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         // tile cost every one of them ~1,500 cycles before the first MFMA (timeline stamps).  A wavefront without keys runs no
         // matrix steps and issues its pieces here.
         constexpr bool SPREAD = RLT_STEPPED_SPREAD != 0 && spread_dma<HD>() && (HD != 64 || (RLT_STEPPED != 0 && !DROP));
-        if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
+        if (SPREAD && TRREAD && !wave_live) {        // its 5 slots of the dealt list, all at once
+            if (t + 1 < nt) {
+                const uint8_t* nq1 = record<HD>(g.img, 0, npair, nt, pair, t + 1);
+                const uint8_t* nd1 = record<HD>(g.dimg, 0, npair, nt, pair, t + 1);
+#pragma unroll
+                for (int pc = 0; pc < 5; ++pc) deal_piece(nq1, nd1, lds + (buf ^ 1) * STAGE, pc);
+            }
+        } else if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
         if (wave_live) {
             const uint16_t* qr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
@@ -986,19 +1007,10 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
             const uint8_t* nq = record<HD>(g.img, 0, npair, nt, pair, min(t + 1, nt - 1));
             const uint8_t* nd = record<HD>(g.dimg, 0, npair, nt, pair, min(t + 1, nt - 1));
             uint8_t* nl = lds + (buf ^ 1) * STAGE;
-            // TRREAD (stepped head-dim-64 body): the dV / dK products take their A operands from the ROWS images with
-            // ds_read_b64_tr_b16, so the transposed images are not copied at all: 37 pieces per tile instead of 73
-            constexpr bool TRREAD = RLT_DKV_TRREAD != 0 && RLT_STEPPED != 0 && HD == 64 && !DROP;
             auto next_piece = [&](int pc) {
-                if (!more && !(TRREAD && true)) return;
-                if (TRREAD && true) {   // the same, branch-free (the last tile re-copies itself into the idle stage)
-                    if (pc < 3) dma_piece_clamped<Rec<HD>::RP>(nl, nq, wv, lane, pc);
-                    else if (pc < 6) dma_piece_clamped<Rec<HD>::RP>(nl + QREC, nd, wv, lane, pc - 3);
-                    else if (pc == 6) dma_piece_clamped<Rec<HD>::AUX>(nl + 2 * QREC, nd + QREC, wv, lane, 0);
-                } else if (TRREAD) {  // 0..2: Q rows image, 3..5: dO rows image, 6: the aux block (-lse, -delta) behind the dO images
-                    if (pc < 3) dma_piece<Rec<HD>::RP>(nl, nq, wv, lane, pc);
-                    else if (pc < 6) dma_piece<Rec<HD>::RP>(nl + QREC, nd, wv, lane, pc - 3);
-                    else if (pc == 6) dma_piece<Rec<HD>::AUX>(nl + 2 * QREC, nd + QREC, wv, lane, 0);
+                if (!more && !TRREAD) return;
+                if (TRREAD) {                     // (the last tile re-copies itself into the idle stage)
+                    if (pc < 5) deal_piece(nq, nd, nl, pc);
                 } else if (pc < 5) dma_piece<QREC>(nl, nq, wv, lane, pc);
                 else dma_piece<STAGE - QREC>(nl + QREC, nd, wv, lane, pc - 5);
             };
