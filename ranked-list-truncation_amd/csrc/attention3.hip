@@ -38,7 +38,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RLT_DQ_TRREAD 1       // ... with K^T read transposed from the K rows image (K^T image not copied)
 #endif
 #ifndef RLT_DQ_SPREAD_EVERY
-#define RLT_DQ_SPREAD_EVERY 3 // ... one LDS-DMA piece every so many of its 24 matrix steps
+#define RLT_DQ_SPREAD_EVERY 4 // ... one LDS-DMA piece every so many of its 24 matrix steps (5 pieces per wavefront)
 #endif
 #ifndef RLT_DKV_TRREAD
 #define RLT_DKV_TRREAD 1      // stepped dK+dV body: transposed operands by ds_read_b64_tr_b16 from the rows images (no transposed images copied)
@@ -734,11 +734,29 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
         dma_copy<Rec<HD>::RP, asm_dma<HD>()>(lds + buf * STAGE + KREC, record<HD>(g.img, 2, npair, nt, pair, t), wv, lane);
         if (DROP && tid < KT) htab[buf * KT + tid] = rlt_col_hash(ps, (uint32_t)(t * KT + tid));
     };
+    // stepped body with transposed reads (head dim 64, no dropout): only the K and V ROWS images are copied - 36 chunks dealt
+    // as one list to the 8 wavefronts, 5 slots each (4 re-copy the last chunk), branch-free (see the dK+dV kernel)
+    constexpr bool DEAL = RLT_DQ_STEPPED != 0 && RLT_DQ_TRREAD != 0 && HD == 64 && !DROP && SPREAD;
+    auto deal_piece = [&](const uint8_t* nk, const uint8_t* nv, uint8_t* nl, int pc) {
+        constexpr int NR = Rec<HD>::RP / 1024;
+        const int id = min(wv + 8 * pc, 2 * NR - 1);
+        const bool isk = id < NR;
+        const int ch = isk ? id : id - NR;
+        const uint8_t* src = (isk ? nk : nv) + ch * 1024 + lane * 16;
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)nl + (isk ? 0 : KREC) + ch * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+    };
     issue(0, 0);
     dma_wait_barrier<asm_dma<HD>()>();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
+        if (DEAL && !wave_live) {                   // a wavefront without queries: its 5 slots of the dealt list, all at once
+            if (t + 1 < nt) {
+#pragma unroll
+                for (int pc = 0; pc < 5; ++pc)
+                    deal_piece(record<HD>(g.img, 1, npair, nt, pair, t + 1), record<HD>(g.img, 2, npair, nt, pair, t + 1), lds + (buf ^ 1) * STAGE, pc);
+            }
+        } else if (!SPREAD || !wave_live) { if (t + 1 < nt) issue(t + 1, buf ^ 1); }
         else if (DROP && t + 1 < nt && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         if (wave_live) {
             const uint16_t* kr_hi = reinterpret_cast<const uint16_t*>(lds + buf * STAGE);
@@ -756,9 +774,8 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
             constexpr bool TRREAD = STEPPED && RLT_DQ_TRREAD != 0;
             auto piece = [&](int pc) {                // 0..4: K record (rows + transposed), 5..7: V rows image
                 if (!SPREAD || (!more && !TRREAD)) return;      // (with TRREAD the last tile re-copies itself into the idle stage)
-                if (TRREAD) {                         // 0..2: K rows image, 3..5: V rows image; branch-free (see dma_piece_clamped)
-                    if (pc < 3) dma_piece_clamped<Rec<HD>::RP>(nl, nk, wv, lane, pc);
-                    else if (pc < 6) dma_piece_clamped<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 3);
+                if (TRREAD) {
+                    if (pc < 5) deal_piece(nk, nv, nl, pc);
                 } else if (pc < 5) dma_piece<KREC>(nl, nk, wv, lane, pc);
                 else dma_piece<Rec<HD>::RP>(nl + KREC, nv, wv, lane, pc - 5);
             };
