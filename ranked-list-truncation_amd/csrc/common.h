@@ -35,26 +35,61 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // below 2^-126 flush to zero, which every caller (softmax weights, sigmoid) tolerates
 __device__ __forceinline__ float rlt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// All of them must be called by a whole wavefront (wave-uniform control flow, 64 active lanes).
+// The cross-lane steps are DPP operand modifiers of the VALU (row_shr 1/2/4/8 inside the rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 across the rows): 6 dependent vector instructions per scan.  The `__shfl` forms they
+// replace went through the LDS crossbar (`ds_bpermute_b32` + `s_waitcnt lgkmcnt` + select per step: six dependent LDS
+// round trips per reduction, which bound the wave-per-list kernels by latency).
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T rlt_dpp(T old, T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+    } else {
+        struct P { int lo, hi; };
+        const P o = __builtin_bit_cast(P, old), s = __builtin_bit_cast(P, v);
+        P r;
+        r.lo = __builtin_amdgcn_update_dpp(o.lo, s.lo, CTRL, ROW_MASK, 0xf, false);
+        r.hi = __builtin_amdgcn_update_dpp(o.hi, s.hi, CTRL, ROW_MASK, 0xf, false);
+        return __builtin_bit_cast(T, r);
+    }
+}
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+__device__ __forceinline__ T rlt_readlane(T v, int lane) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+    } else {
+        struct P { int lo, hi; };
+        P s = __builtin_bit_cast(P, v);
+        s.lo = __builtin_amdgcn_readlane(s.lo, lane);
+        s.hi = __builtin_amdgcn_readlane(s.hi, lane);
+        return __builtin_bit_cast(T, s);
+    }
+}
+// inclusive scan over the 64 lanes with the associative `op` whose identity is `id` (lanes without a source keep `id`)
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_scan_op(T v, T id, Op op) {
+    v = op(v, rlt_dpp<0x111, 0xf>(id, v));      // row_shr:1
+    v = op(v, rlt_dpp<0x112, 0xf>(id, v));      // row_shr:2
+    v = op(v, rlt_dpp<0x114, 0xf>(id, v));      // row_shr:4
+    v = op(v, rlt_dpp<0x118, 0xf>(id, v));      // row_shr:8   -> inclusive inside each row of 16
+    v = op(v, rlt_dpp<0x142, 0xa>(id, v));      // row_bcast:15 into rows 1 and 3
+    v = op(v, rlt_dpp<0x143, 0xc>(id, v));      // row_bcast:31 into rows 2 and 3
     return v;
 }
+// sum over the 64 lanes, the same value (a scalar register) in every lane; fixed order
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    return rlt_readlane(wave_scan_op(v, T(0), [](T a, T b) { return a + b; }), 63);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    return rlt_readlane(wave_scan_op(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); }), 63);
 }
 // inclusive prefix sum across the 64 lanes
 template <typename T>
-__device__ __forceinline__ T wave_scan_incl(T v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        T o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
+__device__ __forceinline__ T wave_scan_incl(T v, int /*lane*/) {
+    return wave_scan_op(v, T(0), [](T a, T b) { return a + b; });
 }
 
 // ---- f32 MFMA (exact fp32 products; 64 FLOP/clk/SIMD on gfx950) -------------------------------

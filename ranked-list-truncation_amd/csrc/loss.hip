@@ -25,6 +25,14 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }   // ln x
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); } // e^x
 
+// (value, index) argmax over the wavefront, first maximum: the wave maximum by DPP, then the smallest index among the
+// lanes that hold it (each lane brings the first maximum of its own positions)
+__device__ __forceinline__ int wave_first_index_of_max(float best, int bi) {
+    const float m = wave_max(best);
+    const int cand = (best == m) ? bi : 0x7fffffff;
+    return rlt_readlane(wave_scan_op(cand, 0x7fffffff, [](int a, int b) { return a < b ? a : b; }), 63);
+}
+
 struct RewardArgs {
     const float* p;        // (B,S) or null
     const float* y;        // (B,S)
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
             for (int i = 0; i < C; ++i) { run += yv[i]; pre[i] = run; }
             const float incl = wave_scan_incl(run, lane);
             const float excl = incl - run;
-            const float n_rel = __shfl(incl, 63, 64);
+            const float n_rel = rlt_readlane(incl, 63);
             // p = c/k, r = c/N, F1 = 2pr/(p+r) (0 when c = 0 or N = 0) = 2c/(k+N) for c > 0
 #pragma unroll
             for (int i = 0; i < C; ++i) {
@@ -212,12 +220,7 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
             const int j = lane * C + i;
             if (j < S && lp[i] > best) { best = lp[i]; bi = j; }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
+        bi = wave_first_index_of_max(best, bi);
         const int k = (bi == 0x7fffffff ? 0 : bi) + 1;
         // utils/metrics.py:15-38: the counts are small integers (exact in fp32), only the DCG sum needs float64
         float hits_f = 0.f, nrel_f = 0.f;
@@ -434,12 +437,7 @@ __global__ __launch_bounds__(256) void cut_metrics_kernel(const float* p, const 
             const float v = pr[j];
             if (v > best) { best = v; bi = j; }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
+        bi = wave_first_index_of_max(best, bi);
         k = (bi == 0x7fffffff ? 0 : bi) + 1;
     }
     // utils/metrics.py:15-38 in float64
