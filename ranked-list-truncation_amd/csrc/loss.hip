@@ -11,6 +11,9 @@
 // Algorithmic bytes per list (fp32): read p 4S + labels 4S, write dL/dp 4S (+ 4 B loss) = 3.6 KB at
 // S = 300.
 #include "common.h"
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -276,6 +279,221 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     }
 }
 
+// ---- the same pass, two lists per wavefront (the form the training step runs) ----------------------------------
+// A half-wavefront (32 lanes) owns a list and every lane keeps the 16-byte pieces it loaded: in round r lane l holds
+// positions 128 r + 4 l .. + 3, so loads and stores are whole coalesced rows and nothing is turned through LDS.  The
+// prefix sums run round by round (3 serial adds, a 32-lane DPP scan - the row_shr steps plus one row_bcast:15 - and the
+// running total of the rounds before); the reductions are the same scan read at the last lane of the half.  Per-position
+// constants (position numbers, the float64 DCG coefficients) are fetched once per wavefront, outside the list loop.
+// Requires S % 4 == 0, S <= 128 R <= 384, 16-byte aligned rows, p and dp present (the general kernel above takes the rest).
+template <typename T, typename Op>
+__device__ __forceinline__ T half_scan_op(T v, T id, Op op) {
+    v = op(v, rlt_dpp<0x111, 0xf>(id, v));
+    v = op(v, rlt_dpp<0x112, 0xf>(id, v));
+    v = op(v, rlt_dpp<0x114, 0xf>(id, v));
+    v = op(v, rlt_dpp<0x118, 0xf>(id, v));
+    v = op(v, rlt_dpp<0x142, 0xa>(id, v));      // row 0 -> row 1, row 2 -> row 3: inclusive inside each half
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T half_last(T v, bool upper) {     // the value of the last lane of the caller's half
+    const T lo = rlt_readlane(v, 31), hi = rlt_readlane(v, 63);
+    return upper ? hi : lo;
+}
+template <typename T>
+__device__ __forceinline__ T half_sum(T v, bool upper) {
+    return half_last(half_scan_op(v, T(0), [](T x, T y) { return x + y; }), upper);
+}
+
+template <int R, bool METRICS, bool F1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F1 ? 4 : 3)))   // <= 128 (168) registers, no spills
+void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
+    constexpr int N = 4 * R;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool upper = lane >= 32;
+    const int hl = lane & 31;
+    const int S = a.S, B = a.B;
+    const bool last_ok = (R - 1) * 128 + 4 * hl < S;          // rounds before the last lie inside the list by construction
+    auto ok = [&](int r) { return r < R - 1 || last_ok; };
+    // ---- per-position constants of this lane -------------------------------------------------------------------
+    float icf[F1 ? 1 : N];                                    // DCG reward: 1 / log2(j + 2), 0 beyond the list
+    if (!F1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) icf[4 * r + i] = ok(r) ? fast_rcp(a.coef[r * 128 + 4 * hl + i]) : 0.f;
+    }
+    const float c_exp = (1.f / a.tau) * 1.4426950408889634f;
+    double part_loss = 0.0, part_f1 = 0.0, part_dcg = 0.0;
+    const int nwaves = gridDim.x * 4;
+    for (int pb = 2 * (blockIdx.x * 4 + wv); pb < B; pb += 2 * nwaves) {
+        const bool live = pb + (upper ? 1 : 0) < B;           // B odd: the idle half shadows its partner, stores masked
+        const int b = live ? pb + (upper ? 1 : 0) : pb;
+        const size_t base = (size_t)b * S;
+        float y[N], p[N];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const size_t at = base + (ok(r) ? r * 128 + 4 * hl : 0);
+            float4 vy = *reinterpret_cast<const float4*>(a.y + at);
+            float4 vp = *reinterpret_cast<const float4*>(a.p + at);
+            if (r == R - 1 && !last_ok) { vy = make_float4(0.f, 0.f, 0.f, 0.f); vp = make_float4(1.f, 1.f, 1.f, 1.f); }
+            y[4 * r] = vy.x; y[4 * r + 1] = vy.y; y[4 * r + 2] = vy.z; y[4 * r + 3] = vy.w;
+            p[4 * r] = vp.x; p[4 * r + 1] = vp.y; p[4 * r + 2] = vp.z; p[4 * r + 3] = vp.w;
+        }
+        // ---- reward r_k (k = j + 1) by prefix sums over the rounds --------------------------------------------
+        float rv[N];
+        float n_rel = 0.f;
+        if (F1) {                                             // utils/metrics.py:85-91: F1 = 2c / (k + N), 0 when c = 0
+            float off = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float s0 = y[4 * r], s1 = s0 + y[4 * r + 1], s2 = s1 + y[4 * r + 2], s3 = s2 + y[4 * r + 3];
+                const float incl = half_scan_op(s3, 0.f, [](float x, float z) { return x + z; });
+                const float ex = (incl - s3) + off;
+                rv[4 * r] = ex + s0; rv[4 * r + 1] = ex + s1; rv[4 * r + 2] = ex + s2; rv[4 * r + 3] = ex + s3;
+                off += half_last(incl, upper);
+            }
+            n_rel = off;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float k0 = (float)(r * 128 + 4 * hl) + n_rel;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float hits = rv[4 * r + i];
+                    rv[4 * r + i] = (hits > 0.f) ? (2.f * hits) * fast_rcp(k0 + (float)(i + 1)) : 0.f;
+                }
+            }
+        } else {                                              // utils/metrics.py:93-101: prefix of (+1 | penalty) / log2(j+2)
+            float off = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float g[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[i] = (y[4 * r + i] == 1.f) ? icf[4 * r + i] : icf[4 * r + i] * a.penalty;
+                const float s0 = g[0], s1 = s0 + g[1], s2 = s1 + g[2], s3 = s2 + g[3];
+                const float incl = half_scan_op(s3, 0.f, [](float x, float z) { return x + z; });
+                const float ex = (incl - s3) + off;
+                rv[4 * r] = ex + s0; rv[4 * r + 1] = ex + s1; rv[4 * r + 2] = ex + s2; rv[4 * r + 3] = ex + s3;
+                off += half_last(incl, upper);
+            }
+            if (METRICS) {
+                float cnt = 0.f;
+#pragma unroll
+                for (int n = 0; n < N; ++n) cnt += y[n];
+                n_rel = half_sum(cnt, upper);
+            }
+        }
+        // ---- q = exp(r / tau) / sum (utils/losses.py:226-228; no maximum subtracted, like the reference) ----------
+        float q[N];
+        if (a.kind != RLT_LOSS_EXPECT) {
+            float zs = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                q[n] = rlt_exp2(rv[n] * c_exp);
+                if (n >= N - 4 && !last_ok) q[n] = 0.f;
+                zs += q[n];
+            }
+            const float iz = fast_rcp(half_sum(zs, upper));
+#pragma unroll
+            for (int n = 0; n < N; ++n) q[n] *= iz;
+        }
+        // ---- loss terms and d/dp (positions beyond the list carry p = 1, q = 0) -----------------------------------
+        float part = 0.f;
+        float dpv[N];
+        if (a.kind == RLT_LOSS_EXPECT) {                      // utils/losses.py:67-68
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const float r_ = (n >= N - 4 && !last_ok) ? 0.f : rv[n];
+                part -= p[n] * r_;
+                dpv[n] = -r_ * a.gscale;
+            }
+        } else if (a.kind == RLT_LOSS_CE || a.kind == RLT_LOSS_KL) {   // utils/losses.py:94-96 / :230, kl_div(log p, q)
+            const bool kl = a.kind == RLT_LOSS_KL;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const float qlq = (kl && q[n] > 0.f) ? q[n] * fast_log(q[n]) : 0.f;
+                part += qlq - q[n] * fast_log(p[n]);
+                dpv[n] = -q[n] * fast_rcp(p[n]) * a.gscale;
+            }
+        } else {                                              // utils/losses.py:232-233, JS
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const float lm = fast_log((p[n] + q[n]) * 0.5f);
+                const float lp_ = fast_log(p[n]);
+                const float qlq = (q[n] > 0.f) ? q[n] * fast_log(q[n]) : 0.f;
+                const float plp = (p[n] > 0.f) ? p[n] * lp_ : 0.f;
+                const float term = 0.5f * ((qlq - q[n] * lm) + (plp - p[n] * lm));
+                part += (n >= N - 4 && !last_ok) ? 0.f : term;   // (beyond the list p = 1, q = 0 gives -log(1/2) / 2, not 0)
+                dpv[n] = 0.5f * (lp_ - lm) * a.gscale;        // gradient flows through log m AND the target p
+            }
+        }
+        const float tot = half_sum(part, upper);
+        if (hl == 0 && live && a.loss_per_list) a.loss_per_list[b] = tot;
+        if (live) part_loss += (double)tot;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (live && ok(r))
+                *reinterpret_cast<float4*>(a.dp + base + r * 128 + 4 * hl) =
+                    make_float4(dpv[4 * r], dpv[4 * r + 1], dpv[4 * r + 2], dpv[4 * r + 3]);
+        // ---- cut metrics of the same lists (run.py:141-145 -> utils/metrics.py:15-38) ----------------------------
+        if (METRICS) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = r * 128 + 4 * hl + i;
+                    if (ok(r) && p[4 * r + i] > best) { best = p[4 * r + i]; bi = j; }
+                }
+            const float m = half_last(half_scan_op(best, -INFINITY, [](float x, float z) { return fmaxf(x, z); }), upper);
+            const int cand = (best == m) ? bi : 0x7fffffff;
+            const int kmin = half_last(half_scan_op(cand, 0x7fffffff, [](int x, int z) { return x < z ? x : z; }), upper);
+            const int k = (kmin == 0x7fffffff ? 0 : kmin) + 1;
+            float hits = 0.f;
+            double dcg = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // 1 / log2(j + 2) in float64 (utils/metrics.py:7) from the per-device table: the same 32 bytes per lane
+                // for every list, served by the cache
+                double ic[4];
+                {
+                    const double* src = icoef_tab + (ok(r) ? r * 128 + 4 * hl : 0);
+                    asm volatile("" : "+v"(src));             // keep the loads here: hoisted out of the list loop they cost 8 R registers
+                    const double2 lo = *reinterpret_cast<const double2*>(src), hi = *reinterpret_cast<const double2*>(src + 2);
+                    ic[0] = lo.x; ic[1] = lo.y; ic[2] = hi.x; ic[3] = hi.y;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = r * 128 + 4 * hl + i;
+                    const bool in = j < k && ok(r);
+                    hits += in ? y[4 * r + i] : 0.f;
+                    const double g = (y[4 * r + i] == 1.f) ? ic[i] : ic[i] * a.mpenalty;
+                    dcg += in ? g : 0.0;
+                }
+            }
+            hits = half_sum(hits, upper);
+            dcg = half_sum(dcg, upper);
+            const double f1 = hits > 0.f ? 2.0 * (double)hits / ((double)k + (double)n_rel) : 0.0;
+            if (hl == 0 && live) {
+                a.k_out[b] = k;
+                a.f1_out[b] = f1;
+                a.dcg_out[b] = dcg;
+            }
+            if (live) { part_f1 += f1; part_dcg += dcg; }
+        }
+    }
+    if (METRICS) {                                            // one record per wavefront: lower half + upper half
+        const double l = rlt_readlane(part_loss, 0) + rlt_readlane(part_loss, 32);
+        const double f = rlt_readlane(part_f1, 0) + rlt_readlane(part_f1, 32);
+        const double d = rlt_readlane(part_dcg, 0) + rlt_readlane(part_dcg, 32);
+        if (lane == 0) {
+            double* rec = a.partials + 3 * ((size_t)blockIdx.x * 4 + wv);
+            rec[0] = l; rec[1] = f; rec[2] = d;
+        }
+    }
+}
+
 // out[0] = scale * sum_i x[i], single workgroup, fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* x, int n, float scale, float* out) {
     __shared__ double sm[256];
@@ -325,8 +543,54 @@ int launch_reward(const RewardArgs& a, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
+// 1 / log2(j + 2) for j < 1024 in float64, one table per device, made on first use (host libm, synchronous copy)
+const double* icoef_table() {
+    static std::mutex mu;
+    static double* tab[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> guard(mu);
+    if (!tab[dev]) {
+        static double h[1024];
+        for (int j = 0; j < 1024; ++j) h[j] = 1.0 / std::log2((double)(j + 2));
+        double* d = nullptr;
+        if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tab[dev] = d;
+    }
+    return tab[dev];
+}
+
+// two lists per wavefront: one workgroup per 8 lists up to the same number of workgroups
+int reward_h_grid(int B) {
+    const int groups = rlt_cdiv(B, 2 * LISTS_PER_WG);
+    return groups < REWARD_MAX_GRID ? groups : REWARD_MAX_GRID;
+}
+template <int R, bool METRICS>
+int launch_reward_h(const RewardArgs& a, hipStream_t st) {
+    const double* tab = nullptr;
+    if (METRICS && !(tab = icoef_table())) return RLT_E_ARG;
+    if (a.metric == RLT_METRIC_F1)
+        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, true>), dim3(reward_h_grid(a.B)), dim3(256), 0, st, a, tab);
+    else
+        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, false>), dim3(reward_h_grid(a.B)), dim3(256), 0, st, a, tab);
+    return RLT_LAUNCH_RESULT();
+}
+
+// *records: partial-sum records the pass writes (METRICS), one per wavefront of its grid
 template <bool METRICS>
-int dispatch_reward_m(const RewardArgs& a, hipStream_t st) {
+int dispatch_reward_m(const RewardArgs& a, hipStream_t st, int* records = nullptr) {
+    static const bool general_only = getenv("RLT_LOSS_GENERAL") != nullptr;      // developer switch: A/B against the general kernel
+    const bool halves = a.p && a.dp && !a.r_out && !a.q_out && (a.S & 3) == 0 && a.S <= 384 && rlt_aligned16(a.dp) &&
+                        rlt_aligned16(a.p) && rlt_aligned16(a.y) && !general_only;
+    if (halves) {
+        if (records) *records = reward_h_grid(a.B) * LISTS_PER_WG;
+        const int r = rlt_cdiv(a.S, 128);
+        if (r <= 1) return launch_reward_h<1, METRICS>(a, st);
+        if (r <= 2) return launch_reward_h<2, METRICS>(a, st);
+        return launch_reward_h<3, METRICS>(a, st);
+    }
+    if (records) *records = reward_grid(a.B) * LISTS_PER_WG;
     const int c = rlt_cdiv(a.S, 64);
     if (c <= 1) return launch_reward<1, METRICS>(a, st);
     if (c <= 2) return launch_reward<2, METRICS>(a, st);
@@ -587,9 +851,10 @@ int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef,
     RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
                  k_out, f1_out, dcg_out, metric_penalty, (double*)ws};
     hipStream_t st = rlt_stream(stream);
-    rc = dispatch_reward_m<true>(a, st);
+    int records = 0;
+    rc = dispatch_reward_m<true>(a, st, &records);
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_metrics_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, reward_grid(B) * LISTS_PER_WG,
+    hipLaunchKernelGGL(loss_metrics_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, records,
                        1.0f / (float)B, loss_out, sums);
     return RLT_LAUNCH_RESULT();
 }

@@ -168,7 +168,8 @@ def losses():
         report(f"Metric.dcg penalty {pen:g}", abs(Metric.dcg(gold["y"], gold["k_s"], penalty=pen) - float(gold[f"metric_dcg_pen/{pen:g}"])), 1e-9)
         report(f"Metric_for_Loss.dcg penalty {pen:g}", abs(float(Metric_for_Loss.dcg(y[4], 17, penalty=pen)) - float(gold[f"reward_dcg_pen/{pen:g}"][2, 16])), 1e-5)
     # loss + cut metrics in one pass (rlt_loss_metrics) == the separate kernels, bit for bit; at B = 5000 the grid strides
-    for (Bf, Sf) in ((10, 300), (5000, 300), (9001, 100), (33, 777)):
+    # and above 16,384 lists the two-lists-per-wavefront pass strides too (odd B: its last wavefront works one half)
+    for (Bf, Sf) in ((10, 300), (5000, 300), (9001, 100), (33, 777), (20001, 300)):
         g = torch.Generator().manual_seed(Bf)
         yy = (torch.rand(Bf, Sf, generator=g) < 0.2).float().to(dev)
         pp = torch.softmax(torch.randn(Bf, Sf, generator=g) * 2, 1).unsqueeze(2).to(dev)
@@ -185,21 +186,27 @@ def losses():
             report(f"fused loss+metrics {cname} B{Bf} S{Sf}: dp", float((p1.grad - p2.grad).abs().max()), 0)
             report(f"fused loss+metrics {cname} B{Bf} S{Sf}: k", float((k1 != k2).sum()), 0)
             report(f"fused loss+metrics {cname} B{Bf} S{Sf}: F1, DCG", max(abs(float(f1) - float(f2)), abs(float(d1) - float(d2)) / max(1.0, abs(float(d1)))), 1e-12)
-    # odd S
-    for S in (40, 100, 200, 301, 777):
+    # list lengths around the round boundaries of the two-lists-per-wavefront pass (128 positions per round, S % 4 == 0,
+    # S <= 384) and lengths only the general pass takes, against the oracle: loss, gradient and - fused - k, F1, DCG
+    from oracle import metrics as om
+    for S in (4, 40, 100, 128, 132, 200, 256, 260, 300, 301, 384, 388, 777):
         yy = (torch.rand(7, S) < 0.2).float()
-        pp = torch.softmax(torch.randn(7, S), 1).unsqueeze(2)
-        for cname in ("div_js_f1_aug1", "div_kl_dcg_aug0", "choopy_dcg"):
-            if "dcg" in cname and S > 300 and False:
-                continue
+        yy[3] = 0.0                                          # a list without relevant documents
+        pp = torch.softmax(torch.randn(7, S) * 3, 1).unsqueeze(2)
+        pp[5, :, 0] = 1.0 / S                                # all equal: the first position is the maximum
+        for cname in ("div_js_f1_aug1", "div_kl_dcg_aug0", "choopy_dcg", "attncutloss_f1"):
             pr = pp.clone().requires_grad_(True)
             lr = make_criterion(ol, cname)(pr, yy)
             lr.backward()
             pg = pp.clone().to(dev).requires_grad_(True)
-            lh = make_criterion(hl, cname)(pg, yy.to(dev))
+            lh, kh, f1h, dcgh = Metric.step(make_criterion(hl, cname), pg, yy.to(dev))
             lh.backward()
             report(f"loss {cname} S={S}", abs(lh.item() - lr.item()) / max(1, abs(lr.item())), 2e-5)
             report(f"dp   {cname} S={S}", rel(pg.grad, pr.grad), 1e-4)
+            ko = om.cut_positions(pp.squeeze(2).numpy())
+            report(f"k    {cname} S={S}", float((kh.cpu().numpy() != ko).sum()), 0)
+            report(f"F1, DCG {cname} S={S}", max(abs(float(f1h) - om.Metric.f1(yy.numpy(), ko)),
+                                                 abs(float(dcgh) - om.Metric.dcg(yy.numpy(), ko))), 1e-12)
     # multi-task
     for tag, nt in (("t3", 3), ("t21", 2.1), ("t22", 2.2)):
         for metric in ("f1", "dcg"):
