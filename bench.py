@@ -147,7 +147,7 @@ def hbm_kernel_roofline(S, dev, lists=65536, reps=30):
     us = a.elapsed_time(b) / reps * 1e3
     nbytes = lists * (12.0 * S + 24)
     gbps = nbytes / us / 1e3
-    return {"kernel": "reward_loss_kernel<5,true> + loss_metrics_final_kernel (rlt_loss_metrics)", "bound": "hbm",
+    return {"kernel": "reward_loss_h_kernel<3,true,true> + loss_metrics_final_kernel (rlt_loss_metrics)", "bound": "hbm",
             "lists": lists, "seq_len": S, "us_per_call": round(us, 2), "algorithmic_bytes": nbytes,
             "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
 

@@ -359,8 +359,7 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 const float k0 = (float)(r * 128 + 4 * hl) + n_rel;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float hits = rv[4 * r + i];
-                    rv[4 * r + i] = (hits > 0.f) ? (2.f * hits) * fast_rcp(k0 + (float)(i + 1)) : 0.f;
+                    rv[4 * r + i] = (2.f * rv[4 * r + i]) * fast_rcp(k0 + (float)(i + 1));   // c = 0 gives 0 (k + N >= 1)
                 }
             }
         } else {                                              // utils/metrics.py:93-101: prefix of (+1 | penalty) / log2(j+2)
@@ -415,17 +414,25 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 part += qlq - q[n] * fast_log(p[n]);
                 dpv[n] = -q[n] * fast_rcp(p[n]) * a.gscale;
             }
-        } else {                                              // utils/losses.py:232-233, JS
+        } else {
+            // utils/losses.py:232-233, JS: (q ln(q/m) + p ln(p/m)) / 2 with m = (p + q) / 2.  In log2 units, with
+            // s = p + q: q (log2 q - log2 s) + p (log2 p - log2 s) + s per position, scaled by ln 2 / 2 once per list;
+            // log2 of max(x, 2^-126): x = 0 contributes 0 (0 * finite), as the reference's 0 log 0 = 0.
+            // d/dp = (ln p - ln m) / 2: the gradient flows through log m AND the target p
+            const float cg = 0.5f * 0.6931471805599453f * a.gscale;
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-                const float lm = fast_log((p[n] + q[n]) * 0.5f);
-                const float lp_ = fast_log(p[n]);
-                const float qlq = (q[n] > 0.f) ? q[n] * fast_log(q[n]) : 0.f;
-                const float plp = (p[n] > 0.f) ? p[n] * lp_ : 0.f;
-                const float term = 0.5f * ((qlq - q[n] * lm) + (plp - p[n] * lm));
-                part += (n >= N - 4 && !last_ok) ? 0.f : term;   // (beyond the list p = 1, q = 0 gives -log(1/2) / 2, not 0)
-                dpv[n] = 0.5f * (lp_ - lm) * a.gscale;        // gradient flows through log m AND the target p
+                const float sm = p[n] + q[n];
+                const float l2s = __builtin_amdgcn_logf(sm);
+                const float dq_ = __builtin_amdgcn_logf(fmaxf(q[n], 1.17549435e-38f)) - l2s;
+                const float dp_ = __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f)) - l2s;
+                part = __builtin_fmaf(q[n], dq_, part);
+                part = __builtin_fmaf(p[n], dp_, part);
+                part += sm;
+                dpv[n] = __builtin_fmaf(dp_, cg, cg);
             }
+            if (!last_ok) part -= 4.f;                        // the 4 positions beyond the list carry p = 1, q = 0: s = 1 each
+            part *= 0.5f * 0.6931471805599453f;
         }
         const float tot = half_sum(part, upper);
         if (hl == 0 && live && a.loss_per_list) a.loss_per_list[b] = tot;
@@ -450,12 +457,14 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             const int cand = (best == m) ? bi : 0x7fffffff;
             const int kmin = half_last(half_scan_op(cand, 0x7fffffff, [](int x, int z) { return x < z ? x : z; }), upper);
             const int k = (kmin == 0x7fffffff ? 0 : kmin) + 1;
+            // DCG@k = sum_{j<k} (y_j == 1 ? 1 : pen) / log2(j + 2) = pen * T[k] + (1 - pen) * sum_{j<k, y_j == 1} 1 / log2(j + 2),
+            // T[k] = sum_{j<k} 1 / log2(j + 2) from the per-device table (float64; 1e-16 relative apart from the serial sum)
             float hits = 0.f;
-            double dcg = 0.0;
+            double rel = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                // 1 / log2(j + 2) in float64 (utils/metrics.py:7) from the per-device table: the same 32 bytes per lane
-                // for every list, served by the cache
+                if (r * 128 >= __builtin_amdgcn_readfirstlane(max(rlt_readlane(k, 0), rlt_readlane(k, 32)))) break;   // both cuts lie before this round
+                // 1 / log2(j + 2) in float64 (utils/metrics.py:7): the same 32 bytes per lane for every list, served by the cache
                 double ic[4];
                 {
                     const double* src = icoef_tab + (ok(r) ? r * 128 + 4 * hl : 0);
@@ -468,13 +477,19 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                     const int j = r * 128 + 4 * hl + i;
                     const bool in = j < k && ok(r);
                     hits += in ? y[4 * r + i] : 0.f;
-                    const double g = (y[4 * r + i] == 1.f) ? ic[i] : ic[i] * a.mpenalty;
-                    dcg += in ? g : 0.0;
+                    rel += (in && y[4 * r + i] == 1.f) ? ic[i] : 0.0;
                 }
             }
             hits = half_sum(hits, upper);
-            dcg = half_sum(dcg, upper);
-            const double f1 = hits > 0.f ? 2.0 * (double)hits / ((double)k + (double)n_rel) : 0.0;
+            rel = half_sum(rel, upper);
+            const double dcg = a.mpenalty * icoef_tab[1024 + k] + (1.0 - a.mpenalty) * rel;
+            // F1 = 2pr / (p + r) = 2c / (k + N) (0 when c = 0, which covers N = 0): small integers, reciprocal by two
+            // Newton steps from v_rcp_f64 (~1e-16 relative; the parity bound on the mean is 1e-12)
+            const double den = (double)k + (double)n_rel;
+            double rc = __builtin_amdgcn_rcp(den);
+            rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+            rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+            const double f1 = 2.0 * (double)hits * rc;
             if (hl == 0 && live) {
                 a.k_out[b] = k;
                 a.f1_out[b] = f1;
@@ -543,7 +558,8 @@ int launch_reward(const RewardArgs& a, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
-// 1 / log2(j + 2) for j < 1024 in float64, one table per device, made on first use (host libm, synchronous copy)
+// 1 / log2(j + 2) for j < 1024 in float64 and their prefix sums, one table per device, made on first use (host libm,
+// synchronous copy)
 const double* icoef_table() {
     static std::mutex mu;
     static double* tab[64] = {};
@@ -551,8 +567,12 @@ const double* icoef_table() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> guard(mu);
     if (!tab[dev]) {
-        static double h[1024];
-        for (int j = 0; j < 1024; ++j) h[j] = 1.0 / std::log2((double)(j + 2));
+        static double h[1024 + 1025];                       // [j] = 1 / log2(j + 2);  [1024 + k] = sum_{j<k} of them
+        h[1024] = 0.0;
+        for (int j = 0; j < 1024; ++j) {
+            h[j] = 1.0 / std::log2((double)(j + 2));
+            h[1024 + j + 1] = h[1024 + j] + h[j];
+        }
         double* d = nullptr;
         if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
         if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
