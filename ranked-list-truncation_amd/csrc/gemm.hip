@@ -686,13 +686,13 @@ __device__ __forceinline__ void load3b(const float* __restrict__ P, int ld, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 512 * i;
-            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(mn0 + kcb_row(idx)) * ((RLT_GEMM_ABL_ & 64) ? 0 : ld) + k0 + 4 * (idx & 7));
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)((mn0 + kcb_row(idx)) & ((RLT_GEMM_ABL_ & 128) ? 2047 : -1)) * ((RLT_GEMM_ABL_ & 64) ? 0 : ld) + k0 + 4 * (idx & 7));
         }
     } else {            // [K][MN]: thread owns a 4(k) x 4(mn) block, k block in the low lane bits
         const int kb = tid & 7, mb = tid >> 3;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(k0 + 4 * kb + i) * ((RLT_GEMM_ABL_ & 64) ? 0 : ld) + mn0 + 4 * mb);
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)((k0 + 4 * kb + i) & ((RLT_GEMM_ABL_ & 128) ? 2047 : -1)) * ((RLT_GEMM_ABL_ & 64) ? 0 : ld) + mn0 + 4 * mb);
     }
 }
 // one quarter (`part` = 0..3) of the split + LDS store of a staged operand tile
@@ -741,27 +741,12 @@ __device__ unsigned long long rlt_gemm_stamp_buf[8 * 4];
 // One workgroup per output tile paid the pipeline start-up (two exposed HBM latencies, ~6,000 cycles) and ran its first
 // K tiles against cold loads for every tile: at K = 256 (8 K tiles) that was 57,000 cycles per tile for 24,600 of
 // MFMA work (timeline stamps, profiles/r02_notes.md).
-// Cache-line prefetch `RLT_GEMM_PF` K tiles ahead of the stream (0 = off): every thread touches ONE 128-byte line of the
-// operand tiles of K tile t + PF with a 4-byte non-temporal load whose value nobody uses (threads 0..255 the 256 lines of
-// the A tile, 256..511 those of the B tile).  The staging loads proper sit one K tile (~2 us) ahead of their use and a
-// wavefront's loads complete in order, so a CU has at most 64 KB in flight: with the loaded HBM latency above that the
-// K loop waits (ablation builds: 3.6 ms -> 2.45 ms for the K = 2048 products when every load hits in the caches).
-#ifndef RLT_GEMM_PF
-#define RLT_GEMM_PF 0
-#endif
-template <bool TA, bool TB>
-__device__ __forceinline__ float prefetch_line(const GemmArgs& g, int m0, int n0, int k0, int tid) {
-    const int x = tid & 255, krow = tid & 31, seg = (tid >> 5) & 7;
-    const float* p;
-    if (tid < 256) p = !TA ? g.A + (size_t)(m0 + x) * g.lda + k0 : g.A + (size_t)(k0 + krow) * g.lda + m0 + 32 * seg;
-    else p = TB ? g.B + (size_t)(n0 + x) * g.ldb + k0 : g.B + (size_t)(k0 + krow) * g.ldb + n0 + 32 * seg;
-    return __builtin_nontemporal_load(p);
-}
 // timing-only ablation builds of the K loop (tools/build_variant.py ... -DRLT_GEMM_ABL=bits; results are wrong by design):
 // 1 = no global loads / split / LDS stores inside the loop, 2 = no workgroup barrier per K tile, 4 = no fragment reads
 // (the MFMAs run on the fragments of the first step), 8 = no output, 16 = no global loads inside the loop (the split + LDS
 // stores run on stale registers), 32 = global loads, but no split / LDS stores (the registers are only consumed), 64 = every
-// row of an operand tile aliases row 0 / k row 0 (same instructions, all loads served by the caches)
+// row of an operand tile aliases row 0 / k row 0 (same instructions, all loads served by the L1), 128 = operand rows taken
+// modulo 2048 (distinct lines per instruction as in the product, but a 2-16 MB footprint that stays in the L2 / MALL)
 #ifndef RLT_GEMM_ABL
 #define RLT_GEMM_ABL 0
 #endif
@@ -788,7 +773,6 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     Stage3 sa, sb;
-    float pf1 = 0.f, pf2 = 0.f;                      // prefetch loads in flight (values unused)
     const bool want_cs = TA && g.colsum != nullptr && tn == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int t) {
@@ -894,14 +878,6 @@ __global__ __launch_bounds__(512) void gemm3b_kernel(GemmArgs g) {
             }
             if (step == 5 && !(RLT_GEMM_ABL & (1 | 16))) load3b<!TA>(g.A, g.lda, fm0, kf, tid, sa);
             if (step == 7 && !(RLT_GEMM_ABL & (1 | 16))) load3b<TB>(g.B, g.ldb, fn0, kf, tid, sb);
-            if (RLT_GEMM_PF > 0 && step == 4) asm volatile("" :: "v"(pf2));      // issued two K tiles ago: older than the loads just waited for
-            if (RLT_GEMM_PF > 0 && step == 7) {
-                const int tp = t + RLT_GEMM_PF;
-                const bool wp = PERSIST && has_next && tp >= nt_;
-                const int kp = kbeg + min(wp ? tp - nt_ : tp, nt_ - 1) * BK3;
-                pf2 = pf1;
-                pf1 = prefetch_line<TA, TB>(g, wp ? nm0 : m0, wp ? nn0 : n0, kp, tid);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
