@@ -84,11 +84,13 @@ int rlt_reward_matrix(const float* labels, const float* dcg_coef, int B, int S, 
 int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int S, int metric, float penalty, float tau,
                          float* r_out, float* q_out, void* stream);
 /* Training-step form (run.py:126 + :141-145 in ONE pass over p and labels): everything rlt_reward_loss_ex produces, plus
- * the cut metrics of rlt_cut_metrics_ex on the same rows while they are in LDS - k_out (B) int32 = argmax_j p + 1 (first
+ * the cut metrics of rlt_cut_metrics_ex on the same rows while they are in registers - k_out (B) int32 = argmax_j p + 1 (first
  * maximum), f1_out / dcg_out (B) float64 (DCG with `metric_penalty`, utils/metrics.py:27), sums[0..1] = their batch sums.
  * loss_out = (sum of the per-list terms)/B from a float64 sum.  All outputs required except dp.  Two launches: the pass
- * (one ranked list per wavefront, a grid sized to the chip striding over the lists; every wavefront leaves its float64
- * partial sums in ws) and a one-workgroup fixed-order reduction of those partials (deterministic).
+ * (two ranked lists per wavefront - one per 32-lane half - when S % 4 == 0 and S <= 384, one per wavefront otherwise; a grid
+ * sized to the chip striding over the lists; every wavefront leaves its float64 partial sums in ws) and a one-workgroup
+ * fixed-order reduction of those partials (deterministic).  The float64 DCG coefficients 1/log2(j+2) and their prefix sums
+ * come from a per-device table the library builds on first use (a 16 KB allocation and one synchronous copy).
  * ws: rlt_loss_metrics_workspace(B) bytes.
  * Algorithmic bytes per list: read p, labels 8S, write dp 4S + 24 B of results (3.6 KB at S = 300). */
 size_t rlt_loss_metrics_workspace(int B);

@@ -5,7 +5,7 @@ returns a 0-d tensor supporting .backward() and .item().
 
 The reference builds its (B,S) reward matrix with B*S python calls of O(S) tensor ops; here the
 reward matrix, its softmax, the divergence and d(loss)/d(output) come out of ONE kernel pass
-(`rlt_reward_loss`), one ranked list per wavefront.
+(`rlt_reward_loss`), one ranked list per wavefront or per half wavefront.
 """
 import torch
 from torch import nn
