@@ -712,8 +712,13 @@ __device__ __forceinline__ void store3b_part(uint16_t* __restrict__ Thi, uint16_
         const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
         const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
         const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
-        const int row = prow2(4 * mb + part);
-        const int off = row * 32 + 8 * swz2(row, kb >> 1) + 4 * (kb & 1);
+        // offset of part 0; the other three follow from it by one xor-add (prow2 puts bit 0 of the part into row bit 2, which
+        // is also the low bit of the row's swizzle key).  Kept opaque so that ONE offset register lives across the K loop:
+        // hoisted as four, the fourth was spilled in the persistent NN kernel and its reload (a scratch load, in order
+        // behind the tile prefetch) made every K tile wait for all loads in flight.
+        int base = ((mb >> 1) * 8 + (mb & 1)) * 32 + 4 * (kb & 1) + 8 * ((kb >> 1) ^ (((mb >> 1) & 1) * 2));
+        asm volatile("" : "+v"(base));
+        const int off = (base ^ (8 * (part & 1))) + 128 * (part & 1) + 64 * (part >> 1);
         uint2 hi, lo;
         split4(f0[part], f1[part], f2[part], f3[part], hi, lo);
         *reinterpret_cast<uint2*>(Thi + off) = hi;
@@ -936,10 +941,15 @@ template <bool TA, bool TB>
 int launch_gemm3b(GemmArgs g, int ns, hipStream_t st) {
     const size_t shm = (size_t)2 * 4 * PL2 * sizeof(uint16_t);
     g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
-    if constexpr (!TA && TB) {      // NT only: measured -6 % at K = 256, -2 % at K = 2048; the NN form got SLOWER (K = 2048: +20 %)
+    if constexpr (!TA) {
+        // measured: NT -6 % at K = 256, -2 % at K = 2048.  NN (RLT_GEMM_PERSIST_NN=1): -7 % / -2 % alone with a bias epilogue
+        // - once its K loop no longer reloaded a spilled LDS offset (store3b_part: a scratch load in order behind the tile
+        // prefetch had cost +20 %) - but the training step, whose dX products accumulate in place, is 0.4 ms slower with it
         static const int persist_wgs = [] { const char* e = getenv("RLT_GEMM_PERSIST"); return e ? atoi(e) : 256; }();   // 0: off
+        static const int persist_nn = [] { const char* e = getenv("RLT_GEMM_PERSIST_NN"); return e ? atoi(e) : 0; }();
         const long long tiles = (long long)g.tiles_m * g.tiles_n;
-        if (persist_wgs > 0 && ns == 1 && g.K / BK3 >= 2 && tiles > persist_wgs && persist_wgs % 8 == 0) {
+        const bool want = TB || (persist_nn && !g.bits_in);
+        if (want && persist_wgs > 0 && ns == 1 && g.K / BK3 >= 2 && tiles > persist_wgs && persist_wgs % 8 == 0) {
             int rc = rlt_allow_lds(gemm3b_kernel<TA, TB, true>, shm);
             if (rc) return rc;
             hipLaunchKernelGGL((gemm3b_kernel<TA, TB, true>), dim3(persist_wgs), dim3(512), shm, st, g);
