@@ -267,6 +267,9 @@ int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* 
 /* keep-mask of the attention-probability dropout as data (tests, small B): out (S,H,B,B) =
  * keep ? 1/(1-p) : 0 for (position, head, query, key) */
 int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, float* out, void* stream);
+/* the same for the (position, head) pairs pair0 .. pair0 + npair - 1 only, pair = position * H + head: out (npair,B,B)
+ * (tests at benchmark sizes, where the whole (S,H,B,B) mask would not fit) */
+int rlt_attention_dropout_mask_range(uint32_t seed, int pair0, int npair, int B, float p, float* out, void* stream);
 
 /* ------------------------------------------------------------------ BiLSTM recurrence (M2)
  * One bidirectional LSTM layer with hidden size 128 (nn.LSTM(..., hidden_size=128,

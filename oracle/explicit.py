@@ -55,9 +55,10 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return (x - mu) / torch.sqrt(var + eps) * weight + bias
 
 
-def list_axis_attention(x, in_w, in_b, out_w, out_b, n_head):
+def list_axis_attention(x, in_w, in_b, out_w, out_b, n_head, prob_mask=None):
     """Multi-head self-attention over axis 0 of x (B,S,E): at each position s and head h the
-    B lists attend to each other; scores scaled by 1/sqrt(E/n_head)."""
+    B lists attend to each other; scores scaled by 1/sqrt(E/n_head).  `prob_mask` (S,head,B,B): train-mode dropout
+    of the attention probabilities as data - keep ? 1/(1-p) : 0, multiplied onto softmax(score) like F.dropout does."""
     n_list, n_pos, emb = x.shape
     hd = emb // n_head
     qkv = x @ in_w.t() + in_b                                # (B,S,3E)
@@ -66,25 +67,40 @@ def list_axis_attention(x, in_w, in_b, out_w, out_b, n_head):
     shape = lambda t: t.reshape(n_list, n_pos, n_head, hd).permute(1, 2, 0, 3)
     q, k, v = shape(q), shape(k), shape(v)
     score = (q @ k.transpose(-1, -2)) / math.sqrt(hd)        # (S,head,B,B)
-    ctx = torch.softmax(score, dim=-1) @ v                   # (S,head,B,hd)
+    prob = torch.softmax(score, dim=-1)
+    if prob_mask is not None:
+        prob = prob * prob_mask
+    ctx = prob @ v                                           # (S,head,B,hd)
     ctx = ctx.permute(2, 0, 1, 3).reshape(n_list, n_pos, emb)
     return ctx @ out_w.t() + out_b
 
 
-def encoder_layer(x, sd, prefix, n_head, relu_gate=None):
-    """Post-norm encoder layer (dropout 0) from a `TransformerEncoderLayer` state_dict.
+def encoder_layer(x, sd, prefix, n_head, relu_gate=None, masks=None):
+    """Post-norm encoder layer from a `TransformerEncoderLayer` state_dict; dropout 0 unless `masks` is given.
+
+    `masks` (tests only): the four train-mode dropouts of nn.TransformerEncoderLayer with their keep-masks as DATA
+    (keep ? 1/(1-p) : 0): "attn" (S,head,B,B) on the attention probabilities, "res1" (B,S,E) = dropout1 on the attention
+    branch, "ffn" (B,S,FF) on the ReLU output, "res2" (B,S,E) = dropout2 on the FFN branch.  CPU-torch's RNG stream cannot
+    be reproduced on the device, so train-mode parity is defined on identical masks.
 
     `relu_gate(z) -> 0/1 tensor` (tests only) replaces the ReLU's own branch decision `z > 0`: ReLU is discontinuous in
     its derivative, so a unit whose pre-activation lies within rounding distance of zero may legitimately take either
     branch in two implementations; a test that wants to bound everything ELSE passes the other implementation's
     decisions for exactly those units (and counts them)."""
     g = lambda name: sd[prefix + name].to(x.dtype)
+    m = masks or {}
     att = list_axis_attention(x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"),
-                              g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_head)
+                              g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_head, m.get("attn"))
+    if "res1" in m:
+        att = att * m["res1"]
     x = layer_norm(x + att, g("norm1.weight"), g("norm1.bias"))
     z = x @ g("linear1.weight").t() + g("linear1.bias")
     hid = torch.relu(z) if relu_gate is None else z * relu_gate(z.detach())
+    if "ffn" in m:
+        hid = hid * m["ffn"]
     ff = hid @ g("linear2.weight").t() + g("linear2.bias")
+    if "res2" in m:
+        ff = ff * m["res2"]
     return layer_norm(x + ff, g("norm2.weight"), g("norm2.bias"))
 
 

@@ -476,11 +476,11 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint32_t seed, size_t
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         out[i] = rlt_keep(seed, (uint32_t)(i / cols), (uint32_t)(i % cols), thr) ? 1.f / (1.f - p) : 0.f;
 }
-__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, int npair, int B, float p, float* out) {
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, int pair0, int npair, int B, float p, float* out) {
     const uint32_t thr = rlt_drop_threshold(p);
     const size_t bb = (size_t)B * B, n = (size_t)npair * bb;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int pair = (int)(i / bb);
+        const int pair = pair0 + (int)(i / bb);
         const size_t rem = i % bb;
         out[i] = rlt_keep(pair_seed(seed, pair), (uint32_t)(rem / B), (uint32_t)(rem % B), thr) ? 1.f / (1.f - p) : 0.f;
     }
@@ -512,7 +512,13 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
 
 int rlt_attention_dropout_mask(uint32_t seed, int S, int B, int H, float p, float* out, void* stream) {
     RLT_CHECK_ARG(out && S > 0 && B > 0 && H > 0 && p >= 0.f && p < 1.f);
-    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(1024), dim3(256), 0, rlt_stream(stream), seed, S * H, B, p, out);
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(1024), dim3(256), 0, rlt_stream(stream), seed, 0, S * H, B, p, out);
+    return RLT_LAUNCH_RESULT();
+}
+
+int rlt_attention_dropout_mask_range(uint32_t seed, int pair0, int npair, int B, float p, float* out, void* stream) {
+    RLT_CHECK_ARG(out && pair0 >= 0 && npair > 0 && B > 0 && p >= 0.f && p < 1.f);
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(1024), dim3(256), 0, rlt_stream(stream), seed, pair0, npair, B, p, out);
     return RLT_LAUNCH_RESULT();
 }
 

@@ -14,6 +14,18 @@
 //  * fp32 -> (hi, lo) splitting happens once per workgroup per tile, at staging time (4x4 register transpose
 //    for the transposed image), not per MFMA.
 #include "attention_common.h"
+
+// One LDS-DMA piece as inline assembly: M0 carries the LDS destination.  hipcc treats M0 as a reserved register (a
+// clobber on it is rejected with a warning and ignored), so the statement saves and restores it: whatever the compiler
+// keeps in M0 around the asm (its own global_load_lds builtins in a mixed instantiation, movrel / readlane lowerings)
+// survives.  Two scalar moves per piece, ~5 pieces per wavefront and tile.
+#define RLT_DMA_ASM(dst, src)                                                                                         \
+    do {                                                                                                              \
+        uint32_t m0_keep_;                                                                                            \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(m0_keep_) : "s"(dst), "v"(src) : "memory");                                              \
+    } while (0)
+
 #include <stdlib.h>
 
 namespace {
@@ -334,7 +346,7 @@ __device__ __forceinline__ void dma_copy(uint8_t* lds_dst, const uint8_t* __rest
             if constexpr (ASM) {
                 const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
                 const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+                RLT_DMA_ASM(dst, src);
             } else {
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc + chunk * 1024 + lane * 16),
                                                  (void __attribute__((address_space(3)))*)(lds_dst + chunk * 1024), 16, 0, 0);
@@ -350,7 +362,7 @@ __device__ __forceinline__ void dma_piece(uint8_t* lds_dst, const uint8_t* __res
     if (chunk < NBYTES / 1024) {
         const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
         const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+        RLT_DMA_ASM(dst, src);
     }
 }
 
@@ -361,7 +373,7 @@ __device__ __forceinline__ void dma_piece_clamped(uint8_t* lds_dst, const uint8_
     const int chunk = min(wv + 8 * c, NBYTES / 1024 - 1);
     const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(lds_dst + chunk * 1024);
     const uint8_t* src = gsrc + chunk * 1024 + lane * 16;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+    RLT_DMA_ASM(dst, src);
 }
 
 // Register fragments fetched from HBM before the tile loop must have ARRIVED before the loop: an empty asm statement
@@ -744,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void attn3_bwd_dq_kernel(Attn3Args g) {
         const int ch = isk ? id : id - NR;
         const uint8_t* src = (isk ? nk : nv) + ch * 1024 + lane * 16;
         const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)nl + (isk ? 0 : KREC) + ch * 1024;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+        RLT_DMA_ASM(dst, src);
     };
     issue(0, 0);
     dma_wait_barrier<asm_dma<HD>()>();
@@ -987,7 +999,7 @@ __global__ __launch_bounds__(512) void attn3_bwd_dkv_kernel(Attn3Args g) {
         const int ch = isq ? id : id - NR;
         const uint8_t* src = (isq ? nq : nd) + (isaux ? QREC : ch * 1024) + lane * 16;
         const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)nl + (isq ? 0 : QREC) + (isaux ? QREC : ch * 1024);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+        RLT_DMA_ASM(dst, src);
     };
     issue(0, 0);
     dma_wait_barrier<asm_dma<HD>()>();

@@ -27,6 +27,19 @@ constexpr int LISTS_PER_WG = 4;
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }   // ln x
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); } // e^x
+// v_log_f32 / v_rcp_f32 read a denormal input as zero (log -> -inf, rcp -> inf) where the reference's logf / division give
+// finite values (ln 1e-40 = -92.1).  The cut distribution p can underflow into that range (a softmax over 300 logits), so
+// the terms in p scale a denormal argument into the normal range first; an exact 0 still gives -inf / inf as in torch.
+__device__ __forceinline__ float safe_log(float x) {
+    const bool den = x < 1.17549435e-38f;
+    return (__builtin_amdgcn_logf(den ? x * 4294967296.f : x) - (den ? 32.f : 0.f)) * 0.6931471805599453f;
+}
+// num / x: 1 / x alone overflows for x < 2.9e-39 where the quotient the reference forms, (-q / B) / p, is still finite
+__device__ __forceinline__ float safe_div(float num, float x) {
+    const bool den = x < 1.17549435e-38f;
+    const float t = num * __builtin_amdgcn_rcpf(den ? x * 4294967296.f : x);
+    return den ? t * 4294967296.f : t;
+}
 
 // (value, index) argmax over the wavefront, first maximum: the wave maximum by DPP, then the smallest index among the
 // lanes that hold it (each lane brings the first maximum of its own positions)
@@ -187,24 +200,24 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
                 float term, g;
                 if (a.kind == RLT_LOSS_EXPECT) {            // utils/losses.py:67-68
                     term = -(p * r);
-                    g = -r;
+                    g = -r * a.gscale;
                 } else if (a.kind == RLT_LOSS_CE) {          // utils/losses.py:94-96
-                    term = -(fast_log(p) * q);
-                    g = -q * fast_rcp(p);
+                    term = -(safe_log(p) * q);
+                    g = safe_div(-q * a.gscale, p);
                 } else if (a.kind == RLT_LOSS_KL) {          // utils/losses.py:230, kl_div(log p, q)
                     const float qlq = (q > 0.f) ? q * fast_log(q) : 0.f;
-                    term = qlq - q * fast_log(p);
-                    g = -q * fast_rcp(p);
+                    term = qlq - q * safe_log(p);
+                    g = safe_div(-q * a.gscale, p);
                 } else {                                     // utils/losses.py:232-233, JS
                     const float lm = fast_log((p + q) * 0.5f);
-                    const float lp_ = fast_log(p);
+                    const float lp_ = safe_log(p);
                     const float qlq = (q > 0.f) ? q * fast_log(q) : 0.f;
                     const float plp = (p > 0.f) ? p * lp_ : 0.f;
                     term = 0.5f * ((qlq - q * lm) + (plp - p * lm));
-                    g = 0.5f * (lp_ - lm);                   // gradient flows through log m AND the target p
+                    g = 0.5f * (lp_ - lm) * a.gscale;        // gradient flows through log m AND the target p
                 }
                 part += term;
-                dpv[i] = g * a.gscale;
+                dpv[i] = g;
             }
             const float tot = wave_sum(part);
             if (lane == 0 && a.loss_per_list) a.loss_per_list[b] = tot;
@@ -411,13 +424,15 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
 #pragma unroll
             for (int n = 0; n < N; ++n) {
                 const float qlq = (kl && q[n] > 0.f) ? q[n] * fast_log(q[n]) : 0.f;
-                part += qlq - q[n] * fast_log(p[n]);
-                dpv[n] = -q[n] * fast_rcp(p[n]) * a.gscale;
+                part += qlq - q[n] * safe_log(p[n]);
+                dpv[n] = safe_div(-q[n] * a.gscale, p[n]);
             }
         } else {
             // utils/losses.py:232-233, JS: (q ln(q/m) + p ln(p/m)) / 2 with m = (p + q) / 2.  In log2 units, with
             // s = p + q: q (log2 q - log2 s) + p (log2 p - log2 s) + s per position, scaled by ln 2 / 2 once per list;
-            // log2 of max(x, 2^-126): x = 0 contributes 0 (0 * finite), as the reference's 0 log 0 = 0.
+            // log2 of max(x, 2^-126): x = 0 contributes 0 (0 * finite), as the reference's 0 log 0 = 0.  (A denormal p
+            // also reads as 2^-126 here: its loss term is exact to 1e-36, its gradient (ln p - ln m) / 2 saturates at
+            // ln 2^-126 = -87.3 where the reference has up to -103; the general pass above has the exact form.)
             // d/dp = (ln p - ln m) / 2: the gradient flows through log m AND the target p
             const float cg = 0.5f * 0.6931471805599453f * a.gscale;
 #pragma unroll

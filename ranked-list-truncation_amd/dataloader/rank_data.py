@@ -79,10 +79,20 @@ class RankData:
             stats = _load(os.path.join(base, stats_dir, f"{dataset_name}_{split}.pkl")) if with_stats else None
             self.buckets[split] = {s: (_pin(torch.from_numpy(x)), _pin(torch.from_numpy(y)), qids)
                                    for s, (x, y, qids) in sorted(_pack(raw, stats, gt).items())}
+        # one feature width for every bucket of both splits (the statistics width is inferred per bucket from its first
+        # query): a model is built for ONE input size, so a mismatch is a data error - say so at load time
+        widths = {(split, s): b[0].shape[2] for split, bs in self.buckets.items() for s, b in bs.items()}
+        if len(set(widths.values())) > 1:
+            raise ValueError(f"feature width differs between length buckets / splits: {widths}")
 
     @property
     def lengths(self):
+        """List lengths of the TRAIN split (what the model is built for); `test_lengths` for the test split."""
         return sorted(self.buckets["train"])
+
+    @property
+    def test_lengths(self):
+        return sorted(self.buckets["test"])
 
     @property
     def n_features(self):

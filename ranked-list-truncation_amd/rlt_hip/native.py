@@ -54,6 +54,7 @@ _SIGNATURES = {
                             P, c_float, c_uint32, P, c_size_t, P]),
     "rlt_dropout_mask": (c_int, [c_uint32, c_size_t, c_int, c_float, P, P]),
     "rlt_attention_dropout_mask": (c_int, [c_uint32, c_int, c_int, c_int, c_float, P, P]),
+    "rlt_attention_dropout_mask_range": (c_int, [c_uint32, c_int, c_int, c_int, c_float, P, P]),
     "rlt_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rlt_colsum": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rlt_segment_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),

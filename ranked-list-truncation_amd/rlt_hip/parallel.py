@@ -13,10 +13,16 @@ buffers, so that zero_grad is one memset, the all-reduce is one collective on on
 `FusedAdam` (torch.optim.Adam semantics: coupled L2, bias correction; run.py:104) is one
 `rlt_adam_step` launch.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import native as N
+
+# RLT_FORCE_DIST=1 (tests / one-GPU rehearsals): run every collective of the step even in a ONE-rank process group, so that
+# the RCCL code path (all-reduce AVG on the flat bucket, parameter broadcast) executes on a one-GPU box.
+FORCE_COLLECTIVES = os.environ.get("RLT_FORCE_DIST") == "1"
 
 
 class FlatModel:
@@ -55,7 +61,7 @@ class FlatModel:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not FORCE_COLLECTIVES:
             return
         if dist.get_backend(group) == "nccl":
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)     # RCCL over xGMI
@@ -64,7 +70,7 @@ class FlatModel:
             self.flat_grad.mul_(1.0 / world)
 
     def broadcast_params(self, src=0, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES):
             dist.broadcast(self.flat_param, src=src, group=group)
 
 

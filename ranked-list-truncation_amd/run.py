@@ -21,6 +21,7 @@ import argparse
 import configparser
 import json
 import logging
+import math
 import os
 import time
 
@@ -35,7 +36,7 @@ from models import AttnCut, BiCut, Choopy, MMOECut, MOECut, MtAttnCut, MtChoopy,
 from utils import losses  # noqa: E402
 from utils.metrics import Metric  # noqa: E402
 from rlt_hip import ops  # noqa: E402
-from rlt_hip.parallel import FlatModel, FusedAdam, shard_bounds  # noqa: E402
+from rlt_hip.parallel import FORCE_COLLECTIVES, FlatModel, FusedAdam, shard_bounds  # noqa: E402
 
 
 class ScalarLog:
@@ -76,6 +77,8 @@ class Trainer:
         self.epochs, self.batch_size = args.epochs, args.batch_size
         self.model_persist, self.save_path, self.model_path = args.model_persist, args.save_path, args.model_path
         self.best_test_f1, self.best_test_dcg = -float('inf'), -float('inf')
+        self.best_epoch = None                  # epoch whose weights were checkpointed (None: no test epoch has run)
+        self.best5_f1 = self.best5_dcg = None
         self.f1_record, self.dcg_record = [], []
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -100,9 +103,12 @@ class Trainer:
         feat = data.n_features
         if len(data.lengths) == 1:
             self.seq_len = data.lengths[0]
-        elif name not in ('bicut', 'attncut', 'mtattncut'):
-            raise ValueError(f"{name} is built for ONE list length; the data holds lengths {data.lengths} "
-                             "(only the BiLSTM models bicut / attncut / mtattncut take length-bucketed batches)")
+        if name not in ('bicut', 'attncut', 'mtattncut') and (len(data.lengths) != 1 or data.test_lengths != data.lengths):
+            # Choopy's position encoding and the MMOE gates are sized by seq_len: a test list of another length would
+            # only fail inside the model at the first test epoch
+            raise ValueError(f"{name} is built for ONE list length; the data holds train lengths {data.lengths} and test "
+                             f"lengths {data.test_lengths} (only the BiLSTM models bicut / attncut / mtattncut take "
+                             "length-bucketed batches)")
         if name == 'bicut':                                                    # run.py:59-64
             self.model = BiCut(input_size=feat, dropout=args.dropout)
             self.criterion = losses.BiCutLoss(metric=args.criterion)
@@ -168,7 +174,7 @@ class Trainer:
         if train:
             self.flat.all_reduce_grads()                        # an empty shard contributes its zeroed bucket
             self.optimizer.step()
-        if self.world > 1:
+        if self.world > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         vals = stats.tolist()                                   # the step's only host sync
         return [v / vals[3] for v in vals[:3]]
@@ -302,7 +308,9 @@ def apply_conf(args):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+    # RLT_FORCE_DIST=1: initialise the process group (and run the step's collectives) even with one rank - the RCCL
+    # rehearsal on a one-GPU box (rlt_hip/parallel.py)
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (FORCE_COLLECTIVES and "RANK" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("RLT_DIST_BACKEND", "nccl")
         if backend == "nccl":
@@ -328,8 +336,9 @@ def main(argv=None):
     result = trainer.run()
     if args.history_json and trainer.rank == 0:
         with open(args.history_json, "w") as f:
-            json.dump({"history": trainer.history, "best_f1": trainer.best_test_f1, "best_dcg": trainer.best_test_dcg,
-                       "best5_f1": trainer.best5_f1, "best5_dcg": trainer.best5_dcg, "best_epoch": trainer.best_epoch,
+            fin = lambda v: v if v is not None and math.isfinite(v) else None     # -inf (no test epoch) is not valid JSON
+            json.dump({"history": trainer.history, "best_f1": fin(trainer.best_test_f1), "best_dcg": fin(trainer.best_test_dcg),
+                       "best5_f1": fin(trainer.best5_f1), "best5_dcg": fin(trainer.best5_dcg), "best_epoch": trainer.best_epoch,
                        "world": trainer.world}, f)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -3,6 +3,7 @@ tensors as the reference's own loaders did on the same files (golden fixture: to
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import golden_util as gu
@@ -88,3 +89,38 @@ def test_shard_bounds_partition():
                 assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
                 cover.extend(range(lo, hi))
             assert cover == list(range(n))
+
+
+def test_feature_width_mismatch_is_reported_at_load(tmp_path):
+    """Buckets / splits whose statistics widths differ cannot feed one model: RankData says so when the files are read
+    (the width is inferred per bucket from its first query)."""
+    import pickle
+    from dataloader import RankData
+    from dataloader.synth import write_synthetic_robust04
+    root = write_synthetic_robust04(str(tmp_path), "robust04", "drmm_tks", n_train=6, n_test=4, seq_len=30, seed=1)
+    path = os.path.join(root, "attncut", "drmm_tks_test.pkl")
+    with open(path, "rb") as f:
+        stats = pickle.load(f)
+    stats = {q: [row + [0.5] for row in rows] for q, rows in stats.items()}       # the test split gets a third statistic
+    with open(path, "wb") as f:
+        pickle.dump(stats, f)
+    with pytest.raises(ValueError, match="feature width differs"):
+        RankData("robust04", "drmm_tks", True, str(tmp_path))
+
+
+def test_test_split_lengths_are_exposed(tmp_path):
+    """run.py refuses single-length models (Choopy, MMOECut) when the test split holds a length the train split lacks;
+    RankData exposes both."""
+    import pickle
+    from dataloader import RankData
+    from dataloader.synth import write_synthetic_robust04
+    root = write_synthetic_robust04(str(tmp_path), "robust04", "drmm_tks", n_train=4, n_test=3, seq_len=30, seed=2)
+    path = os.path.join(root, "drmm_tks_test.pkl")
+    with open(path, "rb") as f:
+        raw = pickle.load(f)
+    q0 = next(iter(raw))
+    raw[q0] = dict(list(raw[q0].items())[:20])                                     # one test list is shorter
+    with open(path, "wb") as f:
+        pickle.dump(raw, f)
+    data = RankData("robust04", "drmm_tks", False, str(tmp_path))
+    assert data.lengths == [30] and data.test_lengths == [20, 30]

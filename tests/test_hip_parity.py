@@ -26,12 +26,23 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
                 BiLSTM at B=4096, LayerNorm at 1,228,800 rows
     full_size_kernels  BiLSTM 4096x300 and encoder layers 4096x300 (E256/H4), 8192x300 (E128/H8) at full size against
                 list-/position-subset references with sparse upstream gradients
+    scale_dropout  the TRAIN-MODE kernel variants at benchmark shapes: list attention with probability dropout at B=4096
+                (hd 64, p 0.4) / 8192 (hd 16, p 0.2) fwd + dQ/dK/dV vs fp64 on the exported masks, the FFN-hidden dropout
+                epilogue of rlt_gemm_bits and add_ln with branch dropout at 1,228,800 rows, full-size encoder layers in
+                train mode (4096x300 p 0.4, 8192x300 p 0.2) vs position-subset fp64 references with all four masks
     flip_aligned_grads  whole-model gradients vs the oracle with knife-edge ReLU units following the device's branch
                 (counted): per-parameter rel-L2 1e-4 (fp32 mode) / 1e-3 (bf16x3)
     trainer_bookkeeping  run.py's Trainer vs the same loop on the oracle: per-epoch means, best / best-5, checkpointed
                 epoch and weights, scalar log
+    trainer_buckets  run.py's Trainer on lists of 100 / 200 / 300 documents (length-bucketed batches, BASELINE configs[4]'s
+                shape) vs the oracle loop over the same BatchLoader schedule: per-epoch means
+    scale_mmoe  MMOE gates (K = 76,800) / mixture fwd+bwd at 2048 x 300 vs fp64, MtCutLoss terms at 4096 x 300 vs the oracle,
+                the whole MMOECut(4 experts, tasks 2.1) at 1024 x 300 vs the oracle module in fp64 on the device
     path_level  rlt_encoder_layer_fwd/bwd (composed in the library) == the same launches driven from the host, bit for bit
     trainer_dp  run.py with two ranks on this GPU (gloo rehearsal) vs the shard-wise oracle: ragged and empty shards
+    rccl_one_rank  bench.py and run.py as children of torch.distributed.run with ONE rank over RCCL (RLT_FORCE_DIST=1):
+                init_process_group("nccl", device_id), broadcast, all-reduce(AVG) of the flat bucket, NCCL barrier execute;
+                results equal the run without a process group
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
     models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
@@ -59,8 +70,8 @@ def probe():
 
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
-                  "scale_models", "scale_ops", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "path_level", "lstm_generic", "trainer_dp"]
-MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe"]
+                  "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
+MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank"]
 
 
 def _run(probe, name):

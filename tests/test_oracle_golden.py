@@ -224,3 +224,47 @@ def test_dcg_penalty_argument_against_reference():
         assert float((ol.reward_matrix(rows, "dcg", pen) - want).abs().max()) < 4e-5
         loop = torch.stack([torch.stack([ol.reward_dcg(r, j + 1, pen) for j in range(0, 300, 37)]) for r in rows])
         assert float((loop - want[:, 0:300:37]).abs().max()) < 1e-6
+
+
+def test_explicit_encoder_layer_dropout_masks_match_the_stock_module(monkeypatch):
+    """oracle/explicit.py's encoder layer with the four train-mode dropouts given as keep-masks (the reference for the
+    GPU's dropout tests, where the device's own masks are exported as data) against the STOCK nn.TransformerEncoderLayer
+    in train() with torch's dropouts replaced by those same masks: dropout1 / dropout / dropout2 are the module's own
+    nn.Dropout children (swapped for mask multipliers), the attention-probability dropout is F.dropout inside
+    F.multi_head_attention_forward's need_weights path (patched to multiply by the mask)."""
+    import torch.nn.functional as F
+    torch.manual_seed(7)
+    B, S, E, H, FF, p = 9, 4, 32, 4, 64, 0.3
+    layer = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dim_feedforward=FF, dropout=p).double()
+    layer.train()
+    keep = lambda *shape: (torch.rand(*shape) >= p).double() / (1 - p)
+    masks = {"attn": keep(S, H, B, B), "res1": keep(B, S, E), "ffn": keep(B, S, FF), "res2": keep(B, S, E)}
+
+    class Mask(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            return x * self.m
+
+    layer.dropout1, layer.dropout, layer.dropout2 = Mask(masks["res1"]), Mask(masks["ffn"]), Mask(masks["res2"])
+    # the attention weights F.dropout sees are (S*H, B, B) in (position, head) order
+    monkeypatch.setattr(F, "dropout", lambda w, p=0.5, training=True, inplace=False: w * masks["attn"].reshape(w.shape))
+    x = torch.randn(B, S, E, dtype=torch.float64, requires_grad=True)
+    # need_weights=True takes the explicit softmax -> dropout -> bmm path (the SDPA path draws its own mask internally)
+    att = layer.self_attn(x, x, x, need_weights=True)[0]
+    want = layer.norm1(x + layer.dropout1(att))
+    want = layer.norm2(want + layer.dropout2(layer.linear2(layer.dropout(torch.relu(layer.linear1(want))))))
+    monkeypatch.undo()
+    x2 = x.detach().clone().requires_grad_(True)
+    got = explicit.encoder_layer(x2, layer.state_dict(), "", H, masks=masks)
+    assert float((got - want).abs().max()) < 1e-12
+    g = torch.randn(B, S, E, dtype=torch.float64)
+    want.backward(g)
+    got.backward(g)
+    assert float((x2.grad - x.grad).abs().max()) < 1e-11
+    # and without masks it is the eval() / dropout-0 layer
+    layer2 = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dim_feedforward=FF, dropout=0.0).double()
+    layer2.load_state_dict({k: v for k, v in layer.state_dict().items()})
+    assert float((explicit.encoder_layer(x, layer.state_dict(), "", H) - layer2(x)).abs().max()) < 1e-12

@@ -207,6 +207,33 @@ def losses():
             report(f"k    {cname} S={S}", float((kh.cpu().numpy() != ko).sum()), 0)
             report(f"F1, DCG {cname} S={S}", max(abs(float(f1h) - om.Metric.f1(yy.numpy(), ko)),
                                                  abs(float(dcgh) - om.Metric.dcg(yy.numpy(), ko))), 1e-12)
+    # cut probabilities underflowed into the denormal range: v_log_f32 / v_rcp_f32 read them as zero; the CE /
+    # KL terms and the general pass scale them into the normal range first.  S = 300: two-lists-per-wavefront pass,
+    # S = 301: general pass.  (The fast JS pass clamps at 2^-126 instead: its loss is exact, its gradient saturates.)
+    for S in (300, 301):
+        g = torch.Generator().manual_seed(S)
+        yy = (torch.rand(6, S, generator=g) < 0.2).float()
+        pp = torch.softmax(torch.randn(6, S, generator=g) * 2, 1)
+        pp[:, 5::37] = torch.tensor([1e-39, 3e-41, 1e-44, 5e-40, 2e-38, 1e-42])[:, None]
+        pp = pp.unsqueeze(2)
+        for cname in ("attncutloss_f1", "div_kl_dcg_aug0", "div_kl_f1_aug1") + (("div_js_f1_aug1",) if S == 301 else ()):
+            if cname.startswith("div_js"):
+                # torch's own fp32 backward of the JS terms (x/y pieces of xlogy with a 3-bit denormal p) is off by 1e-2 from
+                # the exact (ln p - ln m) / 2 at p = 1e-44; keep >= 13 significant bits so that the reference is a reference
+                pp = pp.clone()
+                pp[2, 5::37] = 4e-41
+                pp[5, 5::37] = 7e-40
+            pr = pp.clone().requires_grad_(True)
+            lr = make_criterion(ol, cname)(pr, yy)
+            lr.backward()
+            pg = pp.clone().to(dev).requires_grad_(True)
+            lh = make_criterion(hl, cname)(pg, yy.to(dev))
+            lh.backward()
+            report(f"denormal p: loss {cname} S={S}", abs(lh.item() - lr.item()) / max(1, abs(lr.item())), 2e-5)
+            fin = torch.isfinite(pr.grad)
+            # per entry: 1e-4 of its own size (the denormal positions carry gradients up to 1e36) or 1e-6 absolute
+            report(f"denormal p: dp {cname} S={S} (finite entries)", float(((pg.grad.cpu() - pr.grad)[fin].abs() / (pr.grad[fin].abs() + 1e-2)).max()), 1e-4)
+            report(f"denormal p: dp {cname} S={S} (same infinities)", float((torch.isfinite(pg.grad.cpu()) != fin).sum()), 0)
     # multi-task
     for tag, nt in (("t3", 3), ("t21", 2.1), ("t22", 2.2)):
         for metric in ("f1", "dcg"):
@@ -744,6 +771,7 @@ def _param_rel_l2(hip, ref):
     out = {}
     for n, a in hip.named_parameters():
         g = refs[n].grad if refs[n].grad is not None else torch.zeros_like(refs[n])    # parameter not on the loss's path
+        g = g.detach().cpu()                         # (the oracle module may have run in fp64 on the device)
         mine = a.grad.detach().cpu().double() if a.grad is not None else torch.zeros_like(g).double()
         out[n] = float((mine - g.double()).norm()) / max(float(g.norm()), 1e-3 * top)
     return out
@@ -762,7 +790,10 @@ SCALE_MODEL_CASES = [
 def scale_models():
     """Whole models at benchmark batch sizes against the CPU oracle (stock torch-CPU modules): outputs 1e-4 (the bound
     BASELINE.json states; observed ~1e-6), identical cut positions except lists whose two best positions are closer
-    than 4e-6 in the oracle's own output (reported), loss 1e-4, per-parameter gradient relative L2 (bound below)."""
+    than 4e-6 in the oracle's own output (reported), loss 1e-4, and per-parameter gradient relative L2 within
+    1e-3 (bf16x3) / 2e-4 (exact fp32) of the oracle's - about 10x what is observed - with the oracle's encoder layers
+    following the device's ReLU branch on the (counted) knife-edge units (flip_aligned_grads explains why); the
+    un-aligned figure is printed beside it."""
     import models as hm
     from oracle import losses as ol, metrics as omet, models as om
     from oracle.cases import make_criterion
@@ -770,7 +801,9 @@ def scale_models():
     from utils import losses as hl
     from utils.metrics import Metric
     only = os.environ.get("PROBE_CASES")
-    grad_tol = 3e-2 if N.get_precision() == "bf16x3" else 5e-3
+    bf = N.get_precision() == "bf16x3"
+    grad_tol = 1e-3 if bf else 2e-4
+    edge = 3e-4 if bf else 4e-6
     for tag, cls, kw, B, S, F_, cname in SCALE_MODEL_CASES:
         if only and tag not in only.split(","):
             continue
@@ -783,21 +816,35 @@ def scale_models():
         hip = hip.to(dev)
         x, y = synthetic_lists(B, S, F_, 901 + S)
         ref.train(), hip.train()
-        out_r = ref(x)
-        loss_r = make_criterion(ol, cname, case)(out_r, y)
-        loss_r.backward()
-        t_cpu = time.time() - t0
         out_h = hip(x.to(dev))
+        outs_h = list(out_h) if isinstance(out_h, (list, tuple)) else [out_h]
+        nodes = _encoder_nodes(outs_h)                   # the device's ReLU decisions, before backward frees the stash
         loss_h = make_criterion(hl, cname, case)(out_h, y.to(dev))
         loss_h.backward()
-        outs_r = out_r if isinstance(out_r, (list, tuple)) else [out_r]
-        outs_h = out_h if isinstance(out_h, (list, tuple)) else [out_h]
+        # un-aligned oracle first: its outputs, loss and cut positions are THE reference; its gradients the printed
+        # diagnostic (bf16x3 mode only: the second oracle backward doubles the CPU time of the section)
+        plain = None
+        if bf:
+            out_r = ref(x)
+            loss_r = make_criterion(ol, cname, case)(out_r, y)
+            loss_r.backward()
+            plain = _param_rel_l2(hip, ref)
+            ref.zero_grad()
+        else:
+            with torch.no_grad():
+                out_r = ref(x)
+                loss_r = make_criterion(ol, cname, case)(out_r, y)
+        outs_r = list(out_r) if isinstance(out_r, (list, tuple)) else [out_r]
+        outs_r = [o.detach() for o in outs_r]
+        counts = _align_relu(ref, hip, nodes, B, S, edge)
+        make_criterion(ol, cname, case)(ref(x), y).backward()
+        t_cpu = time.time() - t0
         for i, (a, b) in enumerate(zip(outs_h, outs_r)):
-            scale = max(1.0, float(b.detach().abs().max()))
-            report(f"{tag} out{i} max|d|", float((a.detach().cpu() - b.detach()).abs().max()) / scale, 1e-4)
+            scale = max(1.0, float(b.abs().max()))
+            report(f"{tag} out{i} max|d|", float((a.detach().cpu() - b).abs().max()) / scale, 1e-4)
             # relative to the values themselves (p ~ 1/S): the bound a wrong tile would break by orders of magnitude
             report(f"{tag} out{i} rel", rel(a, b), 2e-4)
-        p_r = outs_r[-1].detach().squeeze(2)
+        p_r = outs_r[-1].squeeze(2)
         k_r = omet.cut_positions(p_r.numpy())
         k_h, f1_h, dcg_h = Metric.evaluate(outs_h[-1], y.to(dev))
         k_h = k_h.cpu().numpy()
@@ -810,13 +857,18 @@ def scale_models():
         report(f"{tag} DCG", abs(float(dcg_h) - omet.Metric.dcg(y.numpy(), k_h)), 1e-6)
         report(f"{tag} F1 vs oracle k", abs(float(f1_h) - omet.Metric.f1(y.numpy(), k_r)), 1e-4)
         report(f"{tag} loss", abs(float(loss_h) - float(loss_r)) / max(1.0, abs(float(loss_r))), 1e-4)
+        report(f"{tag} ReLU decisions differing outside |z| < {edge:g}", float(counts[1]), 0)
         errs = _param_rel_l2(hip, ref)
         worst = max(errs, key=errs.get)
-        report(f"{tag} grad rel-L2 worst ({worst})", errs[worst], grad_tol)
+        report(f"{tag} grad rel-L2 worst, flip-aligned ({worst})", errs[worst], grad_tol)
         med = sorted(errs.values())[len(errs) // 2]
-        report(f"{tag} grad rel-L2 median", med, grad_tol / 10)
-        print(f"   ({tag}: oracle {t_cpu:.1f}s, total {time.time() - t0:.1f}s)", flush=True)
-        del hip, out_h, loss_h
+        report(f"{tag} grad rel-L2 median, flip-aligned", med, grad_tol / 5)
+        diag = ""
+        if plain is not None:
+            wp = max(plain, key=plain.get)
+            diag = f"un-aligned worst rel-L2 {plain[wp]:.2e} ({wp}), median {sorted(plain.values())[len(plain) // 2]:.2e}; "
+        print(f"   ({tag}: {counts[0]} of {counts[2]} FFN units aligned; {diag}oracle {t_cpu:.1f}s, total {time.time() - t0:.1f}s)", flush=True)
+        del hip, out_h, loss_h, nodes
         torch.cuda.empty_cache()
 
 
@@ -954,6 +1006,127 @@ def scale_ops():
     report(f"add_ln dgamma {T}x256", rel(gd.grad, dgr), 5e-5)
 
 
+def _attn_mask_pairs(seed, pair0, npair, B, p):
+    """keep-masks (npair,B,B) of the attention-probability dropout for pairs pair0.. (pair = position * H + head)."""
+    mk = torch.empty(npair, B, B, device=dev)
+    N.call("rlt_attention_dropout_mask_range", seed, pair0, npair, B, p, N.ptr(mk), N.stream())
+    return mk
+
+
+@section
+def scale_dropout():
+    """The TRAIN-MODE (dropout > 0) kernel variants at the shapes of the benchmark steps: they are
+    separate instantiations (`attn3_fwd/bwd_dkv/bwd_dq_kernel<.,true>` with their per-tile double-buffered hash tables and
+    the compiler-scheduled tile body, `attn_*_kernel<.,.,true>` in exact-fp32 mode, the dropout epilogue of `rlt_gemm_bits`,
+    `add_ln_*` with the branch dropout).  The reference trains with these rates (hyper_parameter_drmm_tks.conf:41: 0.4;
+    models/Choopy.py:7: 0.2).  References: fp64 on the device with the kernels' own keep-masks exported as data."""
+    # ---- list-axis attention with probability dropout: 16 / 32 key tiles per column, forward + dQ / dK / dV
+    for (B, S, H, HD, p) in [(4096, 2, 4, 64, 0.4), (8192, 2, 8, 16, 0.2)]:
+        E = H * HD
+        seed = 77000 + B
+        g = torch.Generator(device="cpu").manual_seed(B + HD + 1)
+        qkv = torch.randn(B, S, 3 * E, generator=g)
+        dout = torch.randn(B, S, E, generator=g)
+        qd = _pm(qkv).to(dev).requires_grad_(True)
+        od = ops.ListAttentionFn.apply(qd, S, B, H, p, seed)
+        od.backward(_pm(dout).to(dev))
+        o_dev, g_dev = _unpm(od.detach(), B, S), _unpm(qd.grad, B, S)
+        # fp64 reference one (position, head) at a time: a 4096^2 / 8192^2 score matrix and its mask per iteration
+        q64 = qkv.to(dev).double()
+        d64 = dout.to(dev).double()
+        o_ref = torch.empty(B, S, E, dtype=torch.float64, device=dev)
+        g_ref = torch.empty(B, S, 3 * E, dtype=torch.float64, device=dev)
+        keep_sum = 0.0
+        for s_ in range(S):
+            for h in range(H):
+                mk = _attn_mask_pairs(seed, s_ * H + h, 1, B, p)[0].double()
+                keep_sum += float((mk > 0).double().mean())
+                sl = lambda part: slice(part * E + h * HD, part * E + (h + 1) * HD)
+                q, k, v = [q64[:, s_, sl(i)].clone().requires_grad_(True) for i in range(3)]
+                o = ((torch.softmax(q @ k.t() / math.sqrt(HD), -1) * mk) @ v)
+                o.backward(d64[:, s_, h * HD:(h + 1) * HD])
+                o_ref[:, s_, h * HD:(h + 1) * HD] = o.detach()
+                for i, t in enumerate((q, k, v)):
+                    g_ref[:, s_, sl(i)] = t.grad
+                del mk, q, k, v, o
+        report(f"drop attn keep fraction B{B} HD{HD} p{p}", abs(keep_sum / (S * H) - (1 - p)), 2e-3)
+        report(f"drop attn fwd  B{B} S{S} H{H} HD{HD} p{p}", rel(o_dev, o_ref), mfma_tol(1e-5))
+        report(f"drop attn dq   B{B} S{S} H{H} HD{HD} p{p}", rel(g_dev[..., :E], g_ref[..., :E]), mfma_tol(3e-5))
+        report(f"drop attn dk   B{B} S{S} H{H} HD{HD} p{p}", rel(g_dev[..., E:2 * E], g_ref[..., E:2 * E]), mfma_tol(3e-5))
+        report(f"drop attn dv   B{B} S{S} H{H} HD{HD} p{p}", rel(g_dev[..., 2 * E:], g_ref[..., 2 * E:]), mfma_tol(3e-5))
+        del qd, od, q64, d64, o_ref, g_ref, o_dev, g_dev
+        torch.cuda.empty_cache()
+    # ---- FFN hidden dropout fused into the rlt_gemm_bits epilogue at 1,228,800 rows, and the masked dH product
+    T, Fh, E, p, seed = 4096 * 300, 2048, 256, 0.4, 424243
+    gg = torch.Generator(device=dev).manual_seed(6)
+    rn = lambda *s_: torch.randn(*s_, device=dev, generator=gg)
+    A, W, bias = rn(T, E), rn(Fh, E) / 16, rn(Fh) / 10
+    Hd = torch.empty(T, Fh, device=dev)
+    bits = ops.alloc_relu_bits(T, Fh, dev)
+    ops.gemm_bits(0, 1, T, Fh, E, A, E, W, E, Hd, Fh, bias=bias, flags=N.GEMM_RELU, bits_out=bits, drop_p=p, seed=seed)
+    mk = torch.empty(T, Fh, device=dev)
+    N.call("rlt_dropout_mask", seed, T, Fh, p, N.ptr(mk), N.stream())
+    worst, top, badbits, near = 0.0, 0.0, 0, 0
+    for lo, hi in _chunks(T, 65536):
+        z = A[lo:hi].double() @ W.double().t() + bias.double()
+        ref = torch.relu(z) * mk[lo:hi].double()
+        worst = max(worst, float((Hd[lo:hi].double() - ref).abs().max()))
+        top = max(top, float(ref.abs().max()))
+        un = ops.unpack_relu_bits(bits[lo // 32:hi // 32], hi - lo)
+        badbits += int((un != (Hd[lo:hi] > 0)).sum())
+        # the bit must be "passed the ReLU and kept": compare with the fp64 decision away from the knife edge
+        want = (z > 0) & (mk[lo:hi] > 0)
+        near += int(((un != want) & (z.abs() > 1e-4)).sum())
+    report(f"gemm_bits relu+dropout fwd {T}x{Fh}x{E} p{p} (all rows)", worst / top, mfma_tol(1e-5))
+    report(f"gemm_bits relu+dropout bits == (output > 0) {T}x{Fh}", float(badbits), 0)
+    report(f"gemm_bits relu+dropout bits == fp64 (z > 0 and kept) outside |z| < 1e-4", float(near), 0)
+    report(f"gemm_bits dropout keep fraction {T}x{Fh}", abs(float((mk > 0).float().mean()) - (1 - p)), 1e-3)
+    dY, W2 = rn(T, E), rn(E, Fh) / 16
+    dH = torch.empty(T, Fh, device=dev)
+    ops.gemm_bits(0, 0, T, Fh, E, dY, E, W2, Fh, dH, Fh, bits_in=bits, mask_scale=1.0 / (1.0 - p))
+    worst, top = 0.0, 0.0
+    for lo, hi in _chunks(T, 65536):
+        ref = (dY[lo:hi].double() @ W2.double()) * (Hd[lo:hi] > 0) / (1.0 - p)
+        worst = max(worst, float((dH[lo:hi].double() - ref).abs().max()))
+        top = max(top, float(ref.abs().max()))
+    report(f"gemm_bits masked+scaled bwd {T}x{Fh}x{E} p{p} (all rows)", worst / top, mfma_tol(2e-6 * 16 + 1e-6))
+    del A, W, Hd, bits, mk, dY, W2, dH
+    torch.cuda.empty_cache()
+    # ---- residual + LayerNorm with the branch dropout at 1,228,800 rows, forward and backward (every row compared)
+    p, seed = 0.4, 515151
+    x, r, gmm, bt, dy = rn(T, 256), rn(T, 256), rn(256), rn(256), rn(T, 256)
+    xd, rd, gd, bd = [t.clone().requires_grad_(True) for t in (x, r, gmm, bt)]
+    yd = ops.AddLayerNormFn.apply(xd, rd, gd, bd, 1e-5, p, seed)
+    yd.backward(dy)
+    mk = torch.empty(T, 256, device=dev)
+    N.call("rlt_dropout_mask", seed, T, 256, p, N.ptr(mk), N.stream())
+    worst = wdx = wdr = 0.0
+    dgr = torch.zeros(256, dtype=torch.float64, device=dev)
+    dbr = torch.zeros(256, dtype=torch.float64, device=dev)
+    for lo, hi in _chunks(T, 131072):
+        xr = x[lo:hi].double().requires_grad_(True)
+        rr = r[lo:hi].double().requires_grad_(True)
+        gr, br = gmm.double().requires_grad_(True), bt.double().requires_grad_(True)
+        yr = F.layer_norm(xr + rr * mk[lo:hi].double(), (256,), gr, br, 1e-5)
+        yr.backward(dy[lo:hi].double())
+        worst = max(worst, float((yd[lo:hi].double() - yr).abs().max()))
+        wdx = max(wdx, float((xd.grad[lo:hi].double() - xr.grad).abs().max()))
+        wdr = max(wdr, float((rd.grad[lo:hi].double() - rr.grad).abs().max()))
+        dgr += gr.grad
+        dbr += br.grad
+    report(f"drop add_ln fwd {T}x256 p{p} (all rows)", worst, 2e-5)
+    report(f"drop add_ln dx  {T}x256 p{p} (all rows)", wdx, 1e-4)
+    report(f"drop add_ln dr  {T}x256 p{p} (all rows)", wdr, 2e-4)
+    report(f"drop add_ln dgamma {T}x256 p{p}", rel(gd.grad, dgr), 5e-5)
+    report(f"drop add_ln dbeta  {T}x256 p{p}", rel(bd.grad, dbr), 5e-5)
+    del x, r, dy, xd, rd, yd, mk
+    torch.cuda.empty_cache()
+    # ---- whole encoder layers at FULL size in train mode: position-subset fp64 reference with all four masks exported
+    _full_encoder_cases([("attncut 4096x300 E256 H4 dropout 0.4", 4096, 256, 4, None, 0.4, [0, 149, 299]),
+                         ("choopy 8192x300 E128 H8 dropout 0.2", 8192, 128, 8, None, 0.2, [1, 298])], 300)
+
+
+
 def _saved_hidden(y):
     """The FFN hidden activation (T, 2048) the encoder-layer tape node of `y` keeps for its backward."""
     return ops.encoder_ffn_hidden(y)
@@ -1000,20 +1173,32 @@ def full_size_kernels():
     del xd, yd, dh
     torch.cuda.empty_cache()
     # ---- (1b) encoder layers at full size, position subset vs the fp64 restatement
-    for (tag, Bq, E, H, src) in [("attncut 4096x300 E256 H4", 4096, 256, 4, h_full), ("choopy 8192x300 E128 H8", 8192, 128, 8, None)]:
-        if only and tag.split()[0] not in only:
-            continue
+    cases = [("attncut 4096x300 E256 H4", 4096, 256, 4, h_full, 0.0, [0, 1, 149, 299]),
+             ("choopy 8192x300 E128 H8", 8192, 128, 8, None, 0.0, [0, 1, 149, 299])]
+    _full_encoder_cases([c for c in cases if not only or c[0].split()[0] in only], S)
+    del h_full
+
+
+def _full_encoder_cases(cases, S):
+    """Encoder layers at full size against the fp64 restatement (oracle/explicit.py, run on the device) on a SUBSET of
+    positions with a sparse upstream gradient; `p_drop > 0`: train mode, the reference takes the layer's four keep-masks
+    (attention probabilities, both residual branches, FFN hidden) as data from the library's mask exports."""
+    from models._common import ParamTree
+    from oracle import explicit
+    for (tag, Bq, E, H, src, p_drop, pos) in cases:
         T = S * Bq
         torch.manual_seed(11)
-        layer = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dropout=0.0)
+        layer = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dropout=p_drop)
+        FF = layer.linear1.out_features
         pl = ParamTree(layer).to(dev)
         if src is None:
             src = torch.randn(T, E, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
         xin = src.clone().requires_grad_(True)
-        y = ops.encoder_layer(xin, pl, S, Bq, H)
-        pos = [0, 1, 149, 299]
+        torch.manual_seed(12)
+        y = ops.encoder_layer(xin, pl, S, Bq, H, p_drop)
         rows = torch.cat([torch.arange(s * Bq, (s + 1) * Bq, device=dev) for s in pos])
-        hid_dev = _saved_hidden(y)[rows] > 0                       # the device's ReLU decisions on the subset rows
+        hid_dev = _saved_hidden(y)[rows] > 0                       # the device's ReLU (and keep) decisions on the subset rows
+        seeds = y.grad_fn.cfg[7]
         gsub = torch.randn(len(rows), E, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
         dy = torch.zeros(T, E, device=dev)
         dy[rows] = gsub
@@ -1024,18 +1209,32 @@ def full_size_kernels():
         edge = 2e-4 if N.get_precision() == "bf16x3" else 2e-6
         to_bse = lambda t: t.reshape(len(pos), Bq, -1).permute(1, 0, 2)
         gate_dev = to_bse(hid_dev)
+        masks, kept = None, None
+        if p_drop > 0:
+            s_attn, s_ln1, s_ffn, s_ln2 = seeds
+
+            def row_mask(seed, cols):
+                mk = torch.empty(T, cols, device=dev)
+                N.call("rlt_dropout_mask", seed, T, cols, p_drop, N.ptr(mk), N.stream())
+                return to_bse(mk[rows]).double()
+            masks = {"attn": torch.stack([_attn_mask_pairs(s_attn, s * H, H, Bq, p_drop) for s in pos]).double(),
+                     "res1": row_mask(s_ln1, E), "ffn": row_mask(s_ffn, FF), "res2": row_mask(s_ln2, E)}
+            kept = masks["ffn"] > 0
+            for name, mk in masks.items():
+                report(f"full encoder {tag}: keep fraction of the {name} mask", abs(float((mk > 0).double().mean()) - (1 - p_drop)), 3e-3)
         flips = [0, 0]
 
         def gate(z):
             own = z > 0
             near = z.abs() < edge
-            flips[0] += int((near & (own != gate_dev)).sum())
-            flips[1] += int((~near & (own != gate_dev)).sum())
-            return torch.where(near, gate_dev, own).to(z.dtype)
+            dev_dec = gate_dev if kept is None else torch.where(kept, gate_dev, own)    # a dropped unit shows no decision
+            flips[0] += int((near & (own != dev_dec)).sum())
+            flips[1] += int((~near & (own != dev_dec)).sum())
+            return torch.where(near, dev_dec, own).to(z.dtype)
 
         xs = to_bse(src[rows]).double().requires_grad_(True)
         prm64 = {k: v.detach().to(dev).double().requires_grad_(True) for k, v in layer.state_dict().items()}
-        yr = explicit.encoder_layer(xs, prm64, "", H, relu_gate=gate)
+        yr = explicit.encoder_layer(xs, prm64, "", H, relu_gate=gate, masks=masks)
         yr.backward(to_bse(gsub).double())
         report(f"full encoder {tag}: ReLU decisions differing from fp64 outside |z| < {edge:g}", float(flips[1]), 0)
         print(f"   ({tag}: {flips[0]} knife-edge ReLU units of {hid_dev.numel()} follow the device's branch)", flush=True)
@@ -1048,9 +1247,8 @@ def full_size_kernels():
             g64 = prm64[name].grad
             err = float((prm.grad.double() - g64).norm() / g64.norm())
             report(f"full encoder d{name} {tag}", err, mfma_tol(1e-4))
-        del xin, y, dy, xs, yr, prm64, src
+        del xin, y, dy, xs, yr, prm64, src, masks, kept
         torch.cuda.empty_cache()
-    del h_full
 
 
 @section
@@ -1139,6 +1337,7 @@ def _align_relu(ref, hip, nodes, B, S, edge):
         n_layers += 1
 
         def act(z, gate_dev=gate_dev):
+            gate_dev = gate_dev.to(z.device)                 # (the oracle module may run in fp64 on the device)
             own = z.detach() > 0
             near = z.detach().abs() < edge
             counts[0] += int((near & (own != gate_dev)).sum())
@@ -1148,6 +1347,115 @@ def _align_relu(ref, hip, nodes, B, S, edge):
         mod.activation = act
     assert n_layers == len(nodes), (n_layers, len(nodes))
     return counts
+
+
+@section
+def scale_mmoe():
+    """MMOECut (models/MMOECut.py:86-110) and the multi-task criterion at a C4-like per-GPU shape (VERDICT r02 items
+    3b / weak 4): (i) the gate product (B, 76800) @ (76800, n_e), its softmax, the mixture and their gradients at
+    B = 2048 x 300 against fp64 on the device; (ii) RerankLoss / BCE partial sums (rlt_mt_terms) and their gradients at
+    4096 x 300 against the CPU oracle; (iii) the WHOLE model MMOECut(4 experts, tasks 2.1) at 1024 x 300 with MtCutLoss
+    against the oracle MODULE evaluated in float64 on the device (same restatement as the CPU oracle, stock torch
+    modules; the criterion runs on the host on its outputs) - outputs, cut positions, loss, flip-aligned gradients."""
+    import models as hm
+    from oracle import losses as ol, metrics as omet, models as om
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from utils import losses as hl
+    from utils.metrics import Metric
+    # ---- (i) gates + mixture at B = 2048, S = 300, C = 256 (K = 76,800), 2 tasks x 4 experts
+    B, S, C, nt, ne = 2048, 300, 256, 2, 4
+    g = torch.Generator(device=dev).manual_seed(21)
+    rn = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    h = rn(S * B, C)
+    wg = [rn(S * C, ne) / math.sqrt(S * C) * 3 for _ in range(nt)]
+    ex = [rn(S * B, C) for _ in range(ne)]
+    dm = rn(nt, S * B, C)
+    hd_ = h.clone().requires_grad_(True)
+    wd = [w.clone().requires_grad_(True) for w in wg]
+    ed = [e.clone().requires_grad_(True) for e in ex]
+    gd = ops.MMOEGateFn.apply(hd_, S, B, *wd)
+    md = ops.MMOEMixFn.apply(gd, S, B, *ed)
+    md.backward(dm)
+    h64 = _unpm(h, B, S).double().requires_grad_(True)                      # (B,S,C)
+    w64 = [w.double().requires_grad_(True) for w in wg]
+    e64 = [_unpm(e, B, S).double().requires_grad_(True) for e in ex]
+    g64 = [torch.softmax(h64.reshape(B, -1) @ w, 1) for w in w64]
+    m64 = torch.stack([sum(gt[:, e_, None, None] * e64[e_] for e_ in range(ne)) for gt in g64])       # (nt,B,S,C)
+    m64.backward(torch.stack([_unpm(dm[t], B, S) for t in range(nt)]).double())
+    report(f"mmoe gates B{B} S{S} K{S * C} nt{nt} ne{ne}", rel(gd, torch.stack(g64)), 2e-5)
+    report(f"mmoe mixed B{B} S{S}", rel(torch.stack([_unpm(md[t].detach(), B, S) for t in range(nt)]), m64), 2e-5)
+    report(f"mmoe dh    B{B} S{S}", rel(_unpm(hd_.grad, B, S), h64.grad), 1e-4)
+    for t in range(nt):
+        report(f"mmoe dwg{t} B{B} S{S}", rel(wd[t].grad, w64[t].grad), 1e-4)
+    for e_ in range(ne):
+        report(f"mmoe dex{e_} B{B} S{S}", rel(_unpm(ed[e_].grad, B, S), e64[e_].grad), 1e-4)
+    del h, wg, ex, dm, hd_, wd, ed, gd, md, h64, w64, e64, g64, m64
+    torch.cuda.empty_cache()
+    # ---- (ii) multi-task terms at 4096 x 300: the three task codes of MtCutLoss against the CPU oracle
+    B, S = 4096, 300
+    x, y = synthetic_lists(B, S, 1, 4242)
+    gcpu = torch.Generator().manual_seed(7)
+    cut = torch.softmax(torch.randn(B, S, generator=gcpu) * 2, 1).unsqueeze(2)
+    rer = (torch.randn(B, S, generator=gcpu) * 0.01 + 0.02 * y).unsqueeze(2)      # hinge active or not by the margin
+    cls = torch.sigmoid(torch.randn(B, S, generator=gcpu)).unsqueeze(2)
+    for nt_ in (3, 2.1, 2.2):
+        for scale in (1.0, -1.0):                            # -1: relevant documents score LOWER -> the hinge is active
+            def outs(device, dtype=torch.float32):
+                c, r_, p_ = [t.clone().to(device).requires_grad_(True) for t in (cls, rer * scale, cut)]
+                return [c, r_, p_] if nt_ == 3 else ([c, p_] if nt_ == 2.1 else [r_, p_])
+            o_r, o_h = outs("cpu"), outs(dev)
+            l_r = ol.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=nt_)(o_r, y)
+            l_h = hl.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=nt_)(o_h, y.to(dev))
+            l_r.backward(), l_h.backward()
+            tag = f"mtcut {B}x{S} tasks {nt_:g} hinge {'active' if scale < 0 else 'inactive'}"
+            report(f"{tag}: loss", abs(float(l_h) - float(l_r)) / max(1.0, abs(float(l_r))), 1e-5)
+            for i, (a, b) in enumerate(zip(o_h, o_r)):
+                gb = b.grad if b.grad is not None else torch.zeros_like(b)      # inactive hinge: the oracle returns a constant 0
+                report(f"{tag}: d out{i}", float((a.grad.cpu() - gb).abs().max() / max(1e-30, float(gb.abs().max()))), 1e-4)
+    # ---- (iii) the whole model at 1024 x 300 against the oracle module in float64 on the device
+    B, S = 1024, 300
+    kw = dict(seq_len=S, num_experts=4, num_tasks=2.1)
+    bf = N.get_precision() == "bf16x3"
+    edge, grad_tol = (3e-4, 1e-3) if bf else (4e-6, 2e-4)
+    t0 = time.time()
+    ref = om.MMOECut(dropout=0.0, **kw)
+    fill_state_dict(ref, 977)
+    hip = hm.MMOECut(dropout=0.0, **kw)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    ref = ref.double().to(dev)
+    x, y = synthetic_lists(B, S, 3, 978)
+    ref.train(), hip.train()
+    out_h = hip(x.to(dev))
+    nodes = _encoder_nodes(list(out_h))
+    crit_h = hl.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=2.1)
+    crit_r = ol.MtCutLoss(metric="f1", rerank_weight=0.4, classi_weight=0.6, num_tasks=2.1)
+    loss_h = crit_h(out_h, y.to(dev))
+    loss_h.backward()
+    counts = _align_relu(ref, hip, nodes, B, S, edge)
+    out_r = ref(x.to(dev).double())
+    loss_r = crit_r([o.cpu().float() for o in out_r], y)          # the criterion in the oracle's own arithmetic (fp32, host)
+    loss_r.backward()
+    for i, (a, b) in enumerate(zip(out_h, out_r)):
+        report(f"mmoecut_e4_t21_b{B}_s{S} out{i} max|d|", float((a.detach().double() - b.detach()).abs().max()), 1e-5)
+        report(f"mmoecut_e4_t21_b{B}_s{S} out{i} rel", rel(a, b), 2e-4)
+    p_r = out_r[-1].detach().squeeze(2).cpu()
+    k_r = omet.cut_positions(p_r.float().numpy())
+    k_h, f1_h, dcg_h = Metric.evaluate(out_h[-1], y.to(dev))
+    top2 = torch.topk(p_r, 2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]).numpy()
+    differ = k_h.cpu().numpy() != k_r
+    report(f"mmoecut_e4_t21_b{B}_s{S} k mismatches outside knife-edge lists (gap >= 4e-6)", float((differ & (gap >= 4e-6)).sum()), 0)
+    print(f"   ({int(differ.sum())} cut positions differ, {int((gap < 4e-6).sum())} knife-edge lists of {B}; "
+          f"{len(set(k_r.tolist()))} distinct cut positions)", flush=True)
+    report(f"mmoecut_e4_t21_b{B}_s{S} F1 vs oracle k", abs(float(f1_h) - omet.Metric.f1(y.numpy(), k_r)), 1e-4)
+    report(f"mmoecut_e4_t21_b{B}_s{S} loss", abs(float(loss_h) - float(loss_r)) / max(1.0, abs(float(loss_r))), 1e-4)
+    report(f"mmoecut_e4_t21_b{B}_s{S} ReLU decisions differing outside |z| < {edge:g}", float(counts[1]), 0)
+    errs = _param_rel_l2(hip, ref)
+    worst = max(errs, key=errs.get)
+    report(f"mmoecut_e4_t21_b{B}_s{S} grad rel-L2 worst, flip-aligned ({worst})", errs[worst], grad_tol)
+    report(f"mmoecut_e4_t21_b{B}_s{S} grad rel-L2 median, flip-aligned", sorted(errs.values())[len(errs) // 2], grad_tol / 5)
+    print(f"   ({counts[0]} of {counts[2]} FFN units aligned; {time.time() - t0:.1f}s)", flush=True)
 
 
 FLIP_CASES = [
@@ -1212,16 +1520,21 @@ def trajectory():
     from utils.metrics import Metric
     from rlt_hip.parallel import FlatModel, FusedAdam
     K = 20
-    for tag, cls, kw, B, cname, lr, wd in [("attncut_b32", "AttnCut", {}, 32, "div_js_f1_aug1", 1e-4, 0.0025),
-                                           ("mtattncut_t3_b16", "MtAttnCut", {"num_tasks": 3}, 16, "mtcut_f1", 3e-5, 0.005)]:
+    # the Choopy case: small position encoding + unsorted list-specific scores, so that the lists of the batch cut at
+    # different positions (with the plain recipe every list of a Choopy batch cuts at the same one)
+    for tag, cls, kw, B, F_, cname, lr, wd, fill_kw, noise in [
+            ("attncut_b32", "AttnCut", {}, 32, 3, "div_js_f1_aug1", 1e-4, 0.0025, {}, 0.0),
+            ("mtattncut_t3_b16", "MtAttnCut", {"num_tasks": 3}, 16, 3, "mtcut_f1", 3e-5, 0.005, {}, 0.0),
+            ("choopy_b32", "Choopy", {}, 32, 1, "choopy_f1", 1e-4, 0.0025, {"pe_scale": 0.05}, 2.0),
+            ("mmoecut_e4_t21_b16", "MMOECut", {"num_experts": 4, "num_tasks": 2.1}, 16, 3, "mtcut_f1", 3e-5, 0.005, {}, 0.0)]:
         case = {"kwargs": kw, "w_r": 0.4, "w_c": 0.6}
         S = 300
         ref = getattr(om, cls)(dropout=0.0, **kw)
-        fill_state_dict(ref, 800 + B)
+        fill_state_dict(ref, 800 + B, **fill_kw)
         hip = getattr(hm, cls)(dropout=0.0, **kw)
         hip.load_state_dict(ref.state_dict())
         hip = hip.to(dev)
-        x, y = synthetic_lists(B, S, 3, 801)
+        x, y = synthetic_lists(B, S, F_, 801, noise=noise)
         xd, yd = x.to(dev), y.to(dev)
         flat = FlatModel(hip)
         opt_h = FusedAdam(flat, lr=lr, weight_decay=wd)
@@ -1258,18 +1571,25 @@ def trajectory():
         report(f"trajectory {tag}: max |d p| over {K} steps", worst_p, 1e-4)
         report(f"trajectory {tag}: cut positions differing outside knife-edge lists", float(kdiff), 0)
         print(f"   ({tag}: {kedge} knife-edge cut-position differences over {K} steps x {B} lists)", flush=True)
+        # cut positions after the K steps (p has moved away from its initial 1/S): identical on every list whose two best
+        # positions are at least 1e-5 apart in the oracle (the number of such lists and of distinct k is printed)
+        clear = gap >= 1e-5
+        report(f"trajectory {tag}: cut positions after {K} steps on the {int(clear.sum())} of {B} lists with top-2 gap >= 1e-5",
+               float((differ & clear).sum()), 0)
+        print(f"   ({tag}: after {K} steps {int(clear.sum())} of {B} lists have a top-2 gap >= 1e-5 (median gap {float(np.median(gap)):.2e}), "
+              f"{len(set(k_r.tolist()))} distinct cut positions, max p {float(p_r.max()):.4f} vs 1/S = {1 / S:.4f})", flush=True)
         # parameters after K steps: relative L2 over the whole flat vector (Adam normalises by sqrt(v): parameters with an
         # analytically zero gradient move by rounding noise of either sign, so a per-parameter max would be meaningless)
         pr = torch.cat([q.detach().reshape(-1) for q in ref.parameters()])
         ph = torch.cat([q.detach().reshape(-1).cpu() for q in hip.parameters()])
         report(f"trajectory {tag}: |params - oracle params| / |oracle step| after {K} steps",
-               float((ph - pr).norm()) / max(1e-30, float((pr - torch.cat([q.reshape(-1) for q in _fresh_params(om, cls, kw, 800 + B)])).norm())), 0.2)
+               float((ph - pr).norm()) / max(1e-30, float((pr - torch.cat([q.reshape(-1) for q in _fresh_params(om, cls, kw, 800 + B, fill_kw)])).norm())), 0.2)
 
 
-def _fresh_params(om, cls, kw, seed):
+def _fresh_params(om, cls, kw, seed, fill_kw=None):
     from oracle.weights import fill_state_dict
     m = getattr(om, cls)(dropout=0.0, **kw)
-    fill_state_dict(m, seed)
+    fill_state_dict(m, seed, **(fill_kw or {}))
     return [q.detach() for q in m.parameters()]
 
 
@@ -1369,6 +1689,75 @@ def trainer_bookkeeping():
             report(f"Trainer {name} train/loss_step count and steps", 0.0 if [r["step"] for r in tags["train/loss_step"]] == list(range(EPOCHS * steps_per_epoch)) else 1.0, 0)
             report(f"Trainer {name} test/F1_epoch scalars", float(np.abs(np.array([r["value"] for r in tags["test/F1_epoch"]]) - np.array([h["test"][1] for h in trainer.history])).max()), 1e-12)
 
+
+
+@section
+def trainer_buckets():
+    """BASELINE configs[4]'s shape on the product path: run.py's Trainer on a set with lists of 100 / 200 / 300 documents
+    (homogeneous length-bucketed batches served round-robin, dataloader/rank_data.py), MtAttnCut + MtCutLoss, against the
+    same loop written with the CPU oracle over the same BatchLoader schedule: per-epoch train / test means of loss, F1
+    and DCG, and the number of batches of each length."""
+    import tempfile
+    import run as hip_run
+    from dataloader import BatchLoader, RankData, write_synthetic_robust04
+    from oracle import losses as ol, metrics as omet, models as om
+    EPOCHS, BS, LR, WD, SEED = 2, 4, 1e-4, 0.0025, 11
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=21, n_test=9, seed=6, lengths=(100, 200, 300))
+        for name, nt in (("mtattncut", 3), ("attncut", None)):
+            argv = ["--model-name", name, "--dataset-base", tmp, "--epochs", str(EPOCHS), "--use-conf", "0", "--batch-size", str(BS),
+                    "--criterion", "f1", "--dropout", "0.0", "--lr", str(LR), "--weight-decay", str(WD), "--seed", str(SEED),
+                    "--tensorboard-dir", ""]
+            args = hip_run.build_parser().parse_args(argv)
+            args.model_path = None
+            torch.manual_seed(SEED)
+            trainer = hip_run.Trainer(args)
+            init = {k: v.detach().clone().cpu() for k, v in trainer.model.state_dict().items()}
+            trainer.run()
+            if nt is None:
+                ref, crit = om.AttnCut(input_size=3, dropout=0.0), ol.DivLoss(metric="f1", div_type="js", augmented=True)
+            else:
+                ref = om.MtAttnCut(input_size=3, num_tasks=nt, dropout=0.0)
+                crit = ol.MtCutLoss(metric="f1", rerank_weight=args.rerank_weight, classi_weight=args.class_weight, num_tasks=nt)
+            ref.load_state_dict(init)
+            opt = torch.optim.Adam(ref.parameters(), lr=LR, weight_decay=WD)
+            rd = RankData("robust04", "drmm_tks", True, tmp)
+            pairs = lambda split: [(x, y) for (x, y, _q) in rd.buckets[split].values()]
+            tr = BatchLoader(pairs("train"), BS, True, None, SEED)
+            te = BatchLoader(pairs("test"), BS, True, None, SEED + 1)
+            # (a third loader for the schedule check: iterating one advances its permutation stream)
+            seen = [int(x.shape[1]) for x, _ in BatchLoader(pairs("train"), BS, True, None, SEED)]
+            report(f"Trainer buckets {name}: the train loader serves lengths 100/200/300 round-robin",
+                   0.0 if seen[:6] == [100, 200, 300, 100, 200, 300] and sorted(set(seen)) == [100, 200, 300] else 1.0, 0)
+
+            def evaluate(out, y):
+                p = (out[-1] if isinstance(out, (list, tuple)) else out).detach().squeeze(2).numpy()
+                k = omet.cut_positions(p)
+                return omet.Metric.f1(y.numpy(), k), omet.Metric.dcg(y.numpy(), k)
+
+            for epoch in range(EPOCHS):
+                tot, n = np.zeros(3), 0
+                ref.train()
+                for x, y in tr:
+                    opt.zero_grad()
+                    out = ref(x)
+                    loss = crit(out, y)
+                    loss.backward()
+                    opt.step()
+                    tot += np.array([loss.item(), *evaluate(out, y)])
+                    n += 1
+                want_tr = tot / n
+                tot, n = np.zeros(3), 0
+                ref.eval()
+                with torch.no_grad():
+                    for x, y in te:
+                        out = ref(x)
+                        tot += np.array([crit(out, y).item(), *evaluate(out, y)])
+                        n += 1
+                want_te = tot / n
+                for split, want in (("train", want_tr), ("test", want_te)):
+                    got = np.array(trainer.history[epoch][split])
+                    report(f"Trainer buckets {name} epoch {epoch} {split} loss/F1/DCG means", float(np.abs(got - want).max() / max(1.0, np.abs(want).max())), 1e-4)
 
 
 @section
@@ -1479,6 +1868,61 @@ def trainer_dp():
                 report(f"trainer_dp epoch {e} {split} loss/F1/DCG", float(np.abs(g - want).max() / max(1.0, np.abs(want).max())), 1e-4)
 
 
+@section
+def rccl_one_rank():
+    """The RCCL code path on this one-GPU box: bench.py and run.py as fresh children of torch.distributed.run with ONE
+    rank and RLT_FORCE_DIST=1 - init_process_group("nccl", device_id=...), the parameter broadcast, the all-reduce(AVG) of
+    the flat gradient bucket every step and the NCCL barriers all execute (with one rank they otherwise early-return, so
+    the driver's 8-GPU run would be the first time they ran).  A one-rank AVG must leave the bucket bitwise unchanged, so
+    the training state must equal the same command without the process group."""
+    import json
+    import subprocess
+    import tempfile
+    from dataloader import write_synthetic_robust04
+    bench_py = os.path.join(REPO, "bench.py")
+    run_py = os.path.join(REPO, "ranked-list-truncation_amd", "run.py")
+    base = [bench_py, "--gpus", "1", "--batch", "96", "--steps", "3", "--warmup", "1", "--other-steps", "0", "--no-cpu-baseline",
+            "--precision", "fp32"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    plain = subprocess.run([sys.executable] + base, env=env, capture_output=True, text=True, timeout=600)
+    report("rccl_one_rank: plain bench.py exit status", float(plain.returncode), 0)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1"]
+    forced = subprocess.run(launch + ["--master-port", "29741"] + base, env=dict(env, RLT_FORCE_DIST="1"),
+                            capture_output=True, text=True, timeout=600)
+    report("rccl_one_rank: bench.py under torch.distributed.run (1 rank, nccl) exit status", float(forced.returncode), 0)
+    if plain.returncode or forced.returncode:
+        print(plain.stderr[-1500:], forced.stderr[-3000:])
+        return
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(forced.stdout.strip().splitlines()[-1])
+    col = b["collective"] or {}
+    report("rccl_one_rank: collective.backend == nccl", 0.0 if col.get("backend") == "nccl" else 1.0, 0)
+    report("rccl_one_rank: rccl_ranks == 1", abs(col.get("rccl_ranks", -1) - 1), 0)
+    report("rccl_one_rank: one-rank AVG leaves the flat gradient bucket unchanged (max |diff|)", float(col.get("one_rank_avg_max_abs_diff", 1.0)), 0)
+    report("rccl_one_rank: plain run has no process group", 0.0 if a["collective"] is None else 1.0, 0)
+    vals = [b["train_state"][k] for k in ("loss", "f1", "dcg")]
+    report("rccl_one_rank: finite training state", 0.0 if all(math.isfinite(v) for v in vals) else 1.0, 0)
+    report("rccl_one_rank: training state == the run without a process group",
+           max(abs(a["train_state"][k] - b["train_state"][k]) for k in ("loss", "f1", "dcg")), 0)
+    # run.py (the Trainer's data-parallel loop: broadcast, per-step all-reduce of gradients and of the logged sums)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=12, n_test=6, seq_len=300, seed=4)
+        hist = {}
+        for tag, pre, extra_env in (("plain", [sys.executable], {}), ("nccl", launch + ["--master-port", "29742"], {"RLT_FORCE_DIST": "1"})):
+            hist[tag] = os.path.join(tmp, tag + ".json")
+            cmd = pre + [run_py, "--model-name", "attncut", "--dataset-base", tmp, "--epochs", "2", "--use-conf", "0", "--batch-size", "6",
+                         "--criterion", "f1", "--dropout", "0.0", "--lr", "1e-4", "--weight-decay", "0.0025", "--seed", "5",
+                         "--history-json", hist[tag], "--tensorboard-dir", ""]
+            res = subprocess.run(cmd, env=dict(env, RLT_PRECISION=N.get_precision(), **extra_env), capture_output=True, text=True, timeout=600)
+            report(f"rccl_one_rank: run.py {tag} exit status", float(res.returncode), 0)
+            if res.returncode:
+                print(res.stderr[-3000:])
+                return
+        ha, hb = json.load(open(hist["plain"])), json.load(open(hist["nccl"]))
+        worst = max(abs(x - y) for ea, eb in zip(ha["history"], hb["history"]) for sp in ("train", "test") for x, y in zip(ea[sp], eb[sp]))
+        report("rccl_one_rank: run.py per-epoch means, nccl 1 rank == no process group", worst, 0)
+
+
 if __name__ == "__main__":
     want = [w for w in sys.argv[1:] if not w.startswith("--")]
     for w in sys.argv[1:]:
@@ -1490,9 +1934,11 @@ if __name__ == "__main__":
         if want and fn.__name__ not in want:
             continue
         print(f"\n=== {fn.__name__} ===", flush=True)
+        t_sec = time.time()
         try:
             fn()
             torch.cuda.synchronize()
+            print(f"--- {fn.__name__}: {time.time() - t_sec:.1f} s", flush=True)
         except Exception:
             traceback.print_exc()
             RESULTS.append((fn.__name__ + " EXCEPTION", float("nan"), 0, False))
