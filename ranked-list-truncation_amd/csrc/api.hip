@@ -4,12 +4,15 @@
 #include <stdlib.h>
 #include <string.h>
 
-// precision mode of the MFMA contractions: 0 = exact fp32 MFMA, 1 = split-bf16 (3 bf16 products, fp32 accumulate)
+// precision mode of the MFMA contractions: 0 = exact fp32 MFMA, 1 = split-bf16 (3 bf16 products, fp32 accumulate),
+// 2 = fp32-faithful six-product split for the GEMM family (attention and BiLSTM on the exact fp32 MFMA kernels)
 static int g_precision = -1;
 int rlt_precision() {
     if (g_precision < 0) {
         const char* e = getenv("RLT_PRECISION");
-        g_precision = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+        if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) g_precision = RLT_PRECISION_FP32;
+        else if (e && (!strcmp(e, "bf16x6") || !strcmp(e, "2"))) g_precision = RLT_PRECISION_BF16X6;
+        else g_precision = RLT_PRECISION_BF16X3;
     }
     return g_precision;
 }
@@ -17,7 +20,7 @@ int rlt_precision() {
 extern "C" {
 
 int rlt_set_precision(int mode) {
-    if (mode != RLT_PRECISION_FP32 && mode != RLT_PRECISION_BF16X3) return RLT_E_ARG;
+    if (mode != RLT_PRECISION_FP32 && mode != RLT_PRECISION_BF16X3 && mode != RLT_PRECISION_BF16X6) return RLT_E_ARG;
     g_precision = mode;
     return 0;
 }

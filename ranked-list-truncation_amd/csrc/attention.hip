@@ -495,7 +495,7 @@ static int attn_mode_any() {
         if (!e) return -1;
         return (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : 0;
     }();
-    return forced >= 0 ? forced : rlt_precision();
+    return forced >= 0 ? forced : (rlt_precision() == RLT_PRECISION_BF16X3 ? 1 : 0);      // bf16x6 mode: the exact fp32 kernels
 }
 // head dims 16 / 32 / 64 have split-bf16 kernels; 128 (PLECut: d_model 256, 2 heads, models/PLECut.py:56) runs on the
 // exact-fp32 kernels in either mode (a correct, unhurried instantiation: it is not on a benchmarked configuration)

@@ -963,6 +963,361 @@ int launch_gemm3b(GemmArgs g, int ns, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
+// ======================================================================================================
+// "bf16x6": fp32-FAITHFUL products on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 values,
+// x = h + m + l (h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits, the last residual is exactly
+// representable), and a*b is evaluated as the six products  h*h' + h*m' + m*h' + h*l' + l*h' + m*m'  on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each of them is exact in the matrix pipe (8 x 8 bits); what is dropped
+// (m*l' + l*m' + l*l') is at most 2^-26 |a b| - a quarter of an fp32 ulp of the product, below the rounding of the fp32
+// accumulation itself (2^-24 of the running sum) that the f32 MFMA kernel above pays as well.  So the result carries the
+// full 24 operand bits, where bf16x3 carries 16: the mode is held to the EXACT-FP32 tolerances in the tests.  Six
+// products cost 2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3 of the f32 MFMA.
+// 256 x 128 tile, 8 wavefronts (4 x 2, each 64 x 64: 64 accumulator VGPRs), K tiles of 32; LDS: two buffers of
+// [A_h | A_m | A_l] (256 rows) and [B_h | B_m | B_l] (128 rows), planes in gemm3b's layout (64-byte rows, permuted and
+// chunk-swizzled), 2 x 72 KB.  With twice the matrix work per operand byte of the bf16x3 kernel the K loop is bound by
+// the matrix pipe, not by the L2 -> CU path that bounds gemm3b.
+constexpr int BM6 = 256, BN6 = 128;
+constexpr int PLA6 = 256 * 32, PLB6 = 128 * 32;          // bf16 elements per plane
+constexpr int BUF6 = 3 * PLA6 + 3 * PLB6;                // per LDS buffer
+
+__device__ __forceinline__ void split4x3(float a, float b, float c, float d, uint2& hi, uint2& mid, uint2& lo) {
+    hi.x = pack_bf16x2(a, b);
+    hi.y = pack_bf16x2(c, d);
+    asm("" : "+v"(hi.x), "+v"(hi.y));          // as in split4: keep the packed pair, do not re-convert
+    const float ra = a - __builtin_bit_cast(float, hi.x << 16), rb = b - __builtin_bit_cast(float, hi.x & 0xffff0000u);
+    const float rc = c - __builtin_bit_cast(float, hi.y << 16), rd = d - __builtin_bit_cast(float, hi.y & 0xffff0000u);
+    mid.x = pack_bf16x2(ra, rb);
+    mid.y = pack_bf16x2(rc, rd);
+    asm("" : "+v"(mid.x), "+v"(mid.y));
+    lo.x = pack_bf16x2(ra - __builtin_bit_cast(float, mid.x << 16), rb - __builtin_bit_cast(float, mid.x & 0xffff0000u));
+    lo.y = pack_bf16x2(rc - __builtin_bit_cast(float, mid.y << 16), rd - __builtin_bit_cast(float, mid.y & 0xffff0000u));
+}
+
+// B operand tile: 128 (n) x 32 (k).  K-contiguous ([N][K]): 1024 float4, two per thread; N-contiguous ([K][N]): 4 x 4
+// blocks like load3b, 256 threads (wavefronts 0..3) hold one each
+struct Stage6B { float4 v[4]; };
+template <bool KC>
+__device__ __forceinline__ void load6b(const float* __restrict__ P, int ld, int n0, int k0, int tid, Stage6B& st) {
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i;
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(n0 + kcb_row(idx)) * ld + k0 + 4 * (idx & 7));
+        }
+    } else if (tid < 256) {
+        const int kb = tid & 7, mb = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(k0 + 4 * kb + i) * ld + n0 + 4 * mb);
+    }
+}
+// one part of the three-way split + LDS store of a staged tile; planes Th / Tm / Tl.  KC: part = which float4 of the thread;
+// !KC: part = which of the 4 columns of the thread's 4 x 4 block
+template <bool KC>
+__device__ __forceinline__ void store6_part(uint16_t* __restrict__ Th, uint16_t* __restrict__ Tm, uint16_t* __restrict__ Tl,
+                                            int tid, const float4 (&v)[4], int part) {
+    uint2 hi, mid, lo;
+    int off;
+    if (KC) {
+        const int idx = tid + 512 * part;
+        const int row = prow2(kcb_row(idx)), kq = idx & 7;
+        off = row * 32 + 8 * swz2(row, kq >> 1) + 4 * (kq & 1);
+        split4x3(v[part].x, v[part].y, v[part].z, v[part].w, hi, mid, lo);
+    } else {
+        const int kb = tid & 7, mb = tid >> 3;
+        const float* f0 = reinterpret_cast<const float*>(&v[0]);
+        const float* f1 = reinterpret_cast<const float*>(&v[1]);
+        const float* f2 = reinterpret_cast<const float*>(&v[2]);
+        const float* f3 = reinterpret_cast<const float*>(&v[3]);
+        int base = ((mb >> 1) * 8 + (mb & 1)) * 32 + 4 * (kb & 1) + 8 * ((kb >> 1) ^ (((mb >> 1) & 1) * 2));
+        asm volatile("" : "+v"(base));
+        off = (base ^ (8 * (part & 1))) + 128 * (part & 1) + 64 * (part >> 1);
+        split4x3(f0[part], f1[part], f2[part], f3[part], hi, mid, lo);
+    }
+    *reinterpret_cast<uint2*>(Th + off) = hi;
+    *reinterpret_cast<uint2*>(Tm + off) = mid;
+    *reinterpret_cast<uint2*>(Tl + off) = lo;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm6_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    int bid, zslab;
+    decode_block(g, bid, zslab);                     // g.tiles_* count 256 x 128 tiles here
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM6, n0 = tn * BN6;
+    const int kbeg = zslab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // two staging register sets: K tile t+1 (loaded one whole iteration ago) is split and stored to LDS during iteration
+    // t while the loads of K tile t+2 go into the other set at the START of iteration t - a full iteration of cover for
+    // the memory latency (with one set, loaded at the end of an iteration and consumed at the start of the next, every K
+    // tile waited for its loads: 55 % of the matrix pace)
+    Stage3 sa0, sa1;
+    Stage6B sb0, sb1;
+    constexpr bool AKC = !TA, BKC = TB;              // operand stored with K contiguous
+    const bool b_active = BKC || tid < 256;          // wave-uniform
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_cs = [&](const Stage3& sa) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+    };
+    auto planes_a = [&](int buf) { return lds + buf * BUF6; };
+    auto planes_b = [&](int buf) { return lds + buf * BUF6 + 3 * PLA6; };
+    auto stash_a = [&](int buf, int part, const Stage3& sa) {
+        uint16_t* pa_ = planes_a(buf);
+        store6_part<AKC>(pa_, pa_ + PLA6, pa_ + 2 * PLA6, tid, sa.v, part);
+    };
+    auto stash_b = [&](int buf, int part, const Stage6B& sb) {
+        uint16_t* pb_ = planes_b(buf);
+        if (b_active) store6_part<BKC>(pb_, pb_ + PLB6, pb_ + 2 * PLB6, tid, sb.v, part);
+    };
+    constexpr int BPARTS = BKC ? 2 : 4;
+    const int pl = prow2(l31);
+    const int sw = (pl >> 2) & 3;
+    const int nt = (kend - kbeg) / BK3;
+
+    // prologue: K tile 0 into LDS buffer 0, K tile 1 into staging set 0
+    load3b<AKC>(g.A, g.lda, m0, kbeg, tid, sa0);
+    load6b<BKC>(g.B, g.ldb, n0, kbeg, tid, sb0);
+    if (want_cs) add_cs(sa0);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stash_a(0, part, sa0);
+#pragma unroll
+    for (int part = 0; part < BPARTS; ++part) stash_b(0, part, sb0);
+    {
+        const int k1 = kbeg + min(1, nt - 1) * BK3;
+        load3b<AKC>(g.A, g.lda, m0, k1, tid, sa0);
+        load6b<BKC>(g.B, g.ldb, n0, k1, tid, sb0);
+    }
+    __syncthreads();
+
+    // iteration t: multiply K tile t (LDS buffer t & 1); split + store K tile t+1 from (sa_st, sb_st) into the other
+    // buffer; fetch K tile t+2 into (sa_ld, sb_ld)
+    auto iteration = [&](int t, const Stage3& sa_st, const Stage6B& sb_st, Stage3& sa_ld, Stage6B& sb_ld) {
+        const int buf = t & 1;
+        const uint16_t* pa = planes_a(buf) + (wm * 64 + pl) * 32;
+        const uint16_t* pb = planes_b(buf) + (wn * 64 + pl) * 32;
+        const bool do_stash = t + 1 < nt;
+        const int kf = kbeg + min(t + 2, nt - 1) * BK3;          // unconditional fetch (see gemm3b_kernel)
+        load3b<AKC>(g.A, g.lda, m0, kf, tid, sa_ld);
+        load6b<BKC>(g.B, g.ldb, n0, kf, tid, sb_ld);
+        bf16x8 a[2][2][3], b[2][3];                              // [slot][i][h|m|l], [slot][h|m|l]
+        auto load_a = [&](int ks, int slot) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[slot][i][q] = *reinterpret_cast<const bf16x8*>(pa + q * PLA6 + i * 32 * 32 + co);
+        };
+        auto load_b = [&](int ks, int j, int slot) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const bf16x8*>(pb + q * PLB6 + j * 32 * 32 + co);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int ks = step >> 1, j = step & 1;
+            if (step + 1 < 4) load_b((step + 1) >> 1, (step + 1) & 1, (step + 1) & 1);
+            if (step == 0) load_a(1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][1], b[step & 1][1], c, 0, 0, 0);   // m m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][2], b[step & 1][0], c, 0, 0, 0);   // l h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[step & 1][2], c, 0, 0, 0);   // h l'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][1], b[step & 1][0], c, 0, 0, 0);   // m h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[step & 1][1], c, 0, 0, 0);   // h m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][0], b[step & 1][0], c, 0, 0, 0);   // h h'
+                acc[i][j] = c;
+            }
+            // split + LDS store of the next K tile behind this step's MFMAs: A part `step`, B parts in steps 2 and 3
+            if (do_stash) {
+                if (step == 0 && want_cs) add_cs(sa_st);
+                stash_a(buf ^ 1, step, sa_st);
+                if (step >= 2) {
+#pragma unroll
+                    for (int q = 0; q < BPARTS / 2; ++q) stash_b(buf ^ 1, (step - 2) * (BPARTS / 2) + q, sb_st);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int t = 0; t < nt; t += 2) {
+        iteration(t, sa0, sb0, sa1, sb1);
+        __syncthreads();
+        if (t + 1 < nt) {
+            iteration(t + 1, sa1, sb1, sa0, sb0);
+            __syncthreads();
+        }
+    }
+    write_output_t<2>(g, acc, m0 + wm * 64, n0 + wn * 64, true, l31, hh, zslab);
+    if (want_cs) {                                     // 8 threads (tid = 8*mb + kb) hold partial sums of columns 4*mb..+3
+        float4* red = reinterpret_cast<float4*>(gsm);
+        __syncthreads();
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[8 * tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 o = red[8 * tid + j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)zslab * g.M : g.colsum) + m0 + 4 * tid;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+
+// 256 x 256 tile of the same six-product scheme (N % 256 == 0).  The 256 x 128 kernel above asks the L2 for 384 cache
+// lines per 48 MFMAs of a wavefront and runs at ~48 % of the matrix pace however far ahead its loads are issued (one or
+// two staging register sets: same time) - like gemm3b it is bound by the number of lines a CU can have in flight, not by
+// latency cover.  This tile asks for 512 lines per 96 MFMAs.  Six planes of gemm3b's layout (256 rows x 64 bytes each,
+// 96 KB) leave no room for a second LDS buffer, so the K loop is: barrier, split + store K tile t from the staging
+// registers, barrier, issue the loads of K tile t+1 (a whole multiply of cover), 96 MFMAs per wavefront.  The split is
+// not hidden behind MFMAs (both wavefronts of a SIMD sit in it together): ~15 % of the loop, against the 2x it buys.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm6b_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);          // [A_h | A_m | A_l | B_h | B_m | B_l], PL2 elements each
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    int bid, zslab;
+    decode_block(g, bid, zslab);                     // g.tiles_* count 256 x 256 tiles here
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int kbeg = zslab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stage3 sa, sb;
+    constexpr bool AKC = !TA, BKC = TB;
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pl = prow2(l31);
+    const int sw = (pl >> 2) & 3;
+    const int nt = (kend - kbeg) / BK3;
+    const uint16_t* pa = lds + (wm * 64 + pl) * 32;
+    const uint16_t* pb = lds + 3 * PL2 + (wn * 128 + pl) * 32;
+
+    load3b<AKC>(g.A, g.lda, m0, kbeg, tid, sa);
+    load3b<BKC>(g.B, g.ldb, n0, kbeg, tid, sb);
+    for (int t = 0; t < nt; ++t) {
+        if (t > 0) __syncthreads();                  // every wavefront has read the fragments of K tile t-1
+        if (want_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+        }
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            store6_part<AKC>(lds, lds + PL2, lds + 2 * PL2, tid, sa.v, part);
+            store6_part<BKC>(lds + 3 * PL2, lds + 4 * PL2, lds + 5 * PL2, tid, sb.v, part);
+        }
+        __syncthreads();
+        {                                            // unconditional (the last iteration re-reads the last K tile)
+            const int kf = kbeg + min(t + 1, nt - 1) * BK3;
+            load3b<AKC>(g.A, g.lda, m0, kf, tid, sa);
+            load3b<BKC>(g.B, g.ldb, n0, kf, tid, sb);
+        }
+        bf16x8 a[2][3], b[2][3];                     // [i][h|m|l], [slot][h|m|l]
+        auto load_a = [&](int ks) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(pa + q * PL2 + i * 32 * 32 + co);
+        };
+        auto load_b = [&](int ks, int j, int slot) {
+            const int co = 8 * ((2 * ks + hh) ^ sw);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const bf16x8*>(pb + q * PL2 + j * 32 * 32 + co);
+        };
+        load_a(0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int ks = step >> 2, j = step & 3;
+            if (step + 1 < 8) load_b((step + 1) >> 2, (step + 1) & 3, (step + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[step & 1][1], c, 0, 0, 0);   // m m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[step & 1][0], c, 0, 0, 0);   // l h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[step & 1][2], c, 0, 0, 0);   // h l'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[step & 1][0], c, 0, 0, 0);   // m h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[step & 1][1], c, 0, 0, 0);   // h m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[step & 1][0], c, 0, 0, 0);   // h h'
+                acc[i][j] = c;
+            }
+            if (step == 3) load_a(1);                // the A fragments of k-step 1 (their registers are free now)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
+    if (want_cs) {                                   // 8 threads (tid = 8*mb + kb) hold partial sums of columns 4*mb..+3
+        float4* red = reinterpret_cast<float4*>(gsm);
+        __syncthreads();
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[8 * tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 o = red[8 * tid + j]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)zslab * g.M : g.colsum) + m0 + 4 * tid;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+template <bool TA, bool TB>
+int launch_gemm6b(GemmArgs g, int ns, hipStream_t st) {
+    const size_t shm = (size_t)6 * PL2 * sizeof(uint16_t);
+    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
+    int rc = rlt_allow_lds(gemm6b_kernel<TA, TB>, shm);
+    if (rc) return rc;
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
+    hipLaunchKernelGGL((gemm6b_kernel<TA, TB>), grid, dim3(512), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+
+// the bf16x6 tile needs M % 256 == 0, N % 128 == 0, whole 32-wide K tiles per slab and the branch-free loader
+// preconditions; other shapes of that mode run on the exact f32 MFMA kernel (more exact still)
+bool gemm6_ok(const GemmArgs& g) {
+    if (!g.vecA || !g.vecB) return false;
+    return !((g.M % BM6) || (g.N % BN6) || (g.K % BK3) || (g.kchunk % BK3));
+}
+template <bool TA, bool TB>
+int launch_gemm6(GemmArgs g, int ns, hipStream_t st) {
+    const size_t shm = (size_t)2 * BUF6 * sizeof(uint16_t);
+    g.tiles_m = g.M / BM6; g.tiles_n = g.N / BN6;
+    int rc = rlt_allow_lds(gemm6_kernel<TA, TB>, shm);
+    if (rc) return rc;
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
+    hipLaunchKernelGGL((gemm6_kernel<TA, TB>), grid, dim3(512), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+
 template <bool TA, bool TB, bool FAST>
 int launch_gemm3_v(const GemmArgs& g, dim3 grid, hipStream_t st) {
     const size_t shm = (size_t)2 * 4 * TILE3 * sizeof(uint16_t);
@@ -1060,11 +1415,13 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
     return launch_gemm_v<TA, TB, BK, 4, false>(g, grid, st);
 }
 
-// 0 = exact fp32 MFMA (parity mode), 1 = split-bf16 (bf16x3); RLT_GEMM_MODE overrides the library-wide mode
+// 0 = exact fp32 MFMA (parity mode), 1 = split-bf16 (bf16x3), 2 = fp32-faithful six-product split (bf16x6);
+// RLT_GEMM_MODE overrides the library-wide mode
 int gemm_mode() {
     static const int forced = [] {
         const char* e = getenv("RLT_GEMM_MODE");
         if (!e) return -1;
+        if (!strcmp(e, "bf16x6") || !strcmp(e, "2")) return 2;
         return (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : 0;
     }();
     return forced >= 0 ? forced : rlt_precision();
@@ -1229,7 +1586,18 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     hipStream_t st = rlt_stream(stream);
     dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     int rc = 0;
-    if (gemm_mode() == 1 && gemm_big_ok(g, ta, tb)) {
+    static const bool x6_small_only = getenv("RLT_GEMM6_SMALL") != nullptr;      // A/B switch: 256 x 128 tiles everywhere
+    if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only) {
+        if (!ta && tb) rc = launch_gemm6b<false, true>(g, ns, st);
+        else if (!ta && !tb) rc = launch_gemm6b<false, false>(g, ns, st);
+        else if (ta && !tb) rc = launch_gemm6b<true, false>(g, ns, st);
+        else rc = launch_gemm6b<true, true>(g, ns, st);
+    } else if (gemm_mode() == 2 && gemm6_ok(g)) {
+        if (!ta && tb) rc = launch_gemm6<false, true>(g, ns, st);
+        else if (!ta && !tb) rc = launch_gemm6<false, false>(g, ns, st);
+        else if (ta && !tb) rc = launch_gemm6<true, false>(g, ns, st);
+        else rc = launch_gemm6<true, true>(g, ns, st);
+    } else if (gemm_mode() == 1 && gemm_big_ok(g, ta, tb)) {
         if (!ta && tb) rc = launch_gemm3b<false, true>(g, ns, st);
         else if (!ta && !tb) rc = launch_gemm3b<false, false>(g, ns, st);
         else if (ta && !tb) rc = launch_gemm3b<true, false>(g, ns, st);

@@ -18,7 +18,8 @@ METRIC_F1, METRIC_DCG = 0, 1
 LOSS_EXPECT, LOSS_CE, LOSS_KL, LOSS_JS = 0, 1, 2, 3
 GEMM_RELU, GEMM_ACCUMULATE = 1, 2
 HEAD_SOFTMAX, HEAD_SIGMOID, HEAD_IDENTITY = 0, 1, 2
-PRECISION_FP32, PRECISION_BF16X3 = 0, 1
+PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X6 = 0, 1, 2
+_PRECISION_NAMES = {PRECISION_FP32: "fp32", PRECISION_BF16X3: "bf16x3", PRECISION_BF16X6: "bf16x6"}
 
 P = c_void_p
 _SIGNATURES = {
@@ -157,13 +158,14 @@ def load():
 
 
 def set_precision(mode):
-    """'fp32' (exact fp32 MFMA products) or 'bf16x3' (split-bf16 products, the default)."""
-    code = {"fp32": PRECISION_FP32, "bf16x3": PRECISION_BF16X3}.get(mode, mode)
+    """'fp32' (exact fp32 MFMA products), 'bf16x3' (split-bf16 products, the default) or 'bf16x6' (fp32-faithful
+    six-product split for the GEMM family, exact-fp32 attention and BiLSTM)."""
+    code = {v: k for k, v in _PRECISION_NAMES.items()}.get(mode, mode)
     check(load().rlt_set_precision(int(code)), "rlt_set_precision")
 
 
 def get_precision():
-    return "fp32" if load().rlt_get_precision() == PRECISION_FP32 else "bf16x3"
+    return _PRECISION_NAMES[load().rlt_get_precision()]
 
 
 def ptr(t):

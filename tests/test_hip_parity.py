@@ -103,6 +103,19 @@ def test_section_by_precision(probe, name, precision):
         native.set_precision("bf16x3")
 
 
+@pytest.mark.parametrize("name", ["gemm", "scale_ops", "dropout", "models", "flip_aligned_grads", "full_size_kernels"])
+def test_section_fp32_faithful_gemm(probe, name):
+    """The third product mode, bf16x6: the GEMM family on an EXACT three-way bf16 split of both operands (six products, all
+    24 mantissa bits; csrc/gemm.hip gemm6_kernel), attention and BiLSTM on the exact-fp32 kernels.  Held to the EXACT-FP32
+    tolerances of every section that drives GEMMs (tools/gpu_probe.py: mfma_tol scales only for bf16x3)."""
+    from rlt_hip import native
+    native.set_precision("bf16x6")
+    try:
+        _run(probe, name)
+    finally:
+        native.set_precision("bf16x3")
+
+
 def test_full_size_models(probe):
     """BASELINE configs[1] (AttnCut 4096 x 300) and configs[2] (Choopy 8192 x 300) at full size, exact-fp32 mode vs
     bf16x3 mode: cut distributions within 1e-4, identical cut positions outside knife-edge lists, loss 1e-4.  The
