@@ -40,7 +40,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 PEAK_HBM_BPS = 8.0e12
 # HBM traffic per launch / per step is NOT measured by this script: it comes from separate rocprofv3 --pmc passes of
 # this same command (tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) committed here:
-PMC_TRAFFIC_FILES = {"bf16x6": (),
+PMC_TRAFFIC_FILES = {"bf16x6": (os.path.join("profiles", "r03_pmc_traffic_bf16x6.json"),),
                      "fp32": (os.path.join("profiles", "r03_pmc_traffic_fp32.json"),),
                      "bf16x3": (os.path.join("profiles", "r03_pmc_traffic_bf16x3.json"), os.path.join("profiles", "r02_pmc_traffic.json"))}
 
@@ -377,7 +377,10 @@ def main():
         (`executed_bf16_tflops` / 2500 is the same fraction).  DESIGN.md section 5."""
         mode, ksum, sec = res["mode"], res["ksum"], res["ms_per_step"] * 1e-3
         launches, ms = ksum.get("attn_bwd_dkv", (0, float("nan")))
-        if mode in ("fp32", "bf16x6"):           # bf16x6: GEMMs only; the attention launches are the exact-fp32 kernels
+        x6_attn = mode == "bf16x6" and hd == 64 and args.dropout == 0 and os.environ.get("RLT_ATTN6", "1") != "0"
+        if x6_attn:                               # six bf16 MFMA products per fp32 product: peak 2500 / 6
+            kern, mult, peak = "attn6_bwd_dkv_kernel", 6, PEAK_BF16_MFMA_TFLOPS
+        elif mode in ("fp32", "bf16x6"):          # bf16x6 at other head dims / with dropout: the exact-fp32 kernels
             kern, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 1, PEAK_F32_MFMA_TFLOPS
         else:
             kern, mult, peak = f"attn3_bwd_dkv_kernel<{hd},{drop_tag}>", 3, PEAK_BF16_MFMA_TFLOPS
@@ -421,8 +424,8 @@ def main():
 
     DTYPES = {"fp32": "f32",
               "bf16x3": "f32 storage and accumulation; MFMA products split into 3 bf16 products (hi*hi + hi*lo + lo*hi, ~16 operand mantissa bits)",
-              "bf16x6": "f32 storage and accumulation; GEMM products from an EXACT 3-way bf16 split of both operands (all 24 mantissa bits, "
-                        "6 bf16 MFMA products, dropped terms <= 2^-26 of the product); attention and BiLSTM on the f32 MFMA"}
+              "bf16x6": "f32 storage and accumulation; GEMM and list-attention products from an EXACT 3-way bf16 split of both operands (all 24 "
+                        "mantissa bits, 6 bf16 MFMA products, dropped terms <= 2^-26 of the product); BiLSTM recurrences on the f32 MFMA"}
     main_res = run_mode(precision, args.steps, args.warmup)
     other_res = run_mode(other, args.other_steps, 1) if args.other_steps > 0 else None
     # the fp32-faithful GEMM mode: timed beside the headline, never the headline itself
@@ -472,11 +475,13 @@ def main():
             out["fp32_faithful_mode"] = {
                 "dtype": DTYPES["bf16x6"], "precision_mode": "bf16x6", "steps": x6_res["steps"],
                 "ms_per_step": round(x6_res["ms_per_step"], 3), "value": round(x6_res["value"], 2), "unit": "lists/s",
+                "roofline": roofline_block(x6_res),
                 "train_state": dict(zip(("loss", "f1", "dcg"), (round(v, 6) for v in x6_res["state"]))),
-                "note": "same step with the GEMM family on the six-product split (csrc/gemm.hip gemm6_kernel): measured against fp64 its "
-                        "products are as accurate as the f32 MFMA's (tools/x6_probe.py, profiles/r03_x6_probe.log) and the GPU suite holds "
-                        "it to the exact-fp32 tolerances; attention (the dominant launch, same roofline as the headline) and the BiLSTM "
-                        "run the exact-fp32 kernels.  Reported beside the headline, not as the headline."}
+                "note": "same step with the GEMM family (csrc/gemm.hip gemm6*_kernel) and the list attention (csrc/attention6.hip) on the "
+                        "exact three-way bf16 split, six MFMA products per fp32 product: measured against fp64 these kernels are as accurate "
+                        "as the f32 MFMA ones or better (tools/x6_probe.py, profiles/r03_x6_probe.log; tools/gpu_probe.py attention / "
+                        "scale_ops) and the whole GPU suite holds the mode to the exact-fp32 tolerances; the BiLSTM recurrences run the "
+                        "exact-fp32 kernels.  Reported beside the headline, not as the headline."}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.cpu_sample_batch, args.cpu_loop_batch)
         print(json.dumps(out), flush=True)

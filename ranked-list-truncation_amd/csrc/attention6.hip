@@ -1,0 +1,421 @@
+// List-axis attention, fp32-FAITHFUL variant on the bf16 matrix pipe ("bf16x6", the attention half of that mode; the GEMM
+// half is gemm6_kernel in gemm.hip): same algorithm, same interface and the same fp32 softmax arithmetic as the exact-fp32
+// kernels of attention.hip, but every MFMA product a*b is evaluated from an EXACT three-way bf16 split of both operands,
+//   x = h + m + l  (h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits),
+//   a*b ~ m*m' + l*h' + h*l' + m*h' + h*m' + h*h'   (six v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest first);
+// what is dropped is <= 2^-26 |a b|, a quarter of an fp32 ulp of the product.  Six bf16 products cost 6/16 of one f32 MFMA
+// product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
+//
+// Head dim 64, no dropout (what the benchmark configurations of the AttnCut / MMOECut family run); every other case of the
+// mode stays on the exact-fp32 kernels.  Layout as in attention.hip: one wavefront owns 32 queries (32 keys in the dK/dV
+// kernel), scores are produced TRANSPOSED so that the softmax is a per-lane loop over accumulator registers and the
+// probabilities are directly the B operand of the next product (registers 8s..8s+7 = k-step s).  Tiles of 64 rows are
+// split once per workgroup at staging time into [row][d] bf16 images (three planes, 144-byte rows); products that contract
+// over the tile's ROW index read their A operand transposed from the same image with ds_read_b64_tr_b16, so no transposed
+// image exists.  One LDS copy of a tile pair (55 KB): two workgroups per CU, their tile phases uncorrelated.
+#include "attention_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+constexpr int HD6 = 64;
+constexpr int LDR6 = HD6 + 8;                  // bf16 elements per image row (144 bytes: 16-byte aligned fragments)
+constexpr int PLANE6 = KT * LDR6;              // elements per plane
+constexpr int IMG6 = 3 * PLANE6;               // one tile image: [h | m | l]
+
+__device__ __forceinline__ uint32_t pk2_6(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    v2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+// exact three-way split of four values (see gemm.hip split4x3)
+__device__ __forceinline__ void split4x3_6(float a, float b, float c, float d, uint2& hi, uint2& mid, uint2& lo) {
+    hi.x = pk2_6(a, b);
+    hi.y = pk2_6(c, d);
+    asm("" : "+v"(hi.x), "+v"(hi.y));
+    const float ra = a - __builtin_bit_cast(float, hi.x << 16), rb = b - __builtin_bit_cast(float, hi.x & 0xffff0000u);
+    const float rc = c - __builtin_bit_cast(float, hi.y << 16), rd = d - __builtin_bit_cast(float, hi.y & 0xffff0000u);
+    mid.x = pk2_6(ra, rb);
+    mid.y = pk2_6(rc, rd);
+    asm("" : "+v"(mid.x), "+v"(mid.y));
+    lo.x = pk2_6(ra - __builtin_bit_cast(float, mid.x << 16), rb - __builtin_bit_cast(float, mid.x & 0xffff0000u));
+    lo.y = pk2_6(rc - __builtin_bit_cast(float, mid.y << 16), rd - __builtin_bit_cast(float, mid.y & 0xffff0000u));
+}
+struct Frag3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Frag3 split8x3(const float (&x)[8]) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4x3_6(x[0], x[1], x[2], x[3], h0, m0, l0);
+    split4x3_6(x[4], x[5], x[6], x[7], h1, m1, l1);
+    Frag3 f;
+    f.h = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    f.m = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+    f.l = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    return f;
+}
+__device__ __forceinline__ f32x16 mfma6(const Frag3& a, const Frag3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+
+// ---- staging: a [64 rows][64] fp32 tile -> registers (thread: 4 consecutive rows x 4 consecutive d) -> three-plane image
+struct Stage6 { float4 v[4]; };
+__device__ __forceinline__ void stage6_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid, Stage6& st) {
+    const int rb = tid >> 4, dq = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * rb + i;
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * ld + 4 * dq);
+        const bool ok = row < nrows;
+        st.v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
+}
+__device__ __forceinline__ void stage6_store(uint16_t* __restrict__ img, int tid, const Stage6& st, float mul) {
+    const int rb = tid >> 4, dq = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2 h, m, l;
+        split4x3_6(st.v[i].x * mul, st.v[i].y * mul, st.v[i].z * mul, st.v[i].w * mul, h, m, l);
+        const int off = (4 * rb + i) * LDR6 + 4 * dq;
+        *reinterpret_cast<uint2*>(img + off) = h;
+        *reinterpret_cast<uint2*>(img + PLANE6 + off) = m;
+        *reinterpret_cast<uint2*>(img + 2 * PLANE6 + off) = l;
+    }
+}
+
+// this lane's half of a global row as B-operand fragments over d: frag[ks] covers d = 16 ks + 8 hh + j
+__device__ __forceinline__ void row_frags6(const float* __restrict__ rowp, int hh, float mul, Frag3 (&f)[HD6 / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < HD6 / 16; ++ks) {
+        const float4 v0 = *reinterpret_cast<const float4*>(rowp + 16 * ks + 8 * hh);
+        const float4 v1 = *reinterpret_cast<const float4*>(rowp + 16 * ks + 8 * hh + 4);
+        const float x[8] = {v0.x * mul, v0.y * mul, v0.z * mul, v0.w * mul, v1.x * mul, v1.y * mul, v1.z * mul, v1.w * mul};
+        f[ks] = split8x3(x);
+    }
+}
+
+// acc (D[row = tile row][col = lane]) += image tile (A, rows sub*32 + l31, contraction over d) x register fragments (B)
+__device__ __forceinline__ f32x16 mma_rows6(const uint16_t* __restrict__ img, int sub, int l31, int hh,
+                                            const Frag3 (&b)[HD6 / 16], f32x16 acc) {
+    const int off = (sub * 32 + l31) * LDR6 + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < HD6 / 16; ++ks) {
+        Frag3 a;
+        a.h = *reinterpret_cast<const bf16x8*>(img + off + 16 * ks);
+        a.m = *reinterpret_cast<const bf16x8*>(img + PLANE6 + off + 16 * ks);
+        a.l = *reinterpret_cast<const bf16x8*>(img + 2 * PLANE6 + off + 16 * ks);
+        acc = mfma6(a, b[ks], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ v4s tr_read6(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 cat_frag6(v4s a, v4s b) {
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// acc[dt] (D[row = d][col = lane]) += sum over the 32 rows of sub-tile `sub` of  image[row][d] * w[row][lane]:
+// A operand = the image read TRANSPOSED (ds_read_b64_tr_b16: the 16-lane group (lane >> 4) covers d = 32 dt + 16 (group & 1) +
+// (lane & 15); the k slots of lane half hh are rows 16 s + 4 hh + {0..3} and + 8 - the rows registers 8s..8s+7 of w hold),
+// B operand = the accumulator registers w of a previous product, split three ways here
+__device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int sub, int lane, const f32x16& w, f32x16 (&acc)[2]) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float x[8] = {w[8 * s + 0], w[8 * s + 1], w[8 * s + 2], w[8 * s + 3], w[8 * s + 4], w[8 * s + 5], w[8 * s + 6], w[8 * s + 7]};
+        const Frag3 b = split8x3(x);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * LDR6 + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            Frag3 a;
+            a.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR6));
+            a.m = cat_frag6(tr_read6(img + PLANE6 + off), tr_read6(img + PLANE6 + off + 8 * LDR6));
+            a.l = cat_frag6(tr_read6(img + 2 * PLANE6 + off), tr_read6(img + 2 * PLANE6 + off + 8 * LDR6));
+            acc[dt] = mfma6(a, b, acc[dt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);          // K tile image
+    uint16_t* Vi = Ki + IMG6;                                   // V tile image
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD6;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
+    const int q = qt * QT + wv * 32 + l31;
+    const bool wave_live = qt * QT + wv * 32 < B;
+    const int qc = min(q, B - 1);
+
+    Frag3 qf[HD6 / 16];
+    row_frags6(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    Stage6 rk, rv;
+    const int nt = rlt_cdiv_dev(B, KT);
+    stage6_load(base + E, ld, 0, B, tid, rk);
+    stage6_load(base + 2 * E, ld, 0, B, tid, rv);
+    stage6_store(Ki, tid, rk, 1.f);
+    stage6_store(Vi, tid, rv, 1.f);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            stage6_load(base + E, ld, (t + 1) * KT, B, tid, rk);
+            stage6_load(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+        }
+        if (wave_live) {
+            f32x16 sc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
+                sc[sub] = mma_rows6(Ki, sub, l31, hh, qf, sc[sub]);            // S^T[key][q], log2 domain
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + sub * 32 + acc_row(r, hh);
+                    if (key >= B) sc[sub][r] = -INFINITY;
+                    tmax = fmaxf(tmax, sc[sub][r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = rlt_exp2(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = rlt_exp2(sc[sub][r] - m_new);
+                    sc[sub][r] = p;
+                    psum += p;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) mma_cols6(Vi, sub, lane, sc[sub], oacc);   // O^T[d][q] += V^T P^T
+        }
+        __syncthreads();                         // every wavefront is done with the tile
+        if (t + 1 < nt) {
+            stage6_store(Ki, tid, rk, 1.f);
+            stage6_store(Vi, tid, rv, 1.f);
+        }
+        __syncthreads();
+    }
+    if (!wave_live) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q < B) {
+        store_acc_T<HD6>(a.o + ((size_t)s * B + q) * E + h * HD6, hh, oacc, 1.f / l_tot);
+        if (hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_tot)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* Qi = reinterpret_cast<uint16_t*>(smem);          // Q tile image (unscaled: the scale sits in the K fragments)
+    uint16_t* Di = Qi + IMG6;                                   // dO tile image
+    float* Ls = reinterpret_cast<float*>(Di + IMG6);            // [KT] lse * log2e
+    float* Es = Ls + KT;                                        // [KT] delta
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD6;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, ktile;
+    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
+    const float* dobase = a.dout + (size_t)s * B * E + h * HD6;
+    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
+    const float* delbase = a.delta + ((size_t)s * H + h) * B;
+    const int key = ktile * QT + wv * 32 + l31;
+    const bool wave_live = ktile * QT + wv * 32 < B;
+    const int kc = min(key, B - 1);
+
+    Frag3 kf[HD6 / 16], vf[HD6 / 16];
+    row_frags6(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kf);
+    row_frags6(base + (size_t)kc * ld + 2 * E, hh, 1.f, vf);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+    Stage6 rq, rd;
+    float rl = 0.f, re = 0.f;
+    const int nt = rlt_cdiv_dev(B, KT);
+    auto load_small = [&](int row0) {
+        if (tid < KT) {
+            const int qi = row0 + tid, qc = min(qi, B - 1);
+            const float l = lsebase[qc], e = delbase[qc];
+            rl = qi < B ? l * LOG2E : 0.f;
+            re = qi < B ? e : 0.f;
+        }
+    };
+    stage6_load(base, ld, 0, B, tid, rq);
+    stage6_load(dobase, (size_t)E, 0, B, tid, rd);
+    load_small(0);
+    stage6_store(Qi, tid, rq, 1.f);
+    stage6_store(Di, tid, rd, 1.f);
+    if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            stage6_load(base, ld, (t + 1) * KT, B, tid, rq);
+            stage6_load(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
+            load_small((t + 1) * KT);
+        }
+        if (wave_live) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+                sc = mma_rows6(Qi, sub, l31, hh, kf, sc);               // S[q][key] (log2 domain)
+                dp = mma_rows6(Di, sub, l31, hh, vf, dp);               // dP[q][key]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + acc_row(r, hh);
+                    const bool ok = t * KT + ql < B;
+                    const float p = ok ? rlt_exp2(sc[r] - Ls[ql]) : 0.f;
+                    sc[r] = p;                                           // P (feeds dV)
+                    dp[r] = p * (dp[r] - Es[ql]);                        // dS
+                }
+                mma_cols6(Di, sub, lane, sc, dv);                        // dV^T[d][key] += dO^T P
+                mma_cols6(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nt) {
+            stage6_store(Qi, tid, rq, 1.f);
+            stage6_store(Di, tid, rd, 1.f);
+            if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
+        }
+        __syncthreads();
+    }
+    if (!wave_live || key >= B) return;
+    float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * HD6;
+    store_acc_T<HD6>(drow + E, hh, dk, a.scale);
+    store_acc_T<HD6>(drow + 2 * E, hh, dv, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Vi = Ki + IMG6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD6;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
+    const int q = qt * QT + wv * 32 + l31;
+    const bool wave_live = qt * QT + wv * 32 < B;
+    const int qc = min(q, B - 1);
+
+    Frag3 qf[HD6 / 16], dof[HD6 / 16];
+    row_frags6(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
+    row_frags6(a.dout + ((size_t)s * B + qc) * E + h * HD6, hh, 1.f, dof);
+    const float lse2 = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
+    const float del = a.delta[((size_t)s * H + h) * B + qc];
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    Stage6 rk, rv;
+    const int nt = rlt_cdiv_dev(B, KT);
+    stage6_load(base + E, ld, 0, B, tid, rk);
+    stage6_load(base + 2 * E, ld, 0, B, tid, rv);
+    stage6_store(Ki, tid, rk, 1.f);
+    stage6_store(Vi, tid, rv, 1.f);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            stage6_load(base + E, ld, (t + 1) * KT, B, tid, rk);
+            stage6_load(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+        }
+        if (wave_live) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+                sc = mma_rows6(Ki, sub, l31, hh, qf, sc);                // S^T[key][q]
+                dp = mma_rows6(Vi, sub, l31, hh, dof, dp);               // dP^T[key][q]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = t * KT + sub * 32 + acc_row(r, hh);
+                    const float p = kidx < B ? rlt_exp2(sc[r] - lse2) : 0.f;
+                    dp[r] = p * (dp[r] - del);                            // dS^T
+                }
+                mma_cols6(Ki, sub, lane, dp, dq);                         // dQ^T[d][q] += K^T dS^T
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nt) {
+            stage6_store(Ki, tid, rk, 1.f);
+            stage6_store(Vi, tid, rv, 1.f);
+        }
+        __syncthreads();
+    }
+    if (!wave_live || q >= B) return;
+    store_acc_T<HD6>(a.dqkv + ((size_t)s * B + q) * ld + h * HD6, hh, dq, a.scale);
+}
+
+}  // namespace
+
+// which: 0 forward, 1 dK/dV, 2 dQ.  Head dim 64, no dropout (the caller checks).
+int rlt_attn6_run(int which, const AttnArgs& a, hipStream_t st) {
+    const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
+    const size_t shm = (size_t)2 * IMG6 * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0);
+    int rc;
+    if (which == 0) {
+        if ((rc = rlt_allow_lds(attn6_fwd_kernel, shm))) return rc;
+        hipLaunchKernelGGL(attn6_fwd_kernel, dim3(grid), dim3(256), shm, st, a);
+    } else if (which == 1) {
+        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel, shm))) return rc;
+        hipLaunchKernelGGL(attn6_bwd_dkv_kernel, dim3(grid), dim3(256), shm, st, a);
+    } else {
+        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel, shm))) return rc;
+        hipLaunchKernelGGL(attn6_bwd_dq_kernel, dim3(grid), dim3(256), shm, st, a);
+    }
+    return RLT_LAUNCH_RESULT();
+}

@@ -89,27 +89,16 @@ def test_section(probe, name):
     _run(probe, name)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x6"])
 @pytest.mark.parametrize("name", MODE_DEPENDENT)
 def test_section_by_precision(probe, name, precision):
-    """Both MFMA precision modes of the library: the default split-bf16 mode and the exact-fp32 mode.
-    Model-level tolerances are identical in both; op-level MFMA tolerances are 6x looser for bf16x3
-    (tools/gpu_probe.py: mfma_tol)."""
+    """All three MFMA precision modes of the library: the default split-bf16 mode, the exact-fp32 mode and the
+    fp32-faithful six-product mode (bf16x6: GEMM family and the head-dim-64 list attention on an EXACT three-way bf16 split
+    of both operands, everything else on the exact-fp32 kernels).  Model-level tolerances are identical in all three;
+    op-level MFMA tolerances are 6x looser for bf16x3 ONLY (tools/gpu_probe.py: mfma_tol) - bf16x6 is held to the
+    exact-fp32 tolerances everywhere."""
     from rlt_hip import native
     native.set_precision(precision)
-    try:
-        _run(probe, name)
-    finally:
-        native.set_precision("bf16x3")
-
-
-@pytest.mark.parametrize("name", ["gemm", "scale_ops", "dropout", "models", "flip_aligned_grads", "full_size_kernels"])
-def test_section_fp32_faithful_gemm(probe, name):
-    """The third product mode, bf16x6: the GEMM family on an EXACT three-way bf16 split of both operands (six products, all
-    24 mantissa bits; csrc/gemm.hip gemm6_kernel), attention and BiLSTM on the exact-fp32 kernels.  Held to the EXACT-FP32
-    tolerances of every section that drives GEMMs (tools/gpu_probe.py: mfma_tol scales only for bf16x3)."""
-    from rlt_hip import native
-    native.set_precision("bf16x6")
     try:
         _run(probe, name)
     finally:
