@@ -15,6 +15,10 @@
 // image exists.  One LDS copy of a tile pair (55 KB): two workgroups per CU, their tile phases uncorrelated.
 #include "attention_common.h"
 
+#ifndef RLT_A6_DKV_PREFETCH
+#define RLT_A6_DKV_PREFETCH 0   // dK+dV kernel, 1: next tile's global loads issued BEFORE the tile body (32 staging registers live across it); measured 48.9 ms against 47.6 with the loads after the body (the partner workgroup covers their latency)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -194,15 +198,18 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
                 sc[sub] = mma_rows6(Ki, sub, l31, hh, qf, sc[sub]);            // S^T[key][q], log2 domain
             }
+            if ((t + 1) * KT > B) {               // keys beyond B exist in the last tile only (their rows are zero-filled)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
+            }
             float tmax = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KT + sub * 32 + acc_row(r, hh);
-                    if (key >= B) sc[sub][r] = -INFINITY;
-                    tmax = fmaxf(tmax, sc[sub][r]);
-                }
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = rlt_exp2(m_run - m_new);
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
+        if (RLT_A6_DKV_PREFETCH && t + 1 < nt) {
             stage6_load(base, ld, (t + 1) * KT, B, tid, rq);
             stage6_load(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
             load_small((t + 1) * KT);
@@ -304,6 +311,9 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
                 sc = mma_rows6(Qi, sub, l31, hh, kf, sc);               // S[q][key] (log2 domain)
                 dp = mma_rows6(Di, sub, l31, hh, vf, dp);               // dP[q][key]
+                // (seeding the accumulators with -lse / -delta, as attention3.hip does, saves two subtractions per score but
+                // rounds every partial sum at the magnitude of lse: measured 10-25 % more error against fp64 - not here; a
+                // last-tile-only branch for the row mask made hipcc duplicate the tile body and spill 86 registers)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
@@ -315,6 +325,11 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                 mma_cols6(Di, sub, lane, sc, dv);                        // dV^T[d][key] += dO^T P
                 mma_cols6(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
             }
+        }
+        if (!RLT_A6_DKV_PREFETCH && t + 1 < nt) {       // no registers held across the tile body; the partner workgroup covers the latency
+            stage6_load(base, ld, (t + 1) * KT, B, tid, rq);
+            stage6_load(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
+            load_small((t + 1) * KT);
         }
         __syncthreads();
         if (t + 1 < nt) {
@@ -380,10 +395,11 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
                 sc = mma_rows6(Ki, sub, l31, hh, qf, sc);                // S^T[key][q]
                 dp = mma_rows6(Vi, sub, l31, hh, dof, dp);               // dP^T[key][q]
+                const bool tail = (t + 1) * KT > B;                       // keys beyond B exist in the last tile only
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = t * KT + sub * 32 + acc_row(r, hh);
-                    const float p = kidx < B ? rlt_exp2(sc[r] - lse2) : 0.f;
+                    float p = rlt_exp2(sc[r] - lse2);
+                    if (tail && t * KT + sub * 32 + acc_row(r, hh) >= B) p = 0.f;
                     dp[r] = p * (dp[r] - del);                            // dS^T
                 }
                 mma_cols6(Ki, sub, lane, dp, dq);                         // dQ^T[d][q] += K^T dS^T
