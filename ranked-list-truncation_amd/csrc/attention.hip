@@ -501,11 +501,12 @@ static int attn_mode_any() {
 // exact-fp32 kernels in either mode (a correct, unhurried instantiation: it is not on a benchmarked configuration)
 static int attn_mode(int HD) { return HD <= 64 ? attn_mode_any() : 0; }
 static bool hd_ok(int HD) { return HD == 16 || HD == 32 || HD == 64 || HD == 128; }
-// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dim 64, no dropout); RLT_ATTN6=0 keeps the
+// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dim 64); RLT_ATTN6=0 keeps the
 // exact-fp32 kernels everywhere (A/B runs)
 static bool attn6_use(int HD, float drop_p) {
     static const bool on = [] { const char* e = getenv("RLT_ATTN6"); return !e || atoi(e) != 0; }();
-    return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD == 64 && drop_p == 0.f;
+    (void)drop_p;
+    return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD == 64;
 }
 
 extern "C" {

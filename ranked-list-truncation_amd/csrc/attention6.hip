@@ -6,8 +6,8 @@
 // what is dropped is <= 2^-26 |a b|, a quarter of an fp32 ulp of the product.  Six bf16 products cost 6/16 of one f32 MFMA
 // product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
 //
-// Head dim 64, no dropout (what the benchmark configurations of the AttnCut / MMOECut family run); every other case of the
-// mode stays on the exact-fp32 kernels.  Layout as in attention.hip: one wavefront owns 32 queries (32 keys in the dK/dV
+// Head dim 64 (the AttnCut / MMOECut family), with and without train-mode dropout; the other head dims of the mode stay on
+// the exact-fp32 kernels.  Layout as in attention.hip: one wavefront owns 32 queries (32 keys in the dK/dV
 // kernel), scores are produced TRANSPOSED so that the softmax is a per-lane loop over accumulator registers and the
 // probabilities are directly the B operand of the next product (registers 8s..8s+7 = k-step s).  Tiles of 64 rows are
 // split once per workgroup at staging time into [row][d] bf16 images (three planes, 144-byte rows); products that contract
@@ -151,10 +151,15 @@ __device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int 
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// DROP: train-mode dropout of the attention probabilities (same counter-based masks as the other two kernel families:
+// keep(pair seed, query, key) = row_hash(query) * col_hash(key) >= threshold; the hashes of a tile's rows / keys sit in a
+// 64-entry LDS table written at staging time, the lane's own hash in a register)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);          // K tile image
     uint16_t* Vi = Ki + IMG6;                                   // V tile image
+    uint32_t* htab = reinterpret_cast<uint32_t*>(Vi + IMG6);    // [KT] column hashes of the tile's keys (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD6;
     const size_t ld = (size_t)3 * E;
@@ -177,12 +182,16 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     Stage6 rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
     stage6_load(base + E, ld, 0, B, tid, rk);
     stage6_load(base + 2 * E, ld, 0, B, tid, rv);
     stage6_store(Ki, tid, rk, 1.f);
     stage6_store(Vi, tid, rv, 1.f);
+    if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
@@ -224,6 +233,13 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
                 }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (DROP) {                          // dropout acts on the normalised probabilities: the normaliser keeps all keys
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sc[sub][r] = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
+            }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
         if (t + 1 < nt) {
             stage6_store(Ki, tid, rk, 1.f);
             stage6_store(Vi, tid, rv, 1.f);
+            if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
     }
@@ -247,12 +264,14 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Qi = reinterpret_cast<uint16_t*>(smem);          // Q tile image (unscaled: the scale sits in the K fragments)
     uint16_t* Di = Qi + IMG6;                                   // dO tile image
     float* Ls = reinterpret_cast<float*>(Di + IMG6);            // [KT] lse * log2e
     float* Es = Ls + KT;                                        // [KT] delta
+    uint32_t* htab = reinterpret_cast<uint32_t*>(Es + KT);      // [KT] row hashes of the tile's queries (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD6;
     const size_t ld = (size_t)3 * E;
@@ -278,6 +297,9 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     Stage6 rq, rd;
     float rl = 0.f, re = 0.f;
     const int nt = rlt_cdiv_dev(B, KT);
@@ -295,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     stage6_store(Qi, tid, rq, 1.f);
     stage6_store(Di, tid, rd, 1.f);
     if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
+    if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
@@ -319,8 +342,14 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                     const int ql = sub * 32 + acc_row(r, hh);
                     const bool ok = t * KT + ql < B;
                     const float p = ok ? rlt_exp2(sc[r] - Ls[ql]) : 0.f;
-                    sc[r] = p;                                           // P (feeds dV)
-                    dp[r] = p * (dp[r] - Es[ql]);                        // dS
+                    float pd = p, dpr = dp[r];
+                    if (DROP) {
+                        const float m = rlt_keep_rc(htab[ql], hk, a.drop_thr) ? inv_keep : 0.f;
+                        pd = p * m;
+                        dpr *= m;
+                    }
+                    sc[r] = pd;                                          // (dropped) P (feeds dV)
+                    dp[r] = p * (dpr - Es[ql]);                          // dS
                 }
                 mma_cols6(Di, sub, lane, sc, dv);                        // dV^T[d][key] += dO^T P
                 mma_cols6(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
@@ -336,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
             stage6_store(Qi, tid, rq, 1.f);
             stage6_store(Di, tid, rd, 1.f);
             if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
+            if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
     }
@@ -346,10 +376,12 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vi = Ki + IMG6;
+    uint32_t* htab = reinterpret_cast<uint32_t*>(Vi + IMG6);    // [KT] column hashes of the tile's keys (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD6;
     const size_t ld = (size_t)3 * E;
@@ -374,12 +406,16 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     Stage6 rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
     stage6_load(base + E, ld, 0, B, tid, rk);
     stage6_load(base + 2 * E, ld, 0, B, tid, rv);
     stage6_store(Ki, tid, rk, 1.f);
     stage6_store(Vi, tid, rv, 1.f);
+    if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
@@ -400,7 +436,9 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     float p = rlt_exp2(sc[r] - lse2);
                     if (tail && t * KT + sub * 32 + acc_row(r, hh) >= B) p = 0.f;
-                    dp[r] = p * (dp[r] - del);                            // dS^T
+                    float dpr = dp[r];
+                    if (DROP) dpr = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? dpr * inv_keep : 0.f;
+                    dp[r] = p * (dpr - del);                              // dS^T
                 }
                 mma_cols6(Ki, sub, lane, dp, dq);                         // dQ^T[d][q] += K^T dS^T
             }
@@ -409,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
         if (t + 1 < nt) {
             stage6_store(Ki, tid, rk, 1.f);
             stage6_store(Vi, tid, rv, 1.f);
+            if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
     }
@@ -418,20 +457,26 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
 
 }  // namespace
 
-// which: 0 forward, 1 dK/dV, 2 dQ.  Head dim 64, no dropout (the caller checks).
-int rlt_attn6_run(int which, const AttnArgs& a, hipStream_t st) {
+template <bool DROP>
+static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    const size_t shm = (size_t)2 * IMG6 * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0);
+    const size_t shm = (size_t)2 * IMG6 * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
     int rc;
     if (which == 0) {
-        if ((rc = rlt_allow_lds(attn6_fwd_kernel, shm))) return rc;
-        hipLaunchKernelGGL(attn6_fwd_kernel, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_fwd_kernel<DROP>, shm))) return rc;
+        hipLaunchKernelGGL(attn6_fwd_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
     } else if (which == 1) {
-        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel, shm))) return rc;
-        hipLaunchKernelGGL(attn6_bwd_dkv_kernel, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel<DROP>, shm))) return rc;
+        hipLaunchKernelGGL(attn6_bwd_dkv_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
     } else {
-        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel, shm))) return rc;
-        hipLaunchKernelGGL(attn6_bwd_dq_kernel, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel<DROP>, shm))) return rc;
+        hipLaunchKernelGGL(attn6_bwd_dq_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
     }
     return RLT_LAUNCH_RESULT();
+}
+
+// which: 0 forward, 1 dK/dV, 2 dQ.  Head dim 64 (the caller checks).  Dropout is a template parameter: hipcc if-converts a
+// run-time `drop_p > 0` test and executes the hashes regardless.
+int rlt_attn6_run(int which, const AttnArgs& a, hipStream_t st) {
+    return a.drop_p > 0.f ? attn6_launch<true>(which, a, st) : attn6_launch<false>(which, a, st);
 }
