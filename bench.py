@@ -425,7 +425,7 @@ def main():
     DTYPES = {"fp32": "f32",
               "bf16x3": "f32 storage and accumulation; MFMA products split into 3 bf16 products (hi*hi + hi*lo + lo*hi, ~16 operand mantissa bits)",
               "bf16x6": "f32 storage and accumulation; GEMM and list-attention products from an EXACT 3-way bf16 split of both operands (all 24 "
-                        "mantissa bits, 6 bf16 MFMA products, dropped terms <= 2^-26 of the product); BiLSTM recurrences on the f32 MFMA"}
+                        "mantissa bits, 6 bf16 MFMA products, dropped terms < 2^-23 of the product worst case, 2^-29 typical); BiLSTM recurrences on the f32 MFMA"}
     main_res = run_mode(precision, args.steps, args.warmup)
     other_res = run_mode(other, args.other_steps, 1) if args.other_steps > 0 else None
     # the fp32-faithful GEMM mode: timed beside the headline, never the headline itself

@@ -44,7 +44,7 @@ int rlt_abi_version(void);
  *                        MFMA with fp32 accumulation (~2^-16 relative error per product, ~2x faster end to end)
  *   RLT_PRECISION_BF16X6 fp32-FAITHFUL products on the bf16 MFMA for the rlt_gemm* family: every operand split
  *                        exactly into three bf16 values (8 + 8 + 8 significand bits), six of the nine partial
- *                        products kept, what is dropped is <= 2^-26 of the product (a quarter of an fp32 ulp) -
+ *                        products kept, what is dropped is < 2^-23 of the product in the worst case (under one fp32 ulp; 2^-29 typical) -
  *                        all 24 operand bits, held to the FP32 mode's tolerances in the tests; attention and the
  *                        BiLSTM recurrences run their exact-fp32 kernels in this mode
  * Default: BF16X3; the environment variable RLT_PRECISION=fp32|bf16x3|bf16x6 selects it at first use. */

@@ -3,7 +3,8 @@
 // kernels of attention.hip, but every MFMA product a*b is evaluated from an EXACT three-way bf16 split of both operands,
 //   x = h + m + l  (h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits),
 //   a*b ~ m*m' + l*h' + h*l' + m*h' + h*m' + h*h'   (six v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest first);
-// what is dropped is <= 2^-26 |a b|, a quarter of an fp32 ulp of the product.  Six bf16 products cost 6/16 of one f32 MFMA
+// what is dropped is < 2^-23 |a b| in the worst case, 2^-29 typically (tests/test_split6.py): under one fp32 ulp of the
+// product.  Six bf16 products cost 6/16 of one f32 MFMA
 // product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
 //
 // Head dim 64 (the AttnCut / MMOECut family), with and without train-mode dropout; the other head dims of the mode stay on

@@ -968,7 +968,8 @@ int launch_gemm3b(GemmArgs g, int ns, hipStream_t st) {
 // x = h + m + l (h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits, the last residual is exactly
 // representable), and a*b is evaluated as the six products  h*h' + h*m' + m*h' + h*l' + l*h' + m*m'  on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each of them is exact in the matrix pipe (8 x 8 bits); what is dropped
-// (m*l' + l*m' + l*l') is at most 2^-26 |a b| - a quarter of an fp32 ulp of the product, below the rounding of the fp32
+// (m*l' + l*m' + l*l') is below 2^-23 |a b| in the worst case (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|; over random operands the largest is
+// 2^-24.3, the median 2^-29: tests/test_split6.py) - under one fp32 ulp of the product, of the size of the rounding of the fp32
 // accumulation itself (2^-24 of the running sum) that the f32 MFMA kernel above pays as well.  So the result carries the
 // full 24 operand bits, where bf16x3 carries 16: the mode is held to the EXACT-FP32 tolerances in the tests.  Six
 // products cost 2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3 of the f32 MFMA.
