@@ -74,13 +74,21 @@ __device__ __forceinline__ f32x16 mma_tile_rows(const float* __restrict__ tile, 
                                                 const float (&regs)[HD / 2], f32x16 acc) {
     constexpr int LD = HD + 4;
     const float* rp = tile + (sub * 32 + l31) * LD + hh * (HD / 2);
+    // the A operands of group j+1 are read from LDS BEFORE the four MFMAs of group j: hipcc otherwise issues each read right
+    // in front of its MFMAs and waits out the LDS latency once per group (ISA: `D W M4 D W M4 ...`; round 3: dK+dV 82.9 ->
+    // 79.4 ms, 256 registers + scratch -> 240.  Chaining the first group of the NEXT product into the current one as well:
+    // no further gain, not kept)
+    float4 a = *reinterpret_cast<const float4*>(rp);
 #pragma unroll
     for (int j = 0; j < HD / 8; ++j) {
-        const float4 a = *reinterpret_cast<const float4*>(rp + 4 * j);
+        float4 an = a;
+        if (j + 1 < HD / 8) an = *reinterpret_cast<const float4*>(rp + 4 * (j + 1));
+        __builtin_amdgcn_sched_barrier(0);
         acc = mfma32(a.x, regs[4 * j + 0], acc);
         acc = mfma32(a.y, regs[4 * j + 1], acc);
         acc = mfma32(a.z, regs[4 * j + 2], acc);
         acc = mfma32(a.w, regs[4 * j + 3], acc);
+        a = an;
     }
     return acc;
 }
@@ -97,10 +105,21 @@ __device__ __forceinline__ void mma_tile_cols(const float* __restrict__ tile, in
         const int d = dt * 32 + l31;
         const bool ok = d < HD;
         const float* cp = tile + (sub * 32 + 4 * hh) * LD + (ok ? d : 0);
+        // operands of the next four MFMAs read ahead of the current four (see mma_tile_rows)
+        float a[4], an[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = ok ? cp[((r & 3) + 8 * (r >> 2)) * LD] : 0.f;
-            acc[dt] = mfma32(a, w[r], acc[dt]);
+        for (int i = 0; i < 4; ++i) a[i] = cp[(i + 8 * 0) * LD];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = cp[(i + 8 * (g + 1)) * LD];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[dt] = mfma32(ok ? a[i] : 0.f, w[4 * g + i], acc[dt]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = an[i];
         }
     }
 }
