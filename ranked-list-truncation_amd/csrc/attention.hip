@@ -125,12 +125,15 @@ __device__ __forceinline__ void mma_tile_cols(const float* __restrict__ tile, in
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+// SB ("single buffer", head dim 64): ONE LDS copy of the K / V tile (35 KB per workgroup) and a 168-register cap, so that THREE
+// workgroups = three wavefronts per SIMD share a CU instead of two (the double-buffered form needs 70 KB); the price is a
+// second barrier per tile, which two other workgroups on the SIMD cover.
+template <int HD, bool DROP, bool SB>
+__global__ __launch_bounds__(256, SB ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32, NB = SB ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                       // [2][KT*LD]
-    float* Vs = smem + 2 * KT * LD;         // [2][KT*LD]
+    float* Ks = smem;                       // [NB][KT*LD]
+    float* Vs = smem + NB * KT * LD;        // [NB][KT*LD]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
@@ -162,8 +165,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) {
+        const int buf = SB ? 0 : (t & 1);
+        if (!SB && t + 1 < nt) {
             tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
             tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
@@ -221,9 +224,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) mma_tile_cols<HD>(vt_, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
         }
+        if (SB) {                                // loads after the tile body (no staging registers live across it), then swap
+            if (t + 1 < nt) {
+                tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+                tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+            }
+            __syncthreads();
+        }
         if (t + 1 < nt) {
-            tile_store<HD>(Ks + (buf ^ 1) * KT * LD, tid, rk);
-            tile_store<HD>(Vs + (buf ^ 1) * KT * LD, tid, rv);
+            tile_store<HD>(Ks + (SB ? 0 : (buf ^ 1)) * KT * LD, tid, rk);
+            tile_store<HD>(Vs + (SB ? 0 : (buf ^ 1)) * KT * LD, tid, rv);
         }
         __syncthreads();
     }
@@ -358,12 +368,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-    constexpr int LD = HD + 4, DT = (HD + 31) / 32;
+template <int HD, bool DROP, bool SB>
+__global__ __launch_bounds__(256, SB ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int LD = HD + 4, DT = (HD + 31) / 32, NB = SB ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
-    float* Vs = smem + 2 * KT * LD;
+    float* Vs = smem + NB * KT * LD;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
@@ -397,8 +407,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) {
+        const int buf = SB ? 0 : (t & 1);
+        if (!SB && t + 1 < nt) {
             tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
             tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
@@ -424,9 +434,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 mma_tile_cols<HD>(kt_, sub, l31, hh, dp, dq);             // dQ^T[d][q] += K^T dS^T
             }
         }
+        if (SB) {
+            if (t + 1 < nt) {
+                tile_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+                tile_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+            }
+            __syncthreads();
+        }
         if (t + 1 < nt) {
-            tile_store<HD>(Ks + (buf ^ 1) * KT * LD, tid, rk);
-            tile_store<HD>(Vs + (buf ^ 1) * KT * LD, tid, rv);
+            tile_store<HD>(Ks + (SB ? 0 : (buf ^ 1)) * KT * LD, tid, rk);
+            tile_store<HD>(Vs + (SB ? 0 : (buf ^ 1)) * KT * LD, tid, rv);
         }
         __syncthreads();
     }
@@ -434,15 +451,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
 }
 
-template <int HD> size_t fwd_smem() { return (size_t)4 * KT * (HD + 4) * sizeof(float); }
+template <int HD> size_t fwd_smem(bool sb = false) { return (size_t)(sb ? 2 : 4) * KT * (HD + 4) * sizeof(float); }
+// head dim 64 forward / dQ: the single-buffer, three-workgroups-per-CU form (RLT_ATTN_SB=0: the double-buffered one)
+static bool attn_sb() {
+    static const bool v = [] { const char* e = getenv("RLT_ATTN_SB"); return !e || atoi(e) != 0; }();
+    return v;
+}
 template <int HD> size_t dkv_smem() { return (size_t)(4 * KT * (HD + 4) + 4 * KT) * sizeof(float); }
 
 template <int HD, bool DROP>
 int launch_fwd_t(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    int rc = rlt_allow_lds(attn_fwd_kernel<HD, DROP>, fwd_smem<HD>());
+    if (HD == 64 && attn_sb()) {
+        int rc = rlt_allow_lds(attn_fwd_kernel<HD, DROP, true>, fwd_smem<HD>(true));
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, DROP, true>), dim3(grid), dim3(256), fwd_smem<HD>(true), st, a);
+        return RLT_LAUNCH_RESULT();
+    }
+    int rc = rlt_allow_lds(attn_fwd_kernel<HD, DROP, false>, fwd_smem<HD>());
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, DROP>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, DROP, false>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
     return RLT_LAUNCH_RESULT();
 }
 template <int HD, bool DROP>
@@ -463,9 +491,15 @@ int launch_dkv_t(const AttnArgs& a, hipStream_t st) {
 template <int HD, bool DROP>
 int launch_dq_t(const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD, DROP>, fwd_smem<HD>());
+    if (HD == 64 && attn_sb() && getenv("RLT_ATTN_SB_DQ")) {       // (at the 168-register cap the dQ kernel spills 80 registers: off)
+        int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD, DROP, true>, fwd_smem<HD>(true));
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP, true>), dim3(grid), dim3(256), fwd_smem<HD>(true), st, a);
+        return RLT_LAUNCH_RESULT();
+    }
+    int rc = rlt_allow_lds(attn_bwd_dq_kernel<HD, DROP, false>, fwd_smem<HD>());
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP, false>), dim3(grid), dim3(256), fwd_smem<HD>(), st, a);
     return RLT_LAUNCH_RESULT();
 }
 // dropout is a template parameter: hipcc if-converts a run-time `drop_p > 0` test and executes the hash regardless
