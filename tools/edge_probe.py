@@ -15,7 +15,7 @@ from rlt_hip import native as N
 
 dev = torch.device("cuda")
 bad = 0
-for prec in ("bf16x3", "fp32"):
+for prec in ("bf16x3", "fp32", "bf16x6"):
     N.set_precision(prec)
     for name, kw, B, S, F in [("AttnCut", {}, 2, 5, 3), ("AttnCut", {}, 33, 64, 3), ("AttnCut", {"input_size": 2}, 7, 11, 2),
                               ("AttnCut", {"input_size": 5}, 4, 9, 5), ("Choopy", {"seq_len": 7}, 3, 7, 1),
