@@ -377,10 +377,10 @@ def main():
         (`executed_bf16_tflops` / 2500 is the same fraction).  DESIGN.md section 5."""
         mode, ksum, sec = res["mode"], res["ksum"], res["ms_per_step"] * 1e-3
         launches, ms = ksum.get("attn_bwd_dkv", (0, float("nan")))
-        x6_attn = mode == "bf16x6" and hd == 64 and os.environ.get("RLT_ATTN6", "1") != "0"
+        x6_attn = mode == "bf16x6" and hd <= 64 and os.environ.get("RLT_ATTN6", "1") != "0"
         if x6_attn:                               # six bf16 MFMA products per fp32 product: peak 2500 / 6
-            kern, mult, peak = f"attn6_bwd_dkv_kernel<{drop_tag}>", 6, PEAK_BF16_MFMA_TFLOPS
-        elif mode in ("fp32", "bf16x6"):          # bf16x6 at other head dims: the exact-fp32 kernels
+            kern, mult, peak = f"attn6_bwd_dkv_kernel<{hd},{drop_tag}>", 6, PEAK_BF16_MFMA_TFLOPS
+        elif mode in ("fp32", "bf16x6"):          # (bf16x6 with RLT_ATTN6=0: the exact-fp32 kernels)
             kern, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 1, PEAK_F32_MFMA_TFLOPS
         else:
             kern, mult, peak = f"attn3_bwd_dkv_kernel<{hd},{drop_tag}>", 3, PEAK_BF16_MFMA_TFLOPS

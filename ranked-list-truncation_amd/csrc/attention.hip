@@ -554,12 +554,12 @@ static int attn_mode_any() {
 // exact-fp32 kernels in either mode (a correct, unhurried instantiation: it is not on a benchmarked configuration)
 static int attn_mode(int HD) { return HD <= 64 ? attn_mode_any() : 0; }
 static bool hd_ok(int HD) { return HD == 16 || HD == 32 || HD == 64 || HD == 128; }
-// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dim 64); RLT_ATTN6=0 keeps the
+// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dims 16 / 32 / 64); RLT_ATTN6=0 keeps the
 // exact-fp32 kernels everywhere (A/B runs)
 static bool attn6_use(int HD, float drop_p) {
     static const bool on = [] { const char* e = getenv("RLT_ATTN6"); return !e || atoi(e) != 0; }();
     (void)drop_p;
-    return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD == 64;
+    return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD <= 64;
 }
 
 extern "C" {
@@ -606,7 +606,7 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
         if (!rlt_aligned16(images)) return RLT_E_ALIGN;
         return rlt_attn3_run(0, a, HD, images, nullptr, st);
     }
-    if (attn6_use(HD, drop_p)) return rlt_attn6_run(0, a, st);
+    if (attn6_use(HD, drop_p)) return rlt_attn6_run(0, a, HD, st);
     if (HD == 128) return launch_fwd<128>(a, st);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
@@ -654,7 +654,7 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     hipStream_t st = rlt_stream(stream);
     if (attn_mode(HD) == 1 && images)
         return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
-    if (attn6_use(HD, drop_p)) return rlt_attn6_run(which, a, st);
+    if (attn6_use(HD, drop_p)) return rlt_attn6_run(which, a, HD, st);
     if (which == 1) {
         if (HD == 128) return launch_dkv<128>(a, st);
         if (HD == 64) return launch_dkv<64>(a, st);

@@ -7,8 +7,8 @@
 // product.  Six bf16 products cost 6/16 of one f32 MFMA
 // product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
 //
-// Head dim 64 (the AttnCut / MMOECut family), with and without train-mode dropout; the other head dims of the mode stay on
-// the exact-fp32 kernels.  Layout as in attention.hip: one wavefront owns 32 queries (32 keys in the dK/dV
+// Head dims 64 (the AttnCut / MMOECut family), 32 and 16 (Choopy / MtChoopy), with and without train-mode dropout; head dim
+// 128 (PLECut) stays on the exact-fp32 kernels in that mode.  Layout as in attention.hip: one wavefront owns 32 queries (32 keys in the dK/dV
 // kernel), scores are produced TRANSPOSED so that the softmax is a per-lane loop over accumulator registers and the
 // probabilities are directly the B operand of the next product (registers 8s..8s+7 = k-step s).  Tiles of 64 rows are
 // split once per workgroup at staging time into [row][d] bf16 images (three planes, 144-byte rows); products that contract
@@ -25,10 +25,11 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 
-constexpr int HD6 = 64;
-constexpr int LDR6 = HD6 + 8;                  // bf16 elements per image row (144 bytes: 16-byte aligned fragments)
-constexpr int PLANE6 = KT * LDR6;              // elements per plane
-constexpr int IMG6 = 3 * PLANE6;               // one tile image: [h | m | l]
+// per head dim: bf16 elements per image row (HD + 8: 16-byte aligned fragments, rows 16 bytes apart in the banks), per plane,
+// per tile image [h | m | l]
+template <int HD> constexpr int ldr6() { return HD + 8; }
+template <int HD> constexpr int plane6() { return KT * (HD + 8); }
+template <int HD> constexpr int img6() { return 3 * KT * (HD + 8); }
 
 __device__ __forceinline__ uint32_t pk2_6(float a, float b) {
     typedef __bf16 v2 __attribute__((ext_vector_type(2)));
@@ -69,35 +70,38 @@ __device__ __forceinline__ f32x16 mfma6(const Frag3& a, const Frag3& b, f32x16 c
     return c;
 }
 
-// ---- staging: a [64 rows][64] fp32 tile -> registers (thread: 4 consecutive rows x 4 consecutive d) -> three-plane image
-struct Stage6 { float4 v[4]; };
-__device__ __forceinline__ void stage6_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid, Stage6& st) {
-    const int rb = tid >> 4, dq = tid & 15;
+// ---- staging: a [64 rows][HD] fp32 tile -> registers (HD / 16 float4 per thread) -> three-plane image
+template <int HD> struct Stage6 { float4 v[HD / 16]; };
+template <int HD>
+__device__ __forceinline__ void stage6_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid, Stage6<HD>& st) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * rb + i;
+    for (int i = 0; i < HD / 16; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = row0 + idx / (HD / 4), dq = idx % (HD / 4);
         const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * ld + 4 * dq);
         const bool ok = row < nrows;
         st.v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
 }
-__device__ __forceinline__ void stage6_store(uint16_t* __restrict__ img, int tid, const Stage6& st, float mul) {
-    const int rb = tid >> 4, dq = tid & 15;
+template <int HD>
+__device__ __forceinline__ void stage6_store(uint16_t* __restrict__ img, int tid, const Stage6<HD>& st, float mul) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < HD / 16; ++i) {
+        const int idx = tid + 256 * i;
         uint2 h, m, l;
         split4x3_6(st.v[i].x * mul, st.v[i].y * mul, st.v[i].z * mul, st.v[i].w * mul, h, m, l);
-        const int off = (4 * rb + i) * LDR6 + 4 * dq;
+        const int off = (idx / (HD / 4)) * ldr6<HD>() + 4 * (idx % (HD / 4));
         *reinterpret_cast<uint2*>(img + off) = h;
-        *reinterpret_cast<uint2*>(img + PLANE6 + off) = m;
-        *reinterpret_cast<uint2*>(img + 2 * PLANE6 + off) = l;
+        *reinterpret_cast<uint2*>(img + plane6<HD>() + off) = m;
+        *reinterpret_cast<uint2*>(img + 2 * plane6<HD>() + off) = l;
     }
 }
 
 // this lane's half of a global row as B-operand fragments over d: frag[ks] covers d = 16 ks + 8 hh + j
-__device__ __forceinline__ void row_frags6(const float* __restrict__ rowp, int hh, float mul, Frag3 (&f)[HD6 / 16]) {
+template <int HD>
+__device__ __forceinline__ void row_frags6(const float* __restrict__ rowp, int hh, float mul, Frag3 (&f)[HD / 16]) {
 #pragma unroll
-    for (int ks = 0; ks < HD6 / 16; ++ks) {
+    for (int ks = 0; ks < HD / 16; ++ks) {
         const float4 v0 = *reinterpret_cast<const float4*>(rowp + 16 * ks + 8 * hh);
         const float4 v1 = *reinterpret_cast<const float4*>(rowp + 16 * ks + 8 * hh + 4);
         const float x[8] = {v0.x * mul, v0.y * mul, v0.z * mul, v0.w * mul, v1.x * mul, v1.y * mul, v1.z * mul, v1.w * mul};
@@ -106,15 +110,16 @@ __device__ __forceinline__ void row_frags6(const float* __restrict__ rowp, int h
 }
 
 // acc (D[row = tile row][col = lane]) += image tile (A, rows sub*32 + l31, contraction over d) x register fragments (B)
+template <int HD>
 __device__ __forceinline__ f32x16 mma_rows6(const uint16_t* __restrict__ img, int sub, int l31, int hh,
-                                            const Frag3 (&b)[HD6 / 16], f32x16 acc) {
-    const int off = (sub * 32 + l31) * LDR6 + 8 * hh;
+                                            const Frag3 (&b)[HD / 16], f32x16 acc) {
+    const int off = (sub * 32 + l31) * ldr6<HD>() + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < HD6 / 16; ++ks) {
+    for (int ks = 0; ks < HD / 16; ++ks) {
         Frag3 a;
         a.h = *reinterpret_cast<const bf16x8*>(img + off + 16 * ks);
-        a.m = *reinterpret_cast<const bf16x8*>(img + PLANE6 + off + 16 * ks);
-        a.l = *reinterpret_cast<const bf16x8*>(img + 2 * PLANE6 + off + 16 * ks);
+        a.m = *reinterpret_cast<const bf16x8*>(img + plane6<HD>() + off + 16 * ks);
+        a.l = *reinterpret_cast<const bf16x8*>(img + 2 * plane6<HD>() + off + 16 * ks);
         acc = mfma6(a, b[ks], acc);
     }
     return acc;
@@ -132,20 +137,25 @@ __device__ __forceinline__ bf16x8 cat_frag6(v4s a, v4s b) {
 // A operand = the image read TRANSPOSED (ds_read_b64_tr_b16: the 16-lane group (lane >> 4) covers d = 32 dt + 16 (group & 1) +
 // (lane & 15); the k slots of lane half hh are rows 16 s + 4 hh + {0..3} and + 8 - the rows registers 8s..8s+7 of w hold),
 // B operand = the accumulator registers w of a previous product, split three ways here
-__device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int sub, int lane, const f32x16& w, f32x16 (&acc)[2]) {
+// Head dim 16: the 32-row MFMA output has 16 rows to spare; the lanes that would supply d = 16..31 read d - 16 again (a
+// valid address) and their output rows are never stored.
+template <int HD>
+__device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int sub, int lane, const f32x16& w,
+                                          f32x16 (&acc)[(HD + 31) / 32]) {
+    constexpr int DT = (HD + 31) / 32, LDR = ldr6<HD>(), PL = plane6<HD>();
     const int hh = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const float x[8] = {w[8 * s + 0], w[8 * s + 1], w[8 * s + 2], w[8 * s + 3], w[8 * s + 4], w[8 * s + 5], w[8 * s + 6], w[8 * s + 7]};
         const Frag3 b = split8x3(x);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
-            const int off = row * LDR6 + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int off = row * LDR + 32 * dt + (HD >= 32 ? 16 * ((lane >> 4) & 1) : 0) + 4 * (lane & 3);
             Frag3 a;
-            a.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR6));
-            a.m = cat_frag6(tr_read6(img + PLANE6 + off), tr_read6(img + PLANE6 + off + 8 * LDR6));
-            a.l = cat_frag6(tr_read6(img + 2 * PLANE6 + off), tr_read6(img + 2 * PLANE6 + off + 8 * LDR6));
+            a.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR));
+            a.m = cat_frag6(tr_read6(img + PL + off), tr_read6(img + PL + off + 8 * LDR));
+            a.l = cat_frag6(tr_read6(img + 2 * PL + off), tr_read6(img + 2 * PL + off + 8 * LDR));
             acc[dt] = mfma6(a, b, acc[dt]);
         }
     }
@@ -155,30 +165,31 @@ __device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int 
 // DROP: train-mode dropout of the attention probabilities (same counter-based masks as the other two kernel families:
 // keep(pair seed, query, key) = row_hash(query) * col_hash(key) >= threshold; the hashes of a tile's rows / keys sit in a
 // 64-entry LDS table written at staging time, the lane's own hash in a register)
-template <bool DROP>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
+    constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);          // K tile image
     uint16_t* Vi = Ki + IMG6;                                   // V tile image
     uint32_t* htab = reinterpret_cast<uint32_t*>(Vi + IMG6);    // [KT] column hashes of the tile's keys (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD6;
+    const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
     const int ntile = rlt_cdiv_dev(B, QT);
     int pair, qt;
     map_block(blockIdx.x, a.S * H, ntile, pair, qt);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
     const int q = qt * QT + wv * 32 + l31;
     const bool wave_live = qt * QT + wv * 32 < B;
     const int qc = min(q, B - 1);
 
-    Frag3 qf[HD6 / 16];
-    row_frags6(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
+    Frag3 qf[HD / 16];
+    row_frags6<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
 
-    f32x16 oacc[2];
+    f32x16 oacc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -186,19 +197,19 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-    Stage6 rk, rv;
+    Stage6<HD> rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
-    stage6_load(base + E, ld, 0, B, tid, rk);
-    stage6_load(base + 2 * E, ld, 0, B, tid, rv);
-    stage6_store(Ki, tid, rk, 1.f);
-    stage6_store(Vi, tid, rv, 1.f);
+    stage6_load<HD>(base + E, ld, 0, B, tid, rk);
+    stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+    stage6_store<HD>(Ki, tid, rk, 1.f);
+    stage6_store<HD>(Vi, tid, rv, 1.f);
     if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) {
-            stage6_load(base + E, ld, (t + 1) * KT, B, tid, rk);
-            stage6_load(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+            stage6_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+            stage6_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
         if (wave_live) {
             f32x16 sc[2];
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
-                sc[sub] = mma_rows6(Ki, sub, l31, hh, qf, sc[sub]);            // S^T[key][q], log2 domain
+                sc[sub] = mma_rows6<HD>(Ki, sub, l31, hh, qf, sc[sub]);            // S^T[key][q], log2 domain
             }
             if ((t + 1) * KT > B) {               // keys beyond B exist in the last tile only (their rows are zero-filled)
 #pragma unroll
@@ -242,16 +253,16 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
                         sc[sub][r] = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
             }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) mma_cols6(Vi, sub, lane, sc[sub], oacc);   // O^T[d][q] += V^T P^T
+            for (int sub = 0; sub < 2; ++sub) mma_cols6<HD>(Vi, sub, lane, sc[sub], oacc);   // O^T[d][q] += V^T P^T
         }
         __syncthreads();                         // every wavefront is done with the tile
         if (t + 1 < nt) {
-            stage6_store(Ki, tid, rk, 1.f);
-            stage6_store(Vi, tid, rv, 1.f);
+            stage6_store<HD>(Ki, tid, rk, 1.f);
+            stage6_store<HD>(Vi, tid, rv, 1.f);
             if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
@@ -259,14 +270,15 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     if (!wave_live) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (q < B) {
-        store_acc_T<HD6>(a.o + ((size_t)s * B + q) * E + h * HD6, hh, oacc, 1.f / l_tot);
+        store_acc_T<HD>(a.o + ((size_t)s * B + q) * E + h * HD, hh, oacc, 1.f / l_tot);
         if (hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_tot)) * LN2;
     }
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <bool DROP>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Qi = reinterpret_cast<uint16_t*>(smem);          // Q tile image (unscaled: the scale sits in the K fragments)
     uint16_t* Di = Qi + IMG6;                                   // dO tile image
@@ -274,34 +286,34 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     float* Es = Ls + KT;                                        // [KT] delta
     uint32_t* htab = reinterpret_cast<uint32_t*>(Es + KT);      // [KT] row hashes of the tile's queries (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD6;
+    const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
     const int ntile = rlt_cdiv_dev(B, QT);
     int pair, ktile;
     map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
-    const float* dobase = a.dout + (size_t)s * B * E + h * HD6;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
+    const float* dobase = a.dout + (size_t)s * B * E + h * HD;
     const float* lsebase = a.lse + ((size_t)s * H + h) * B;
     const float* delbase = a.delta + ((size_t)s * H + h) * B;
     const int key = ktile * QT + wv * 32 + l31;
     const bool wave_live = ktile * QT + wv * 32 < B;
     const int kc = min(key, B - 1);
 
-    Frag3 kf[HD6 / 16], vf[HD6 / 16];
-    row_frags6(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kf);
-    row_frags6(base + (size_t)kc * ld + 2 * E, hh, 1.f, vf);
+    Frag3 kf[HD / 16], vf[HD / 16];
+    row_frags6<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, kf);
+    row_frags6<HD>(base + (size_t)kc * ld + 2 * E, hh, 1.f, vf);
 
-    f32x16 dk[2], dv[2];
+    f32x16 dk[DT], dv[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
     const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
     const uint32_t hk = DROP ? rlt_col_hash(ps, (uint32_t)key) : 0u;
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-    Stage6 rq, rd;
+    Stage6<HD> rq, rd;
     float rl = 0.f, re = 0.f;
     const int nt = rlt_cdiv_dev(B, KT);
     auto load_small = [&](int row0) {
@@ -312,19 +324,19 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
             re = qi < B ? e : 0.f;
         }
     };
-    stage6_load(base, ld, 0, B, tid, rq);
-    stage6_load(dobase, (size_t)E, 0, B, tid, rd);
+    stage6_load<HD>(base, ld, 0, B, tid, rq);
+    stage6_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
     load_small(0);
-    stage6_store(Qi, tid, rq, 1.f);
-    stage6_store(Di, tid, rd, 1.f);
+    stage6_store<HD>(Qi, tid, rq, 1.f);
+    stage6_store<HD>(Di, tid, rd, 1.f);
     if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
     if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         if (RLT_A6_DKV_PREFETCH && t + 1 < nt) {
-            stage6_load(base, ld, (t + 1) * KT, B, tid, rq);
-            stage6_load(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
+            stage6_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
+            stage6_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
             load_small((t + 1) * KT);
         }
         if (wave_live) {
@@ -333,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                 f32x16 sc, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows6(Qi, sub, l31, hh, kf, sc);               // S[q][key] (log2 domain)
-                dp = mma_rows6(Di, sub, l31, hh, vf, dp);               // dP[q][key]
+                sc = mma_rows6<HD>(Qi, sub, l31, hh, kf, sc);               // S[q][key] (log2 domain)
+                dp = mma_rows6<HD>(Di, sub, l31, hh, vf, dp);               // dP[q][key]
                 // (seeding the accumulators with -lse / -delta, as attention3.hip does, saves two subtractions per score but
                 // rounds every partial sum at the magnitude of lse: measured 10-25 % more error against fp64 - not here; a
                 // last-tile-only branch for the row mask made hipcc duplicate the tile body and spill 86 registers)
@@ -352,77 +364,78 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                     sc[r] = pd;                                          // (dropped) P (feeds dV)
                     dp[r] = p * (dpr - Es[ql]);                          // dS
                 }
-                mma_cols6(Di, sub, lane, sc, dv);                        // dV^T[d][key] += dO^T P
-                mma_cols6(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
+                mma_cols6<HD>(Di, sub, lane, sc, dv);                        // dV^T[d][key] += dO^T P
+                mma_cols6<HD>(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
             }
         }
         if (!RLT_A6_DKV_PREFETCH && t + 1 < nt) {       // no registers held across the tile body; the partner workgroup covers the latency
-            stage6_load(base, ld, (t + 1) * KT, B, tid, rq);
-            stage6_load(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
+            stage6_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
+            stage6_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
             load_small((t + 1) * KT);
         }
         __syncthreads();
         if (t + 1 < nt) {
-            stage6_store(Qi, tid, rq, 1.f);
-            stage6_store(Di, tid, rd, 1.f);
+            stage6_store<HD>(Qi, tid, rq, 1.f);
+            stage6_store<HD>(Di, tid, rd, 1.f);
             if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
             if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
     }
     if (!wave_live || key >= B) return;
-    float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * HD6;
-    store_acc_T<HD6>(drow + E, hh, dk, a.scale);
-    store_acc_T<HD6>(drow + 2 * E, hh, dv, 1.f);
+    float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * HD;
+    store_acc_T<HD>(drow + E, hh, dk, a.scale);
+    store_acc_T<HD>(drow + 2 * E, hh, dv, 1.f);
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <bool DROP>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
+    constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vi = Ki + IMG6;
     uint32_t* htab = reinterpret_cast<uint32_t*>(Vi + IMG6);    // [KT] column hashes of the tile's keys (DROP)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int B = a.B, H = a.H, E = H * HD6;
+    const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
     const int ntile = rlt_cdiv_dev(B, QT);
     int pair, qt;
     map_block(blockIdx.x, a.S * H, ntile, pair, qt);
     const int s = pair / H, h = pair % H;
-    const float* base = a.qkv + (size_t)s * B * ld + h * HD6;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
     const int q = qt * QT + wv * 32 + l31;
     const bool wave_live = qt * QT + wv * 32 < B;
     const int qc = min(q, B - 1);
 
-    Frag3 qf[HD6 / 16], dof[HD6 / 16];
-    row_frags6(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
-    row_frags6(a.dout + ((size_t)s * B + qc) * E + h * HD6, hh, 1.f, dof);
+    Frag3 qf[HD / 16], dof[HD / 16];
+    row_frags6<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
+    row_frags6<HD>(a.dout + ((size_t)s * B + qc) * E + h * HD, hh, 1.f, dof);
     const float lse2 = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
     const float del = a.delta[((size_t)s * H + h) * B + qc];
 
-    f32x16 dq[2];
+    f32x16 dq[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
     const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
     const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-    Stage6 rk, rv;
+    Stage6<HD> rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
-    stage6_load(base + E, ld, 0, B, tid, rk);
-    stage6_load(base + 2 * E, ld, 0, B, tid, rv);
-    stage6_store(Ki, tid, rk, 1.f);
-    stage6_store(Vi, tid, rv, 1.f);
+    stage6_load<HD>(base + E, ld, 0, B, tid, rk);
+    stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+    stage6_store<HD>(Ki, tid, rk, 1.f);
+    stage6_store<HD>(Vi, tid, rv, 1.f);
     if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) {
-            stage6_load(base + E, ld, (t + 1) * KT, B, tid, rk);
-            stage6_load(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
+            stage6_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
+            stage6_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
         if (wave_live) {
 #pragma unroll
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
                 f32x16 sc, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_rows6(Ki, sub, l31, hh, qf, sc);                // S^T[key][q]
-                dp = mma_rows6(Vi, sub, l31, hh, dof, dp);               // dP^T[key][q]
+                sc = mma_rows6<HD>(Ki, sub, l31, hh, qf, sc);                // S^T[key][q]
+                dp = mma_rows6<HD>(Vi, sub, l31, hh, dof, dp);               // dP^T[key][q]
                 const bool tail = (t + 1) * KT > B;                       // keys beyond B exist in the last tile only
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -441,43 +454,46 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
                     if (DROP) dpr = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? dpr * inv_keep : 0.f;
                     dp[r] = p * (dpr - del);                              // dS^T
                 }
-                mma_cols6(Ki, sub, lane, dp, dq);                         // dQ^T[d][q] += K^T dS^T
+                mma_cols6<HD>(Ki, sub, lane, dp, dq);                         // dQ^T[d][q] += K^T dS^T
             }
         }
         __syncthreads();
         if (t + 1 < nt) {
-            stage6_store(Ki, tid, rk, 1.f);
-            stage6_store(Vi, tid, rv, 1.f);
+            stage6_store<HD>(Ki, tid, rk, 1.f);
+            stage6_store<HD>(Vi, tid, rv, 1.f);
             if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
     }
     if (!wave_live || q >= B) return;
-    store_acc_T<HD6>(a.dqkv + ((size_t)s * B + q) * ld + h * HD6, hh, dq, a.scale);
+    store_acc_T<HD>(a.dqkv + ((size_t)s * B + q) * ld + h * HD, hh, dq, a.scale);
 }
 
 }  // namespace
 
-template <bool DROP>
+template <int HD, bool DROP>
 static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
-    const size_t shm = (size_t)2 * IMG6 * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
+    const size_t shm = (size_t)2 * img6<HD>() * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
     int rc;
     if (which == 0) {
-        if ((rc = rlt_allow_lds(attn6_fwd_kernel<DROP>, shm))) return rc;
-        hipLaunchKernelGGL(attn6_fwd_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_fwd_kernel<HD, DROP>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_fwd_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
     } else if (which == 1) {
-        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel<DROP>, shm))) return rc;
-        hipLaunchKernelGGL(attn6_bwd_dkv_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel<HD, DROP>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
     } else {
-        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel<DROP>, shm))) return rc;
-        hipLaunchKernelGGL(attn6_bwd_dq_kernel<DROP>, dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel<HD, DROP>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
     }
     return RLT_LAUNCH_RESULT();
 }
 
-// which: 0 forward, 1 dK/dV, 2 dQ.  Head dim 64 (the caller checks).  Dropout is a template parameter: hipcc if-converts a
-// run-time `drop_p > 0` test and executes the hashes regardless.
-int rlt_attn6_run(int which, const AttnArgs& a, hipStream_t st) {
-    return a.drop_p > 0.f ? attn6_launch<true>(which, a, st) : attn6_launch<false>(which, a, st);
+// which: 0 forward, 1 dK/dV, 2 dQ; head dim 16, 32 or 64 (the caller checks).  Dropout is a template parameter: hipcc
+// if-converts a run-time `drop_p > 0` test and executes the hashes regardless.
+int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st) {
+    const bool drop = a.drop_p > 0.f;
+    if (HD == 64) return drop ? attn6_launch<64, true>(which, a, st) : attn6_launch<64, false>(which, a, st);
+    if (HD == 32) return drop ? attn6_launch<32, true>(which, a, st) : attn6_launch<32, false>(which, a, st);
+    return drop ? attn6_launch<16, true>(which, a, st) : attn6_launch<16, false>(which, a, st);
 }

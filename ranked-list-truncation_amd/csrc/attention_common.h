@@ -56,9 +56,9 @@ __device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh,
 
 }  // namespace
 
-// fp32-faithful six-product path (bf16x6 mode, head dim 64, no dropout), defined in attention6.hip: which = 0 forward,
+// fp32-faithful six-product path (bf16x6 mode, head dims 16 / 32 / 64), defined in attention6.hip: which = 0 forward,
 // 1 dK/dV, 2 dQ
-int rlt_attn6_run(int which, const AttnArgs& a, hipStream_t st);
+int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip
 size_t rlt_attn3_images_bytes(int S, int B, int H, int HD, int nmat);
 int rlt_attn3_run(int which, const AttnArgs& a, int HD, void* images, void* dimages, hipStream_t st);
