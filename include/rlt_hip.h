@@ -42,11 +42,12 @@ int rlt_abi_version(void);
  *   RLT_PRECISION_FP32   exact fp32 products on the f32 MFMA (157 TFLOP/s peak) - bit-for-bit fp32 fma chains
  *   RLT_PRECISION_BF16X3 every operand split into bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi on the bf16
  *                        MFMA with fp32 accumulation (~2^-16 relative error per product, ~2x faster end to end)
- *   RLT_PRECISION_BF16X6 fp32-FAITHFUL products on the bf16 MFMA for the rlt_gemm* family: every operand split
- *                        exactly into three bf16 values (8 + 8 + 8 significand bits), six of the nine partial
- *                        products kept, what is dropped is < 2^-23 of the product in the worst case (under one fp32 ulp; 2^-29 typical) -
- *                        all 24 operand bits, held to the FP32 mode's tolerances in the tests; attention and the
- *                        BiLSTM recurrences run their exact-fp32 kernels in this mode
+ *   RLT_PRECISION_BF16X6 fp32-FAITHFUL products on the bf16 MFMA for the rlt_gemm* family and rlt_list_attention_* at
+ *                        head dims 16 / 32 / 64: every operand split exactly into three bf16 values (8 + 8 + 8
+ *                        significand bits), six of the nine partial products kept, what is dropped is < 2^-23 of
+ *                        the product in the worst case (under one fp32 ulp; 2^-29 typical) - all 24 operand bits,
+ *                        held to the FP32 mode's tolerances in the tests; the BiLSTM recurrences (and head dim
+ *                        128) run their exact-fp32 kernels in this mode
  * Default: BF16X3; the environment variable RLT_PRECISION=fp32|bf16x3|bf16x6 selects it at first use. */
 #define RLT_PRECISION_FP32   0
 #define RLT_PRECISION_BF16X3 1
