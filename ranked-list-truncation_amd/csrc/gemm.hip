@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(512) void gemm6b_kernel(GemmArgs g) {
         load_b(0, 0, 0);
 #pragma unroll
         for (int step = 0; step < 8; ++step) {
-            const int ks = step >> 2, j = step & 3;
+            const int j = step & 3;
             if (step + 1 < 8) load_b((step + 1) >> 2, (step + 1) & 3, (step + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
