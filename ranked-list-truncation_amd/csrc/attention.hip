@@ -562,6 +562,13 @@ static bool attn6_use(int HD, float drop_p) {
     return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD <= 64;
 }
 
+// head dim 16 in the exact-fp32 mode: the 16x16x4-MFMA kernels of attention16.hip (RLT_ATTN16=0: the 32x32x2 kernels of this
+// file, whose d-indexed products are half padding at 16)
+static bool attn16_use() {
+    static const bool on = [] { const char* e = getenv("RLT_ATTN16"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 extern "C" {
 
 int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, void* stream) {
@@ -610,6 +617,7 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
     if (HD == 128) return launch_fwd<128>(a, st);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
+    if (attn16_use()) return rlt_attn16_run(0, a, st);
     return launch_fwd<16>(a, st);
 }
 
@@ -655,6 +663,7 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     if (attn_mode(HD) == 1 && images)
         return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
     if (attn6_use(HD, drop_p)) return rlt_attn6_run(which, a, HD, st);
+    if (HD == 16 && attn16_use()) return rlt_attn16_run(which, a, st);
     if (which == 1) {
         if (HD == 128) return launch_dkv<128>(a, st);
         if (HD == 64) return launch_dkv<64>(a, st);

@@ -59,6 +59,8 @@ __device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh,
 // fp32-faithful six-product path (bf16x6 mode, head dims 16 / 32 / 64), defined in attention6.hip: which = 0 forward,
 // 1 dK/dV, 2 dQ
 int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st);
+// exact fp32 at head dim 16 on the 16x16x4 MFMA (no padded head-dim axis), defined in attention16.hip: same `which`
+int rlt_attn16_run(int which, const AttnArgs& a, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip
 size_t rlt_attn3_images_bytes(int S, int B, int H, int HD, int nmat);
 int rlt_attn3_run(int which, const AttnArgs& a, int HD, void* images, void* dimages, hipStream_t st);

@@ -1,0 +1,126 @@
+// Do vector ALU instructions overlap a partner wavefront's fp32 MFMAs on one SIMD of gfx950?
+//
+// 512-thread workgroups, one per CU: wavefronts 0-3 and 4-7 land pairwise on the CU's four SIMDs.  Role A = a loop of
+// independent v_mfma_f32_16x16x4_f32 (or 32x32x2), role B = a loop of independent v_fma_f32.  Timed: A alone (B exits),
+// B alone, both, and ONE wavefront per SIMD running the same MFMAs with NF fillers placed after each MFMA in its own stream.
+//   hipcc --offload-arch=gfx950 -O3 mfma_valu_overlap.hip -o mfma_valu_overlap
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// mode bit 0: MFMA wavefronts run; bit 1: VALU wavefronts run.  nm MFMAs / nv FMAs per loop iteration are compile-time.
+template <int SHAPE, int KIND = 0>
+__global__ __launch_bounds__(512) void two_waves(const float* __restrict__ in, float* __restrict__ out, int iters, int mode) {
+    const int wv = threadIdx.x >> 6;
+    const float a = in[threadIdx.x & 255], b = in[256 + (threadIdx.x & 255)];
+    if (wv < 4) {
+        if (!(mode & 1)) return;
+        if (SHAPE == 16) {
+            f32x4 c[4] = {};
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c[u & 3]) : "v"(a), "v"(b));
+            }
+            float s = 0.f;
+            for (int u = 0; u < 4; ++u) s += c[u][0] + c[u][1] + c[u][2] + c[u][3];
+            if (s == 123.456f) out[0] = s;
+        } else {
+            f32x16 c[2] = {};
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c[u & 1]) : "v"(a), "v"(b));
+            }
+            float s = 0.f;
+            for (int u = 0; u < 2; ++u) for (int r = 0; r < 16; ++r) s += c[u][r];
+            if (s == 123.456f) out[0] = s;
+        }
+    } else {
+        if (!(mode & 2)) return;
+        float f[8];
+        for (int j = 0; j < 8; ++j) f[j] = a + 0.001f * j;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[u & 7]) : "v"(b));
+                else asm volatile("v_exp_f32 %0, %0" : "+v"(f[u & 7]));
+            }
+        }
+        float s = 0.f;
+        for (int j = 0; j < 8; ++j) s += f[j];
+        if (s == 123.456f) out[1] = s;
+    }
+}
+
+// one wavefront per SIMD: each 16x16x4 MFMA followed by NF independent v_fma_f32 in the same stream
+template <int NF, int KIND = 0>
+__global__ __launch_bounds__(256) void one_wave(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    const float a = in[threadIdx.x & 255], b = in[256 + (threadIdx.x & 255)];
+    f32x4 c[4] = {};
+    float f[8];
+    for (int j = 0; j < 8; ++j) f[j] = a + 0.001f * j;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c[u & 3]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[j & 7]) : "v"(b));
+                else asm volatile("v_exp_f32 %0, %0" : "+v"(f[j & 7]));
+            }
+        }
+    }
+    float s = 0.f;
+    for (int u = 0; u < 4; ++u) s += c[u][0] + c[u][1] + c[u][2] + c[u][3];
+    for (int j = 0; j < 8; ++j) s += f[j];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <typename F>
+static float time_ms(F launch) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    float* in; float* out;
+    hipMalloc(&in, 512 * 4); hipMalloc(&out, 16);
+    float h[512];
+    for (int i = 0; i < 512; ++i) h[i] = (float)(i % 97) / 97.f - 0.5f;
+    hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+    const int iters = 20000;
+    for (int shape = 16; shape <= 32; shape += 16) {
+        float t[4];
+        for (int mode = 1; mode <= 3; ++mode)
+            t[mode] = shape == 16 ? time_ms([&] { hipLaunchKernelGGL((two_waves<16>), dim3(256), dim3(512), 0, 0, in, out, iters, mode); })
+                                  : time_ms([&] { hipLaunchKernelGGL((two_waves<32>), dim3(256), dim3(512), 0, 0, in, out, iters, mode); });
+        // per iteration: 512 matrix-pipe cycles (16 x 32 or 8 x 64), 64 FMAs = 256 issue cycles
+        printf("shape %dx: MFMA wave alone %.3f ms, VALU wave alone %.3f ms, both on one SIMD %.3f ms (sum %.3f, max %.3f)\n",
+               shape, t[1], t[2], t[3], t[1] + t[2], t[1] > t[2] ? t[1] : t[2]);
+    }
+    {
+        float t[4];
+        for (int mode = 1; mode <= 3; ++mode)
+            t[mode] = time_ms([&] { hipLaunchKernelGGL((two_waves<16, 1>), dim3(256), dim3(512), 0, 0, in, out, iters, mode); });
+        printf("shape 16x, partner runs v_exp_f32: MFMA wave alone %.3f ms, exp wave alone %.3f ms, both %.3f ms (sum %.3f)\n", t[1], t[2], t[3],
+               t[1] + t[2]);
+        printf("one wave, 16x16x4 + NF v_exp_f32 per MFMA: NF=1 %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<1, 1>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+        printf(", 2: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<2, 1>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+        printf(", 4: %.3f ms\n", time_ms([&] { hipLaunchKernelGGL((one_wave<4, 1>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    }
+    const float base = time_ms([&] { hipLaunchKernelGGL((one_wave<0>), dim3(256), dim3(256), 0, 0, in, out, iters); });
+    printf("one wave, 16x16x4 + NF fillers per MFMA: NF=0 %.3f ms", base);
+    printf(", 2: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<2>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    printf(", 4: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<4>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    printf(", 5: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<5>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    printf(", 6: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<6>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    printf(", 8: %.3f", time_ms([&] { hipLaunchKernelGGL((one_wave<8>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    printf(", 12: %.3f ms\n", time_ms([&] { hipLaunchKernelGGL((one_wave<12>), dim3(256), dim3(256), 0, 0, in, out, iters); }));
+    return 0;
+}
