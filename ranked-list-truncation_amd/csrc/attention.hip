@@ -34,8 +34,17 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ base, size_t
                                           TileRegs<HD>& r) {
     constexpr int PER_ROW = HD / 4, N4 = KT * PER_ROW, NI = (N4 + 255) / 256;
     static_assert(N4 % 256 == 0, "tile must be a whole number of 256-thread passes");
-    // branch-free: clamp the row into the matrix, load unconditionally, zero out-of-range rows with a
-    // select (a guarded load makes hipcc branch around it and drain vmcnt, serialising the burst)
+    if (row0 + KT <= nrows) {            // whole tile in range (uniform): plain loads, no per-element select - the vector
+                                         // ALU time of those selects is not hidden behind the fp32 MFMAs on gfx950
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + 256 * i;
+            r.v[i] = *reinterpret_cast<const float4*>(base + (size_t)(row0 + idx / PER_ROW) * ld + 4 * (idx % PER_ROW));
+        }
+        return;
+    }
+    // last tile: clamp the row into the matrix, load unconditionally, zero out-of-range rows with a select (a guarded
+    // load makes hipcc branch around it and drain vmcnt, serialising the burst)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int idx = tid + 256 * i;
@@ -180,30 +189,43 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
                 sc[sub] = mma_tile_rows<HD>(kt_, sub, l31, hh, qreg, sc[sub]);     // S^T[key][q], log2 domain
             }
-            // mask keys beyond B, tile max
+            if ((t + 1) * KT > B) {               // last tile only: keys beyond B
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
+            }
+            // lazy rescaling: the reference m_run of the weights exp2(sc - m_run) moves only when a score of this tile exceeds
+            // it by more than 8 (O / l does not depend on the reference, and weights up to 2^8 are comfortable in fp32), so the
+            // common tile has no cross-lane step, no rescale of O and l.  On gfx950 the fp32 MFMA and the vector ALU do not
+            // overlap (tools/micro/mfma_valu_overlap.hip: their times add): every vector instruction removed is time won.
             float tmax = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KT + sub * 32 + acc_row(r, hh);
-                    if (key >= B) sc[sub][r] = -INFINITY;
-                    tmax = fmaxf(tmax, sc[sub][r]);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = rlt_exp2(m_run - m_new);
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
+            if (__any(t == 0 || tmax > m_run + 8.f)) {          // wave-uniform; the first tile sets the reference
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = rlt_exp2(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = rlt_exp2(sc[sub][r] - m_new);
+                    const float p = rlt_exp2(sc[sub][r] - m_run);
                     sc[sub][r] = p;
                     psum += p;
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            l_run += psum;
             if (DROP) {                    // dropout acts on the normalised probabilities: the normaliser keeps all keys
                 // (compiled out at p = 0: hipcc if-converts a run-time test and executes the hash regardless)
                 const uint32_t ps = pair_seed(a.seed, pair);
@@ -217,10 +239,6 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {
                         sc[sub][r] = rlt_keep_rc(hq, rlt_col_hash(ps, (uint32_t)key), a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
                     }
             }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) mma_tile_cols<HD>(vt_, sub, l31, hh, sc[sub], oacc);   // O^T[d][q]
         }
@@ -270,8 +288,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                         // [2][KT*LD]
     float* Ds = smem + 2 * KT * LD;           // [2][KT*LD]   dO
-    float* Ls = smem + 4 * KT * LD;           // [2][KT]      lse * log2e
-    float* Es = Ls + 2 * KT;                  // [2][KT]      delta
+    float* Ls = smem + 4 * KT * LD;           // [2][KT]      -lse * log2e (-inf beyond B)
+    float* Es = Ls + 2 * KT;                  // [2][KT]      -delta
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int B = a.B, H = a.H, E = H * HD;
     const size_t ld = (size_t)3 * E;
@@ -304,8 +322,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (tid < KT) {
             const int qi = row0 + tid, qc = min(qi, B - 1);
             const float l = lsebase[qc], e = delbase[qc];
-            rl = qi < B ? l * LOG2E : 0.f;
-            re = qi < B ? e : 0.f;
+            rl = qi < B ? -l * LOG2E : -INFINITY;       // negated: the initial values of the score / dP accumulators
+            re = qi < B ? -e : 0.f;
         }
     };
     tile_load<HD>(base, ld, 0, B, tid, rq);
@@ -330,25 +348,32 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
             const float* et_ = Es + buf * KT;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                // the accumulators start from -lse and -delta of their ROW (the LDS tables hold the negated values, -inf for a
+                // query beyond B, whose weights are then exp2(-inf) = 0): P = exp2(sc), dS = P * dp - no subtraction and no
+                // range test per element.  On gfx950 the fp32 MFMA and the vector ALU do not overlap
+                // (tools/micro/mfma_valu_overlap.hip: their times ADD), so each vector instruction removed is time won.
                 f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_tile_rows<HD>(qt_, sub, l31, hh, kreg, sc);    // S[q][key] (log2 domain)
-                dp = mma_tile_rows<HD>(dt_, sub, l31, hh, vreg, dp);    // dP[q][key]
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
-                    const bool ok = t * KT + ql < B;
-                    const float p = ok ? rlt_exp2(sc[r] - lt_[ql]) : 0.f;
-                    float pd = p, dpr = dp[r];
+                    sc[r] = lt_[ql];
+                    dp[r] = DROP ? 0.f : et_[ql];
+                }
+                sc = mma_tile_rows<HD>(qt_, sub, l31, hh, kreg, sc);    // S[q][key] - lse[q] (log2 domain)
+                dp = mma_tile_rows<HD>(dt_, sub, l31, hh, vreg, dp);    // dP[q][key] (- delta[q])
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = rlt_exp2(sc[r]);
                     if (DROP) {
+                        const int ql = sub * 32 + acc_row(r, hh);
                         const bool keep = rlt_keep(pair_seed(a.seed, pair), (uint32_t)(t * KT + ql), (uint32_t)key, a.drop_thr);
                         const float m = keep ? 1.f / (1.f - a.drop_p) : 0.f;
-                        pd = p * m;
-                        dpr *= m;
+                        sc[r] = p * m;                                       // dropped P (feeds dV)
+                        dp[r] = p * (dp[r] * m + et_[ql]);                   // dS
+                    } else {
+                        sc[r] = p;
+                        dp[r] = p * dp[r];
                     }
-                    sc[r] = pd;                                          // dropped P (feeds dV)
-                    dp[r] = p * (dpr - et_[ql]);                         // dS
                 }
                 mma_tile_cols<HD>(dt_, sub, l31, hh, sc, dv);            // dV^T[d][key] += dO^T P
                 mma_tile_cols<HD>(qt_, sub, l31, hh, dp, dk);            // dK^T[d][key] += Q^T dS
@@ -369,7 +394,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ dQ
 template <int HD, bool DROP, bool SB>
-__global__ __launch_bounds__(256, SB ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, SB ? 3 : (HD <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int LD = HD + 4, DT = (HD + 31) / 32, NB = SB ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -417,19 +442,28 @@ __global__ __launch_bounds__(256, SB ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs a
             const float* vt_ = Vs + buf * KT * LD;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                // -lse and -delta of the lane's query are the accumulators' initial values (see the dK/dV kernel); a key beyond
+                // B starts at -inf (P = 0)
                 f32x16 sc, dp;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-                sc = mma_tile_rows<HD>(kt_, sub, l31, hh, qreg, sc);     // S^T[key][q]
-                dp = mma_tile_rows<HD>(vt_, sub, l31, hh, doreg, dp);    // dP^T[key][q]
+                for (int r = 0; r < 16; ++r) { sc[r] = -lse2; dp[r] = DROP ? 0.f : -del; }
+                if ((t + 1) * KT > B) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[r] = -INFINITY;
+                }
+                sc = mma_tile_rows<HD>(kt_, sub, l31, hh, qreg, sc);     // S^T[key][q] - lse[q]
+                dp = mma_tile_rows<HD>(vt_, sub, l31, hh, doreg, dp);    // dP^T[key][q] (- delta[q])
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = t * KT + sub * 32 + acc_row(r, hh);
-                    const float p = kidx < B ? rlt_exp2(sc[r] - lse2) : 0.f;
-                    float dpr = dp[r];
-                    if (DROP)
-                        dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dpr / (1.f - a.drop_p) : 0.f;
-                    dp[r] = p * (dpr - del);                              // dS^T
+                    const float p = rlt_exp2(sc[r]);
+                    if (DROP) {
+                        const int kidx = t * KT + sub * 32 + acc_row(r, hh);
+                        const float dpr = rlt_keep(pair_seed(a.seed, pair), (uint32_t)q, (uint32_t)kidx, a.drop_thr) ? dp[r] / (1.f - a.drop_p) : 0.f;
+                        dp[r] = p * (dpr - del);
+                    } else {
+                        dp[r] = p * dp[r];                                // dS^T
+                    }
                 }
                 mma_tile_cols<HD>(kt_, sub, l31, hh, dp, dq);             // dQ^T[d][q] += K^T dS^T
             }

@@ -65,6 +65,12 @@ __device__ __forceinline__ f32x4 mfma16x4(const float4& a, const f32x4& b, f32x4
 // address + select: a guarded load would make hipcc branch around it)
 struct Stage { float4 v[NI]; };
 __device__ __forceinline__ void stage_load(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid, Stage& r) {
+    if (row0 + T16 <= nrows) {           // whole tile in range (uniform): no selects
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            r.v[i] = *reinterpret_cast<const float4*>(base + (size_t)(row0 + 64 * i + (tid >> 2)) * ld + 4 * (tid & 3));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = row0 + 64 * i + (tid >> 2);

@@ -226,25 +226,34 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 16; ++r)
                         if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
             }
+            // lazy rescaling (see attention.hip): the reference m_run moves only when a score exceeds it by more than 8, so the
+            // common tile has no cross-lane step and no rescale of O and l
             float tmax = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = rlt_exp2(m_run - m_new);
+            if (__any(t == 0 || tmax > m_run + 8.f)) {          // wave-uniform; the first tile sets the reference
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = rlt_exp2(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = rlt_exp2(sc[sub][r] - m_new);
+                    const float p = rlt_exp2(sc[sub][r] - m_run);
                     sc[sub][r] = p;
                     psum += p;
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            l_run += psum;
             if (DROP) {                          // dropout acts on the normalised probabilities: the normaliser keeps all keys
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -252,10 +261,6 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 16; ++r)
                         sc[sub][r] = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
             }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) mma_cols6<HD>(Vi, sub, lane, sc[sub], oacc);   // O^T[d][q] += V^T P^T
         }
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
         if (tid < KT) {
             const int qi = row0 + tid, qc = min(qi, B - 1);
             const float l = lsebase[qc], e = delbase[qc];
-            rl = qi < B ? l * LOG2E : 0.f;
+            rl = qi < B ? l * LOG2E : INFINITY;
             re = qi < B ? e : 0.f;
         }
     };
@@ -349,11 +354,14 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                 dp = mma_rows6<HD>(Di, sub, l31, hh, vf, dp);               // dP[q][key]
                 // (seeding the accumulators with -lse / -delta, as attention3.hip does, saves two subtractions per score but
                 // rounds every partial sum at the magnitude of lse: measured 10-25 % more error against fp64 - not here; a
-                // last-tile-only branch for the row mask made hipcc duplicate the tile body and spill 86 registers)
+                // last-tile-only branch for the row mask made hipcc duplicate the tile body and spill 86 registers; the mask is
+                // in the lse table instead)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = sub * 32 + acc_row(r, hh);
-                    const bool ok = t * KT + ql < B;
+                    // Ls = +inf for a query beyond B, so its weight is 0 without a range test per element; at head dim 64 the
+                    // test stays: without it hipcc's schedule of this body spills 200 instead of 70 bytes and runs 2 % slower
+                    const bool ok = HD < 64 || t * KT + ql < B;
                     const float p = ok ? rlt_exp2(sc[r] - Ls[ql]) : 0.f;
                     float pd = p, dpr = dp[r];
                     if (DROP) {
@@ -445,11 +453,14 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
                 sc = mma_rows6<HD>(Ki, sub, l31, hh, qf, sc);                // S^T[key][q]
                 dp = mma_rows6<HD>(Vi, sub, l31, hh, dof, dp);               // dP^T[key][q]
-                const bool tail = (t + 1) * KT > B;                       // keys beyond B exist in the last tile only
+                if ((t + 1) * KT > B) {                                   // keys beyond B exist in the last tile only
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[r] = -INFINITY;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = rlt_exp2(sc[r] - lse2);
-                    if (tail && t * KT + sub * 32 + acc_row(r, hh) >= B) p = 0.f;
+                    const float p = rlt_exp2(sc[r] - lse2);
                     float dpr = dp[r];
                     if (DROP) dpr = rlt_keep_rc(hq, htab[sub * 32 + acc_row(r, hh)], a.drop_thr) ? dpr * inv_keep : 0.f;
                     dp[r] = p * (dpr - del);                              // dS^T
