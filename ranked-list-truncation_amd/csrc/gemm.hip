@@ -391,9 +391,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < BK / 8; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
     };
+    const bool whole_mn = m0 + BM <= g.M && n0 + BN <= g.N;
     auto consume = [&](int k0, int buf) {        // mask (fast path), bias-gradient side sum, LDS store
         __builtin_amdgcn_sched_barrier(0);       // do not hoist the first use of the loaded registers above the MFMAs
-        if (FAST) {
+        if (FAST && !(whole_mn && k0 + BK <= kend)) {       // (scalar test) a whole tile needs no zero-select
             mask_tile<!TA, BK>(ra, tid, m0, k0, g.M, kend);
             mask_tile<TB, BK>(rb, tid, n0, k0, g.N, kend);
         }
