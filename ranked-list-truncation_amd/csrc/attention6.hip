@@ -15,6 +15,7 @@
 // over the tile's ROW index read their A operand transposed from the same image with ds_read_b64_tr_b16, so no transposed
 // image exists.  One LDS copy of a tile pair (55 KB): two workgroups per CU, their tile phases uncorrelated.
 #include "attention_common.h"
+#include <stdlib.h>
 
 #ifndef RLT_A6_DKV_PREFETCH
 #define RLT_A6_DKV_PREFETCH 0   // dK+dV kernel, 1: next tile's global loads issued BEFORE the tile body (32 staging registers live across it); measured 48.9 ms against 47.6 with the loads after the body (the partner workgroup covers their latency)
@@ -280,6 +281,241 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward, ping-pong form
+// A SIMD's vector issue port blocks at its head (tools/micro/mfma_valu_overlap.hip): the MFMA bursts of one wavefront and the
+// vector work of its SIMD partner ADD unless (a) the partner really is in a vector phase while this one bursts and (b) the
+// bursting wave steps back from the port for a few cycles after each MFMA.  Two independent 256-thread workgroups per CU give
+// neither.  This form runs ONE 512-thread workgroup per CU (256 queries) as two groups of four wavefronts that share the K / V
+// tile images and execute the same four segments per tile, group B one segment behind group A, a barrier after every segment:
+//     X: the 48 MFMAs of S^T = K Q^T            (matrix)        Y: softmax + dropout + the 3-way split of P   (vector)
+//     Z: the 48 MFMAs of O^T += V^T P^T         (matrix)        W: split + LDS store of the group's half of tile t+1 (vector)
+//   slot:   4t     4t+1   4t+2   4t+3   4t+4
+//   A:      X(t)   Y(t)   Z(t)   W(t)   X(t+1)       (A stages K, into the other image buffer)
+//   B:      W(t-1) X(t)   Y(t)   Z(t)   W(t)         (B stages V)
+// so every slot pairs a matrix segment with a vector segment on each SIMD; `s_nop` behind every MFMA of X and Z (RLT_A6_PP_PAD).
+// Measured (4096 x 60 positions, s_memtime stamps of a -DRLT_PP_STAMPS build, tools/pp_stamps.py): the four slots of a tile take
+// ~1830 / 2110 / 1950-2200 / 2100-2500 cycles + 200-600 at each barrier, 9,700 per tile against 2 x 5,550 for two tiles of the
+// two-workgroup form: 5.55 -> 5.25 ms.  The slots are now as long as their VECTOR segments: the ~610 vector instructions per
+// wavefront and tile (softmax 130, split of P 176, exponentials 32, staging split + addresses 150, ...) do not fit the ~5 issue
+// slots that each of the partner's 96 MFMAs leaves - the kernel is vector-issue-bound, which is what is left to shorten.
+#ifndef RLT_A6_PP_PAD
+#define RLT_A6_PP_PAD 1
+#endif
+__device__ __forceinline__ void pp_pad(f32x16& c) {
+    if (RLT_A6_PP_PAD >= 0) asm volatile("s_nop %1" : "+v"(c) : "n"(RLT_A6_PP_PAD >= 0 ? RLT_A6_PP_PAD : 0));
+}
+__device__ __forceinline__ f32x16 mfma6_pp(const Frag3& a, const Frag3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0); pp_pad(c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0); pp_pad(c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0); pp_pad(c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0); pp_pad(c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0); pp_pad(c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0); pp_pad(c);
+    return c;
+}
+constexpr int QT_PP = 256;     // queries per ping-pong workgroup
+#ifdef RLT_PP_STAMPS
+// diagnostic build only: s_memtime at every segment boundary of workgroup 0, wavefronts 0 (group A) and 4 (group B), tiles 8..15
+__device__ unsigned long long pp_stamps[2 * 8 * 8];
+#define PP_STAMP(k) do { if (blockIdx.x == 0 && (wv == 0 || wv == 4) && lane == 0 && t >= 8 && t < 16) \
+    pp_stamps[((wv >> 2) * 8 + (t - 8)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
+    constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* Ki = reinterpret_cast<uint16_t*>(smem);          // [2] K tile images
+    uint16_t* Vi = Ki + 2 * IMG6;                               // [2] V tile images
+    uint32_t* htab = reinterpret_cast<uint32_t*>(Vi + 2 * IMG6);   // [2][KT] column hashes of the tile's keys (DROP)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int grp = __builtin_amdgcn_readfirstlane(wv >> 2), tid2 = tid & 255;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT_PP);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * HD;
+    const int q = qt * QT_PP + wv * 32 + l31;
+    const bool wave_live = qt * QT_PP + wv * 32 < B;
+    const int qc = min(q, B - 1);
+
+    Frag3 qf[HD / 16];
+    row_frags6<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hq = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    const int nt = rlt_cdiv_dev(B, KT);
+    const float* src = base + (grp == 0 ? E : 2 * E);          // group A stages K, group B stages V
+    uint16_t* mine = grp == 0 ? Ki : Vi;
+    Stage6<HD> st;
+    stage6_load<HD>(src, ld, 0, B, tid2, st);
+    stage6_store<HD>(mine, tid2, st, 1.f);
+    if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
+    if (nt > 1) stage6_load<HD>(src, ld, KT, B, tid2, st);
+    __syncthreads();
+
+    f32x16 sc[2];
+    Frag3 pf[2][2];                                              // P of the tile, split: [sub][s] (rows 16 s .. 16 s + 15 of the sub-tile)
+    // the matrix segments read the fragments of MFMA group g + 1 BEFORE the six MFMAs of group g (a scheduling fence keeps hipcc
+    // from sinking the reads to their use): with the vector work in the partner's shadow, what is left of a slot is the matrix
+    // segment itself, and an exposed LDS latency per group made it 2000-2100 cycles for 1536 of MFMAs (s_memtime stamps)
+    auto seg_x = [&](int t) {
+        const uint16_t* img = Ki + (t & 1) * IMG6;
+        auto frag = [&](int g) {
+            const int off = ((g >> 2) * 32 + l31) * LDR + 8 * hh + 16 * (g & 3);          // g = sub * 4 + ks   (HD / 16 = 4 k steps)
+            Frag3 f;
+            f.h = *reinterpret_cast<const bf16x8*>(img + off);
+            f.m = *reinterpret_cast<const bf16x8*>(img + PL + off);
+            f.l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+            return f;
+        };
+        constexpr int NG = 2 * (HD / 16);
+        Frag3 fr[2];
+        fr[0] = frag(0);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            constexpr int KS = HD / 16;
+            if (g + 1 < NG) fr[(g + 1) & 1] = frag(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g % KS == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            acc = mfma6_pp(fr[g & 1], qf[g % KS], acc);
+            if (g % KS == KS - 1) sc[g / KS] = acc;
+        }
+    };
+    auto seg_y = [&](int t) {
+        if ((t + 1) * KT > B) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * KT + sub * 32 + acc_row(r, hh) >= B) sc[sub][r] = -INFINITY;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
+        if (__any(t == 0 || tmax > m_run + 8.f)) {              // lazy rescaling (attention.hip)
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = rlt_exp2(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        // transcendental (and packed-fp32, and integer-multiply) instructions do NOT run beside a partner's MFMAs - one of them
+        // in eight serialises the whole stream (tools/micro/mfma_valu_overlap.hip) - while plain fp32 / integer / convert
+        // instructions do: the 32 exponentials are issued as one burst between scheduling fences, the subtractions before and the
+        // sum and the three-way split after them stay overlappable (this file is compiled without SLP packing)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[sub][r] -= m_run;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[sub][r] = rlt_exp2(sc[sub][r]);
+        __builtin_amdgcn_sched_barrier(0);
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += sc[sub][r];
+        l_run += psum;
+        if (DROP) {
+            const uint32_t* ht = htab + (t & 1) * KT;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[sub][r] = rlt_keep_rc(hq, ht[sub * 32 + acc_row(r, hh)], a.drop_thr) ? sc[sub][r] * inv_keep : 0.f;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float x[8] = {sc[sub][8 * s2 + 0], sc[sub][8 * s2 + 1], sc[sub][8 * s2 + 2], sc[sub][8 * s2 + 3],
+                                    sc[sub][8 * s2 + 4], sc[sub][8 * s2 + 5], sc[sub][8 * s2 + 6], sc[sub][8 * s2 + 7]};
+                pf[sub][s2] = split8x3(x);
+            }
+    };
+    auto seg_z = [&](int t) {
+        const uint16_t* img = Vi + (t & 1) * IMG6;
+        auto frag = [&](int g) {                                 // g = (sub * 2 + s2) * DT + dt
+            const int dt = g % DT, s2 = (g / DT) & 1, sub = g / (2 * DT);
+            const int row = sub * 32 + 16 * s2 + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * LDR + 32 * dt + (HD >= 32 ? 16 * ((lane >> 4) & 1) : 0) + 4 * (lane & 3);
+            Frag3 f;
+            f.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR));
+            f.m = cat_frag6(tr_read6(img + PL + off), tr_read6(img + PL + off + 8 * LDR));
+            f.l = cat_frag6(tr_read6(img + 2 * PL + off), tr_read6(img + 2 * PL + off + 8 * LDR));
+            return f;
+        };
+        constexpr int NG = 4 * DT;
+        Frag3 fr[2];
+        fr[0] = frag(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) fr[(g + 1) & 1] = frag(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[g % DT] = mfma6_pp(fr[g & 1], pf[g / (2 * DT)][(g / DT) & 1], oacc[g % DT]);
+        }
+    };
+    auto seg_w = [&](int t) {
+        if (t + 1 < nt) {
+            stage6_store<HD>(mine + ((t + 1) & 1) * IMG6, tid2, st, 1.f);
+            if (DROP && tid < KT) htab[((t + 1) & 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
+            if (t + 2 < nt) stage6_load<HD>(src, ld, (t + 2) * KT, B, tid2, st);
+        }
+    };
+    // every wavefront executes 4 nt + 1 barriers
+    if (grp == 1) __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        PP_STAMP(0);
+        if (wave_live) seg_x(t);
+        PP_STAMP(1);
+        __syncthreads();
+        PP_STAMP(2);
+        if (wave_live) seg_y(t);
+        PP_STAMP(3);
+        __syncthreads();
+        PP_STAMP(4);
+        if (wave_live) seg_z(t);
+        PP_STAMP(5);
+        __syncthreads();
+        PP_STAMP(6);
+        seg_w(t);
+        PP_STAMP(7);
+        __syncthreads();
+    }
+    if (grp == 0) __syncthreads();
+    if (!wave_live) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (q < B) {
+        store_acc_T<HD>(a.o + ((size_t)s * B + q) * E + h * HD, hh, oacc, 1.f / l_tot);
+        if (hh == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run + log2f(l_tot)) * LN2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dK, dV
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
@@ -487,6 +723,13 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
     const size_t shm = (size_t)2 * img6<HD>() * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
     int rc;
+    static const bool pp = [] { const char* e = getenv("RLT_A6_PP"); return !e || atoi(e) != 0; }();    // RLT_A6_PP=0: the two-workgroup form
+    if (which == 0 && HD == 64 && pp) {       // ping-pong form: one 512-thread workgroup per CU, 256 queries
+        const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
+        if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP>, shm_pp))) return rc;
+        hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
+        return RLT_LAUNCH_RESULT();
+    }
     if (which == 0) {
         if ((rc = rlt_allow_lds(attn6_fwd_kernel<HD, DROP>, shm))) return rc;
         hipLaunchKernelGGL((attn6_fwd_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
@@ -499,6 +742,12 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     }
     return RLT_LAUNCH_RESULT();
 }
+
+#ifdef RLT_PP_STAMPS
+extern "C" int rlt_debug_pp_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 // which: 0 forward, 1 dK/dV, 2 dQ; head dim 16, 32 or 64 (the caller checks).  Dropout is a template parameter: hipcc
 // if-converts a run-time `drop_p > 0` test and executes the hashes regardless.

@@ -21,7 +21,7 @@ def main():
     out_dir = os.path.join(B.CSRC, "variants")
     os.makedirs(out_dir, exist_ok=True)
     obj = os.path.join(out_dir, f"{name}_{src[:-4]}.o")
-    subprocess.run([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+    subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS.get(src, []) + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
     objs = [o for o in (s[:-4] + ".o" for s in B.sources()) if os.path.basename(o) != src[:-4] + ".o"] + [obj]
     lib = os.path.join(out_dir, f"librlt_{name}.so")
     subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)

@@ -45,7 +45,27 @@ __global__ __launch_bounds__(512) void two_waves_bf16(const uint4* __restrict__ 
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[u & 7]) : "v"(bb));
-                else asm volatile("v_exp_f32 %0, %0" : "+v"(f[u & 7]));
+                else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(f[u & 7]));
+                else if (KIND == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 3) {            // the mix of a split: convert, shift, and, two subtractions, one exp in eight
+                    if ((u & 7) == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(f[u & 7]));
+                    else if ((u & 7) < 3) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                    else if ((u & 7) < 5) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(f[u & 7]));
+                    else asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                }
+                else if (KIND == 6) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(f[u & 7]));
+                else if (KIND == 7) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 8) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(f[u & 7]));
+                else if (KIND == 9) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 10) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 11) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[u & 7]));
+                else if (KIND == 13) asm volatile("v_mov_b32 %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 14) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 15) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[u & 7]) : "v"(bb));
+                else if (KIND == 16) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned long long*>(&f[2 * (u & 3)])) : "v"(*reinterpret_cast<unsigned long long*>(&f[0])));
+                else if (KIND == 4) asm volatile("ds_write_b64 %0, %1" :: "v"((threadIdx.x & 255) * 8 + 16384), "v"(*reinterpret_cast<unsigned long long*>(&f[0])) : "memory");
+                else if (KIND == 5) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<uint4*>(&f[0])) : "v"((threadIdx.x & 255) * 16 + 16384) : "memory");
             }
         }
         float s = 0.f;
@@ -188,6 +208,13 @@ int main() {
             t[mode] = time_ms([&] { hipLaunchKernelGGL((two_waves_bf16<0, 64>), dim3(256), dim3(512), 0, 0, (const uint4*)in, out, iters, mode); });
         printf("bf16 32x32x16 + partner 64 v_fma (256 issue cycles): MFMA alone %.3f ms, vector alone %.3f, both %.3f (sum %.3f)\n",
                t[1], t[2], t[3], t[1] + t[2]);
+#define KINDRUN(K, NVV, NAME) \
+        for (int mode = 1; mode <= 3; ++mode) \
+            t[mode] = time_ms([&] { hipLaunchKernelGGL((two_waves_bf16<K, NVV, 1>), dim3(256), dim3(512), 32768, 0, (const uint4*)in, out, iters, mode); }); \
+        printf("bf16 MFMA + s_nop 2, partner %d x %s per 8 MFMAs: MFMA alone %.3f ms, partner alone %.3f, both %.3f (sum %.3f)\n", NVV, NAME, t[1], t[2], t[3], t[1] + t[2]);
+        KINDRUN(1, 16, "v_exp_f32") KINDRUN(2, 40, "v_cvt_pk_bf16_f32") KINDRUN(3, 40, "split mix") KINDRUN(4, 16, "ds_write_b64") KINDRUN(5, 8, "ds_read_b128 + wait")
+        KINDRUN(6, 40, "v_lshlrev_b32") KINDRUN(7, 40, "v_sub_f32") KINDRUN(8, 40, "v_and_b32") KINDRUN(9, 40, "v_max_f32") KINDRUN(10, 40, "v_mul_f32")
+        KINDRUN(11, 40, "v_add_f32") KINDRUN(12, 16, "v_rcp_f32") KINDRUN(13, 40, "v_mov_b32") KINDRUN(14, 16, "v_mul_lo_u32") KINDRUN(15, 40, "v_cndmask_b32") KINDRUN(16, 20, "v_pk_mul_f32")
 #define PADRUN(P) \
         for (int mode = 1; mode <= 3; ++mode) \
             t[mode] = time_ms([&] { hipLaunchKernelGGL((two_waves_bf16<0, 40, P>), dim3(256), dim3(512), 0, 0, (const uint4*)in, out, iters, mode); }); \
