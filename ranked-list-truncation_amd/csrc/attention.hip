@@ -595,6 +595,15 @@ static bool attn6_use(int HD, float drop_p) {
     (void)drop_p;
     return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD <= 64;
 }
+// RLT_ATTN6_IMG=1: ... staged from pre-split tile images (a prepare pass per call, LDS-DMA in the kernels) instead of every
+// workgroup splitting its tiles itself.  Off by default: measured at 4096 x 60 positions it takes the 176-352 split instructions per
+// tile out of the kernels (dQ 7.16 -> 6.82 ms, dK+dV 10.63 -> 10.50, ping-pong forward 9,900 -> 9,140 cycles per tile) and gives the
+// same time back in the two prepare passes (0.45 + 0.22 ms) - the kernels wait at their two barriers per tile for the staging
+// LATENCY, not for its instructions (profiles/r03_notes.md).  It is the staging a double-buffered form of dQ / dK+dV needs.
+static bool attn6_img(int HD) {
+    static const bool on = [] { const char* e = getenv("RLT_ATTN6_IMG"); return e && atoi(e) != 0; }();
+    return on && attn6_use(HD, 0.f);
+}
 
 // head dim 16 in the exact-fp32 mode: the 16x16x4-MFMA kernels of attention16.hip (RLT_ATTN16=0: the 32x32x2 kernels of this
 // file, whose d-indexed products are half padding at 16)
@@ -629,7 +638,8 @@ static size_t delta_bytes(int S, int B, int H) { return ((size_t)S * H * B * siz
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD) {
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
-    return attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 3) : 0;
+    if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
+    return attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 3) : 0;
 }
 
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
@@ -647,7 +657,15 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
         if (!rlt_aligned16(images)) return RLT_E_ALIGN;
         return rlt_attn3_run(0, a, HD, images, nullptr, st);
     }
-    if (attn6_use(HD, drop_p)) return rlt_attn6_run(0, a, HD, st);
+    if (attn6_use(HD, drop_p)) {
+        if (attn6_img(HD) && images && images_bytes >= rlt_attn6_images_bytes(S, B, H, HD, 3)) {
+            if (!rlt_aligned16(images)) return RLT_E_ALIGN;
+            a.img = images;
+            const int rc = rlt_attn6_run(3, a, HD, st);          // Q / K / V tile images (Q for the backward pass)
+            if (rc) return rc;
+        }
+        return rlt_attn6_run(0, a, HD, st);
+    }
     if (HD == 128) return launch_fwd<128>(a, st);
     if (HD == 64) return launch_fwd<64>(a, st);
     if (HD == 32) return launch_fwd<32>(a, st);
@@ -658,7 +676,8 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
-    return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0);
+    return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1)
+                                                      : attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 1) : 0);
 }
 
 // drop_p < 0: unknown (the stand-alone entry point), the dO records get both images
@@ -673,7 +692,14 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
     if (!split) {
         hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
-        return RLT_LAUNCH_RESULT();
+        int rc = RLT_LAUNCH_RESULT();
+        if (!rc && attn6_img(HD) && images && ws_bytes >= delta_bytes(S, B, H) + rlt_attn6_images_bytes(S, B, H, HD, 1)) {
+            AttnArgs a{};                                         // bf16x6 mode: the dO tile images behind delta
+            a.dout = dout; a.S = S; a.B = B; a.H = H;
+            a.dimg = (uint8_t*)ws + delta_bytes(S, B, H);
+            rc = rlt_attn6_run(4, a, HD, st);
+        }
+        return rc;
     }
     AttnArgs a{};       // split-bf16 mode: the pass that writes the dO records computes delta from the tiles it has in registers
     a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.S = S; a.B = B; a.H = H;
@@ -696,7 +722,14 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     hipStream_t st = rlt_stream(stream);
     if (attn_mode(HD) == 1 && images)
         return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
-    if (attn6_use(HD, drop_p)) return rlt_attn6_run(which, a, HD, st);
+    if (attn6_use(HD, drop_p)) {
+        AttnArgs b = a;
+        if (attn6_img(HD) && images) {                            // (forward wrote the Q / K / V images, bwd_prepare the dO images)
+            b.img = images;
+            b.dimg = (const uint8_t*)ws + delta_bytes(S, B, H);
+        }
+        return rlt_attn6_run(which, b, HD, st);
+    }
     if (HD == 16 && attn16_use()) return rlt_attn16_run(which, a, st);
     if (which == 1) {
         if (HD == 128) return launch_dkv<128>(a, st);

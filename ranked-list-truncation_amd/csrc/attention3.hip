@@ -15,17 +15,6 @@
 //    for the transposed image), not per MFMA.
 #include "attention_common.h"
 
-// One LDS-DMA piece as inline assembly: M0 carries the LDS destination.  hipcc treats M0 as a reserved register (a
-// clobber on it is rejected with a warning and ignored), so the statement saves and restores it: whatever the compiler
-// keeps in M0 around the asm (its own global_load_lds builtins in a mixed instantiation, movrel / readlane lowerings)
-// survives.  Two scalar moves per piece, ~5 pieces per wavefront and tile.
-#define RLT_DMA_ASM(dst, src)                                                                                         \
-    do {                                                                                                              \
-        uint32_t m0_keep_;                                                                                            \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(m0_keep_) : "s"(dst), "v"(src) : "memory");                                              \
-    } while (0)
-
 #include <stdlib.h>
 
 namespace {

@@ -98,6 +98,60 @@ __device__ __forceinline__ void stage6_store(uint16_t* __restrict__ img, int tid
     }
 }
 
+// ---- pre-split tile images in HBM (IMG kernels) ---------------------------------------------------------------------------
+// Without them every workgroup re-splits the same K / V (Q / dO) tiles - 16 to 32 workgroups per (position, head) pair - and the
+// split is vector work in kernels that are vector-ISSUE-bound (profiles/r03_notes.md).  A prepare pass writes each 64-row tile of
+// Q, K, V (forward) and dO (backward) ONCE as the three-plane image in exactly the LDS layout (padding included; 27 / 15 / 9 KiB at
+// head dim 64 / 32 / 16, whole 1 KiB LDS-DMA pieces), and the attention kernels stage a tile with `global_load_lds_dwordx4` - no
+// registers, no vector instructions.  Record (matrix m, pair, tile) at ((m * npair + pair) * ntile + tile) * img6_bytes.
+template <int HD> constexpr int img6_bytes() { return img6<HD>() * 2; }
+static_assert(img6_bytes<64>() % 1024 == 0 && img6_bytes<32>() % 1024 == 0 && img6_bytes<16>() % 1024 == 0, "whole LDS-DMA pieces");
+template <int HD>
+__device__ __forceinline__ const uint8_t* rec6(const void* img, int mat, int npair, int ntile, int pair, int tile) {
+    return reinterpret_cast<const uint8_t*>(img) + ((size_t)((size_t)mat * npair + pair) * ntile + tile) * img6_bytes<HD>();
+}
+// LDS-DMA copy of one image by NW wavefronts (inline assembly: invisible to hipcc's wait-count insertion - the caller waits with
+// dma_fence6() before the barrier that publishes the image)
+template <int HD, int NW>
+__device__ __forceinline__ void dma_image6(uint16_t* lds_img, const uint8_t* __restrict__ rec, int wv, int lane) {
+    constexpr int NP = img6_bytes<HD>() / 1024;
+#pragma unroll
+    for (int c = 0; c < (NP + NW - 1) / NW; ++c) {
+        const int chunk = wv + NW * c;
+        if (chunk < NP) {
+            // (wave-uniform: the LDS destination travels in M0)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(lds_img) + chunk * 1024));
+            const uint8_t* src = rec + chunk * 1024 + lane * 16;
+            RLT_DMA_ASM(dst, src);
+        }
+    }
+}
+__device__ __forceinline__ void dma_fence6() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the prepare pass: one workgroup per (pair, tile), blockIdx.y = matrix
+template <int HD>
+__global__ __launch_bounds__(256) void attn6_prepare_kernel(const float* __restrict__ src, size_t ld, int col0, int cstep, int S, int B, int H,
+                                                            uint8_t* __restrict__ img) {
+    const int tid = threadIdx.x, ntile = rlt_cdiv_dev(B, KT), npair = S * H;
+    const int pair = blockIdx.x / ntile, tile = blockIdx.x % ntile, mat = blockIdx.y;
+    const int s = pair / H, h = pair % H;
+    const float* base = src + (size_t)s * B * ld + col0 + mat * cstep + h * HD;
+    Stage6<HD> st;
+    stage6_load<HD>(base, ld, tile * KT, B, tid, st);
+    uint16_t* rec = reinterpret_cast<uint16_t*>(img + ((size_t)((size_t)mat * npair + pair) * ntile + tile) * img6_bytes<HD>());
+#pragma unroll
+    for (int i = 0; i < HD / 16; ++i) {
+        const int idx = tid + 256 * i;
+        uint2 hh_, mm_, ll_;
+        split4x3_6(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, hh_, mm_, ll_);
+        const int off = (idx / (HD / 4)) * ldr6<HD>() + 4 * (idx % (HD / 4));
+        *reinterpret_cast<uint2*>(rec + off) = hh_;
+        *reinterpret_cast<uint2*>(rec + plane6<HD>() + off) = mm_;
+        *reinterpret_cast<uint2*>(rec + 2 * plane6<HD>() + off) = ll_;
+    }
+}
+
 // this lane's half of a global row as B-operand fragments over d: frag[ks] covers d = 16 ks + 8 hh + j
 template <int HD>
 __device__ __forceinline__ void row_frags6(const float* __restrict__ rowp, int hh, float mul, Frag3 (&f)[HD / 16]) {
@@ -166,7 +220,7 @@ __device__ __forceinline__ void mma_cols6(const uint16_t* __restrict__ img, int 
 // DROP: train-mode dropout of the attention probabilities (same counter-based masks as the other two kernel families:
 // keep(pair seed, query, key) = row_hash(query) * col_hash(key) >= threshold; the hashes of a tile's rows / keys sit in a
 // 64-entry LDS table written at staging time, the lane's own hash in a register)
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool IMG>
 __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -200,15 +254,23 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     Stage6<HD> rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
-    stage6_load<HD>(base + E, ld, 0, B, tid, rk);
-    stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
-    stage6_store<HD>(Ki, tid, rk, 1.f);
-    stage6_store<HD>(Vi, tid, rv, 1.f);
+    const uint8_t* reck = IMG ? rec6<HD>(a.img, 1, a.S * H, nt, pair, 0) : nullptr;      // K / V tile images of this pair
+    const uint8_t* recv = IMG ? rec6<HD>(a.img, 2, a.S * H, nt, pair, 0) : nullptr;
+    if (IMG) {
+        dma_image6<HD, 4>(Ki, reck, wv, lane);
+        dma_image6<HD, 4>(Vi, recv, wv, lane);
+        dma_fence6();
+    } else {
+        stage6_load<HD>(base + E, ld, 0, B, tid, rk);
+        stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+        stage6_store<HD>(Ki, tid, rk, 1.f);
+        stage6_store<HD>(Vi, tid, rv, 1.f);
+    }
     if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
+        if (!IMG && t + 1 < nt) {
             stage6_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
             stage6_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
@@ -267,8 +329,14 @@ __global__ __launch_bounds__(256, 2) void attn6_fwd_kernel(AttnArgs a) {
         }
         __syncthreads();                         // every wavefront is done with the tile
         if (t + 1 < nt) {
-            stage6_store<HD>(Ki, tid, rk, 1.f);
-            stage6_store<HD>(Vi, tid, rv, 1.f);
+            if (IMG) {
+                dma_image6<HD, 4>(Ki, reck + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_image6<HD, 4>(Vi, recv + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_fence6();
+            } else {
+                stage6_store<HD>(Ki, tid, rk, 1.f);
+                stage6_store<HD>(Vi, tid, rv, 1.f);
+            }
             if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
@@ -323,7 +391,7 @@ __device__ unsigned long long pp_stamps[2 * 8 * 8];
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool IMG>
 __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
     constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -358,11 +426,21 @@ __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
     const int nt = rlt_cdiv_dev(B, KT);
     const float* src = base + (grp == 0 ? E : 2 * E);          // group A stages K, group B stages V
     uint16_t* mine = grp == 0 ? Ki : Vi;
+    // IMG: the group's tile images go global -> LDS by LDS-DMA, two tiles ahead (image t + 2 is requested in W(t), when its buffer -
+    // that of tile t - has been read by both groups, and awaited in W(t + 1)): the W segment has no vector work left
+    const uint8_t* rec = IMG ? rec6<HD>(a.img, grp == 0 ? 1 : 2, a.S * H, nt, pair, 0) : nullptr;
+    const int wv4 = wv & 3;
     Stage6<HD> st;
-    stage6_load<HD>(src, ld, 0, B, tid2, st);
-    stage6_store<HD>(mine, tid2, st, 1.f);
+    if (IMG) {
+        dma_image6<HD, 4>(mine, rec, wv4, lane);
+        if (nt > 1) dma_image6<HD, 4>(mine + IMG6, rec + img6_bytes<HD>(), wv4, lane);
+        dma_fence6();
+    } else {
+        stage6_load<HD>(src, ld, 0, B, tid2, st);
+        stage6_store<HD>(mine, tid2, st, 1.f);
+        if (nt > 1) stage6_load<HD>(src, ld, KT, B, tid2, st);
+    }
     if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
-    if (nt > 1) stage6_load<HD>(src, ld, KT, B, tid2, st);
     __syncthreads();
 
     f32x16 sc[2];
@@ -482,9 +560,14 @@ __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
     };
     auto seg_w = [&](int t) {
         if (t + 1 < nt) {
-            stage6_store<HD>(mine + ((t + 1) & 1) * IMG6, tid2, st, 1.f);
+            if (IMG) {
+                dma_fence6();                                    // image t + 1 (requested in W(t - 1) or the prologue) has landed
+                if (t + 2 < nt) dma_image6<HD, 4>(mine + (t & 1) * IMG6, rec + (size_t)(t + 2) * img6_bytes<HD>(), wv4, lane);
+            } else {
+                stage6_store<HD>(mine + ((t + 1) & 1) * IMG6, tid2, st, 1.f);
+                if (t + 2 < nt) stage6_load<HD>(src, ld, (t + 2) * KT, B, tid2, st);
+            }
             if (DROP && tid < KT) htab[((t + 1) & 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
-            if (t + 2 < nt) stage6_load<HD>(src, ld, (t + 2) * KT, B, tid2, st);
         }
     };
     // every wavefront executes 4 nt + 1 barriers
@@ -517,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool IMG>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -565,17 +648,27 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
             re = qi < B ? e : 0.f;
         }
     };
-    stage6_load<HD>(base, ld, 0, B, tid, rq);
-    stage6_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
+    const uint8_t* recq = IMG ? rec6<HD>(a.img, 0, a.S * H, nt, pair, 0) : nullptr;       // Q / dO tile images of this pair
+    const uint8_t* recd = IMG ? rec6<HD>(a.dimg, 0, a.S * H, nt, pair, 0) : nullptr;
+    if (IMG) {
+        dma_image6<HD, 4>(Qi, recq, wv, lane);
+        dma_image6<HD, 4>(Di, recd, wv, lane);
+    } else {
+        stage6_load<HD>(base, ld, 0, B, tid, rq);
+        stage6_load<HD>(dobase, (size_t)E, 0, B, tid, rd);
+    }
     load_small(0);
-    stage6_store<HD>(Qi, tid, rq, 1.f);
-    stage6_store<HD>(Di, tid, rd, 1.f);
+    if (IMG) dma_fence6();
+    else {
+        stage6_store<HD>(Qi, tid, rq, 1.f);
+        stage6_store<HD>(Di, tid, rd, 1.f);
+    }
     if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
     if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (RLT_A6_DKV_PREFETCH && t + 1 < nt) {
+        if (!IMG && RLT_A6_DKV_PREFETCH && t + 1 < nt) {
             stage6_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
             stage6_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
             load_small((t + 1) * KT);
@@ -612,15 +705,22 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
                 mma_cols6<HD>(Qi, sub, lane, dp, dk);                        // dK^T[d][key] += Q^T dS
             }
         }
-        if (!RLT_A6_DKV_PREFETCH && t + 1 < nt) {       // no registers held across the tile body; the partner workgroup covers the latency
+        if (!IMG && !RLT_A6_DKV_PREFETCH && t + 1 < nt) {       // no registers held across the tile body; the partner workgroup covers the latency
             stage6_load<HD>(base, ld, (t + 1) * KT, B, tid, rq);
             stage6_load<HD>(dobase, (size_t)E, (t + 1) * KT, B, tid, rd);
             load_small((t + 1) * KT);
         }
+        if (IMG && t + 1 < nt) load_small((t + 1) * KT);
         __syncthreads();
         if (t + 1 < nt) {
-            stage6_store<HD>(Qi, tid, rq, 1.f);
-            stage6_store<HD>(Di, tid, rd, 1.f);
+            if (IMG) {
+                dma_image6<HD, 4>(Qi, recq + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_image6<HD, 4>(Di, recd + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_fence6();
+            } else {
+                stage6_store<HD>(Qi, tid, rq, 1.f);
+                stage6_store<HD>(Di, tid, rd, 1.f);
+            }
             if (tid < KT) { Ls[tid] = rl; Es[tid] = re; }
             if (DROP && tid < KT) htab[tid] = rlt_row_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
@@ -633,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool IMG>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
     constexpr int DT = (HD + 31) / 32, IMG6 = img6<HD>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -669,15 +769,23 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     Stage6<HD> rk, rv;
     const int nt = rlt_cdiv_dev(B, KT);
-    stage6_load<HD>(base + E, ld, 0, B, tid, rk);
-    stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
-    stage6_store<HD>(Ki, tid, rk, 1.f);
-    stage6_store<HD>(Vi, tid, rv, 1.f);
+    const uint8_t* reck = IMG ? rec6<HD>(a.img, 1, a.S * H, nt, pair, 0) : nullptr;
+    const uint8_t* recv = IMG ? rec6<HD>(a.img, 2, a.S * H, nt, pair, 0) : nullptr;
+    if (IMG) {
+        dma_image6<HD, 4>(Ki, reck, wv, lane);
+        dma_image6<HD, 4>(Vi, recv, wv, lane);
+        dma_fence6();
+    } else {
+        stage6_load<HD>(base + E, ld, 0, B, tid, rk);
+        stage6_load<HD>(base + 2 * E, ld, 0, B, tid, rv);
+        stage6_store<HD>(Ki, tid, rk, 1.f);
+        stage6_store<HD>(Vi, tid, rv, 1.f);
+    }
     if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
+        if (!IMG && t + 1 < nt) {
             stage6_load<HD>(base + E, ld, (t + 1) * KT, B, tid, rk);
             stage6_load<HD>(base + 2 * E, ld, (t + 1) * KT, B, tid, rv);
         }
@@ -706,8 +814,14 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
         }
         __syncthreads();
         if (t + 1 < nt) {
-            stage6_store<HD>(Ki, tid, rk, 1.f);
-            stage6_store<HD>(Vi, tid, rv, 1.f);
+            if (IMG) {
+                dma_image6<HD, 4>(Ki, reck + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_image6<HD, 4>(Vi, recv + (size_t)(t + 1) * img6_bytes<HD>(), wv, lane);
+                dma_fence6();
+            } else {
+                stage6_store<HD>(Ki, tid, rk, 1.f);
+                stage6_store<HD>(Vi, tid, rv, 1.f);
+            }
             if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
         }
         __syncthreads();
@@ -718,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
 
 }  // namespace
 
-template <int HD, bool DROP>
+template <int HD, bool DROP, bool IMG>
 static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.S * a.H * rlt_cdiv(a.B, QT);
     const size_t shm = (size_t)2 * img6<HD>() * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
@@ -726,21 +840,43 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     static const bool pp = [] { const char* e = getenv("RLT_A6_PP"); return !e || atoi(e) != 0; }();    // RLT_A6_PP=0: the two-workgroup form
     if (which == 0 && HD == 64 && pp) {       // ping-pong form: one 512-thread workgroup per CU, 256 queries
         const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
-        if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP>, shm_pp))) return rc;
-        hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
+        if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP, IMG>, shm_pp))) return rc;
+        hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP, IMG>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
         return RLT_LAUNCH_RESULT();
     }
     if (which == 0) {
-        if ((rc = rlt_allow_lds(attn6_fwd_kernel<HD, DROP>, shm))) return rc;
-        hipLaunchKernelGGL((attn6_fwd_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_fwd_kernel<HD, DROP, IMG>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_fwd_kernel<HD, DROP, IMG>), dim3(grid), dim3(256), shm, st, a);
     } else if (which == 1) {
-        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel<HD, DROP>, shm))) return rc;
-        hipLaunchKernelGGL((attn6_bwd_dkv_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dkv_kernel<HD, DROP, IMG>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_bwd_dkv_kernel<HD, DROP, IMG>), dim3(grid), dim3(256), shm, st, a);
     } else {
-        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel<HD, DROP>, shm))) return rc;
-        hipLaunchKernelGGL((attn6_bwd_dq_kernel<HD, DROP>), dim3(grid), dim3(256), shm, st, a);
+        if ((rc = rlt_allow_lds(attn6_bwd_dq_kernel<HD, DROP, IMG>, shm))) return rc;
+        hipLaunchKernelGGL((attn6_bwd_dq_kernel<HD, DROP, IMG>), dim3(grid), dim3(256), shm, st, a);
     }
     return RLT_LAUNCH_RESULT();
+}
+template <int HD>
+static int attn6_prepare(int which, const AttnArgs& a, hipStream_t st) {
+    const int npair = a.S * a.H, ntile = rlt_cdiv(a.B, KT), E = a.H * HD;
+    if (which == 3)        // Q, K, V images from the packed qkv rows (column blocks 0, E, 2E)
+        hipLaunchKernelGGL((attn6_prepare_kernel<HD>), dim3(npair * ntile, 3), dim3(256), 0, st, a.qkv, (size_t)3 * E, 0, E, a.S, a.B, a.H,
+                           (uint8_t*)const_cast<void*>(a.img));
+    else                   // dO images
+        hipLaunchKernelGGL((attn6_prepare_kernel<HD>), dim3(npair * ntile, 1), dim3(256), 0, st, a.dout, (size_t)E, 0, 0, a.S, a.B, a.H,
+                           (uint8_t*)const_cast<void*>(a.dimg));
+    return RLT_LAUNCH_RESULT();
+}
+template <int HD, bool DROP>
+static int attn6_dispatch(int which, const AttnArgs& a, hipStream_t st) {
+    if (which >= 3) return attn6_prepare<HD>(which, a, st);
+    const bool img = a.img != nullptr && (which != 1 || a.dimg != nullptr);
+    return img ? attn6_launch<HD, DROP, true>(which, a, st) : attn6_launch<HD, DROP, false>(which, a, st);
+}
+
+size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat) {
+    const size_t per = HD == 64 ? img6_bytes<64>() : HD == 32 ? img6_bytes<32>() : img6_bytes<16>();
+    return (size_t)nmat * S * H * rlt_cdiv(B, KT) * per;
 }
 
 #ifdef RLT_PP_STAMPS
@@ -749,11 +885,11 @@ extern "C" int rlt_debug_pp_stamps(unsigned long long* out) {
 }
 #endif
 
-// which: 0 forward, 1 dK/dV, 2 dQ; head dim 16, 32 or 64 (the caller checks).  Dropout is a template parameter: hipcc
-// if-converts a run-time `drop_p > 0` test and executes the hashes regardless.
+// which: 0 forward, 1 dK/dV, 2 dQ, 3 / 4 the prepare passes; head dim 16, 32 or 64 (the caller checks).  Dropout is a template
+// parameter: hipcc if-converts a run-time `drop_p > 0` test and executes the hashes regardless.
 int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st) {
     const bool drop = a.drop_p > 0.f;
-    if (HD == 64) return drop ? attn6_launch<64, true>(which, a, st) : attn6_launch<64, false>(which, a, st);
-    if (HD == 32) return drop ? attn6_launch<32, true>(which, a, st) : attn6_launch<32, false>(which, a, st);
-    return drop ? attn6_launch<16, true>(which, a, st) : attn6_launch<16, false>(which, a, st);
+    if (HD == 64) return drop ? attn6_dispatch<64, true>(which, a, st) : attn6_dispatch<64, false>(which, a, st);
+    if (HD == 32) return drop ? attn6_dispatch<32, true>(which, a, st) : attn6_dispatch<32, false>(which, a, st);
+    return drop ? attn6_dispatch<16, true>(which, a, st) : attn6_dispatch<16, false>(which, a, st);
 }

@@ -4,11 +4,23 @@
 
 struct AttnArgs {
     const float* qkv; const float* out; const float* dout; const float* lse; const float* delta;
+    const void* img; const void* dimg;        // bf16x6 mode: pre-split three-plane tile images of Q / K / V and of dO (attention6.hip)
     float* o; float* lse_o; float* dqkv;
     int S, B, H;
     float scale;
     float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
 };
+
+// One LDS-DMA piece as inline assembly: M0 carries the LDS destination.  hipcc treats M0 as a reserved register (a
+// clobber on it is rejected with a warning and ignored), so the statement saves and restores it: whatever the compiler
+// keeps in M0 around the asm (its own global_load_lds builtins in a mixed instantiation, movrel / readlane lowerings)
+// survives.  Two scalar moves per piece, ~5 pieces per wavefront and tile.
+#define RLT_DMA_ASM(dst, src)                                                                                         \
+    do {                                                                                                              \
+        uint32_t m0_keep_;                                                                                            \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(m0_keep_) : "s"(dst), "v"(src) : "memory");                                              \
+    } while (0)
 
 namespace {
 
@@ -59,6 +71,9 @@ __device__ __forceinline__ void store_acc_T(float* __restrict__ dst_row, int hh,
 // fp32-faithful six-product path (bf16x6 mode, head dims 16 / 32 / 64), defined in attention6.hip: which = 0 forward,
 // 1 dK/dV, 2 dQ
 int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st);
+// ... with pre-split tile images (which = 3: write the Q / K / V images from a.qkv into a.img; 4: the dO images from a.dout into
+// a.dimg); nmat matrices of S*H pairs x ceil(B / 64) tiles
+size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat);
 // exact fp32 at head dim 16 on the 16x16x4 MFMA (no padded head-dim axis), defined in attention16.hip: same `which`
 int rlt_attn16_run(int which, const AttnArgs& a, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip

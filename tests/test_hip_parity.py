@@ -71,7 +71,7 @@ def probe():
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
                   "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
-MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank"]
+MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging"]
 
 
 def _run(probe, name):

@@ -1891,6 +1891,23 @@ def trainer_dp():
 
 
 @section
+def x6_image_staging():
+    """The bf16x6 attention kernels staged from pre-split tile images (RLT_ATTN6_IMG=1: a prepare pass per call, LDS-DMA in the
+    kernels; off by default, the switch is read once per process): the op-level attention sections in a child process."""
+    import subprocess
+    env = dict(os.environ, RLT_ATTN6_IMG="1", RLT_PRECISION="bf16x6")
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "attention", "scale_ops"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    report("x6_image_staging: child exit status", float(res.returncode), 0)
+    tail = [l for l in res.stdout.strip().splitlines() if " ok, " in l and "failed" in l]
+    ok, failed = (int(tail[-1].split()[0]), int(tail[-1].split()[2])) if tail else (0, 1)
+    report("x6_image_staging: checks failed in the child", float(failed), 0)
+    report("x6_image_staging: checks run in the child (>= 100)", 0.0 if ok >= 100 else 1.0, 0)
+    if res.returncode or failed:
+        print(res.stdout[-3000:], res.stderr[-2000:])
+
+
+@section
 def rccl_one_rank():
     """The RCCL code path on this one-GPU box: bench.py and run.py as fresh children of torch.distributed.run with ONE
     rank and RLT_FORCE_DIST=1 - init_process_group("nccl", device_id=...), the parameter broadcast, the all-reduce(AVG) of
