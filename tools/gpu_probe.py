@@ -361,6 +361,44 @@ def attention():
     qr = qkv.clone().double()
     od = ops.list_attention(_pm(qkv).to(dev), S, B, H)
     report("attn fwd sharp", rel(_unpm(od, B, S), _attn_ref(qr, H)), mfma_tol(2e-5))
+    # head dim 16 around the tile (64), wavefront (32) and workgroup (128 / 256) boundaries of its kernels
+    for B in (1, 17, 64, 65, 129, 257):
+        S, H, HD = 2, 2, 16
+        E = H * HD
+        qkv = torch.randn(B, S, 3 * E)
+        dout = torch.randn(B, S, E)
+        qr = qkv.clone().double().requires_grad_(True)
+        orf = _attn_ref(qr, H)
+        orf.backward(dout.double())
+        qd = _pm(qkv).to(dev).requires_grad_(True)
+        od = ops.list_attention(qd, S, B, H)
+        od.backward(_pm(dout).to(dev))
+        report(f"attn hd16 boundaries B{B}: fwd", rel(_unpm(od, B, S), orf), mfma_tol(1e-5))
+        report(f"attn hd16 boundaries B{B}: dqkv", rel(_unpm(qd.grad, B, S), qr.grad), mfma_tol(3e-5))
+    # lazy rescaling of the forward kernels (the softmax reference moves only when a score exceeds it by 2^8 = 5.5 natural units):
+    # scores that RISE by ~8.5 per 64-key tile (span 40) or ~60 (span 280) force the slow path in every tile, scores that FALL leave
+    # the first tile's reference in place while the later weights underflow; a ramp of 6 stays inside the lazy window.  At span 280
+    # one fp32 ulp of a score is 3e-5 and the weights of the top keys carry that as a RELATIVE error whatever the kernel does
+    # (measured 2.5e-5 .. 6e-5 on the f32 MFMA): that case has the looser bound.
+    for HD in (16, 64):
+        for tag, span, ftol in (("rising", 40.0, 2e-5), ("steeply rising", 280.0, 2e-4), ("falling", -280.0, 2e-5),
+                                ("inside the window", 6.0, 2e-5)):
+            B, S, H = 300, 2, 2
+            E = H * HD
+            ramp = torch.linspace(0.0, 1.0, B).view(B, 1, 1)
+            q = torch.full((B, S, E), 1.0) + 0.01 * torch.randn(B, S, E)
+            k = ramp * (span / math.sqrt(HD)) * torch.ones(B, S, E) + 0.01 * torch.randn(B, S, E)
+            v = torch.randn(B, S, E)
+            qkv = torch.cat([q, k, v], dim=2)
+            dout = torch.randn(B, S, E)
+            qr = qkv.clone().double().requires_grad_(True)
+            orf = _attn_ref(qr, H)
+            orf.backward(dout.double())
+            qd = _pm(qkv).to(dev).requires_grad_(True)
+            od = ops.list_attention(qd, S, B, H)
+            od.backward(_pm(dout).to(dev))
+            report(f"attn lazy rescale hd{HD} scores {tag}: fwd", rel(_unpm(od, B, S), orf), mfma_tol(ftol))
+            report(f"attn lazy rescale hd{HD} scores {tag}: dqkv", rel(_unpm(qd.grad, B, S), qr.grad), mfma_tol(5 * ftol))
 
 
 @section
