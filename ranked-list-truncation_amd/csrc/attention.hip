@@ -8,10 +8,14 @@
 // Flash-style, fp32 throughout on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products):
 // the score matrix is never written to memory.  One wavefront owns 32 queries (or 32 keys in the
 // dK/dV kernel); scores are produced TRANSPOSED (S^T = K Q^T) so that a query is a lane: the online
-// softmax over keys is a per-lane loop over the 16 accumulator registers plus one cross-half
-// shuffle, and the probability registers are directly the B operand of the P.V product - no LDS
-// round trip, no conversion.  K/V (or Q/dO) tiles of 64 rows are double-buffered in LDS with a
-// register prefetch, shared by the 4 wavefronts of a workgroup.
+// softmax over keys is a per-lane loop over the 16 accumulator registers (its reference moves lazily:
+// a cross-half shuffle and a rescale of O only when a score exceeds it by 2^8), and the probability
+// registers are directly the B operand of the P.V product - no LDS round trip, no conversion.  K/V
+// (or Q/dO) tiles of 64 rows are double-buffered in LDS with a register prefetch, shared by the 4
+// wavefronts of a workgroup.  The fp32 MFMA occupies the vector ALU on gfx950 (tools/micro/
+// mfma_valu_overlap.hip), so the kernels are written for the fewest vector instructions per score:
+// backward accumulators seeded with -lse / -delta, -inf seeds instead of range tests, select-free
+// staging of whole tiles.  Head dim 16 has its own file (attention16.hip: 16x16x4 MFMA).
 //
 // Backward recomputes the probabilities from the saved log-sum-exp (no B x B stash):
 //   kernel dKV: workgroup = 128 keys, loops over queries, accumulates dK^T, dV^T in registers
