@@ -4,27 +4,36 @@
 #include <stdlib.h>
 #include <string.h>
 
-// precision mode of the MFMA contractions: 0 = exact fp32 MFMA, 1 = split-bf16 (3 bf16 products, fp32 accumulate),
-// 2 = fp32-faithful six-product split for the GEMM family (attention and BiLSTM on the exact fp32 MFMA kernels)
-static int g_precision = -1;
-int rlt_precision() {
-    if (g_precision < 0) {
+// Precision mode of the MFMA contractions: RLT_PRECISION_FP32 = exact fp32 MFMA, RLT_PRECISION_BF16X3 = split-bf16 (3 bf16
+// products, 16 operand bits), RLT_PRECISION_BF16X6 = fp32-faithful six-product split (all 24 operand bits; GEMM family, list
+// attention at head dims <= 64, BiLSTM recurrences).
+//   g_default  the process default: env RLT_PRECISION at first use, else BF16X6 (the reference computes in fp32 end to end,
+//              models/AttnCut.py:8-14, so the default of a drop-in is a reference-faithful mode; bf16x3 is opt-in); written
+//              only by rlt_set_precision
+//   tl_scope   the mode of the entry-point call running on this thread (common.h: RltPrecScope), -1 outside any call
+static int g_default = -1;
+static thread_local int tl_scope = -1;
+static int default_precision() {
+    if (g_default < 0) {
         const char* e = getenv("RLT_PRECISION");
-        if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) g_precision = RLT_PRECISION_FP32;
-        else if (e && (!strcmp(e, "bf16x6") || !strcmp(e, "2"))) g_precision = RLT_PRECISION_BF16X6;
-        else g_precision = RLT_PRECISION_BF16X3;
+        if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) g_default = RLT_PRECISION_FP32;
+        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_default = RLT_PRECISION_BF16X3;
+        else g_default = RLT_PRECISION_BF16X6;
     }
-    return g_precision;
+    return g_default;
 }
+int rlt_precision() { return tl_scope >= 0 ? tl_scope : default_precision(); }
+RltPrecScope::RltPrecScope(int p) : saved(tl_scope), set(p >= 0) { if (set) tl_scope = p; }
+RltPrecScope::~RltPrecScope() { if (set) tl_scope = saved; }
 
 extern "C" {
 
 int rlt_set_precision(int mode) {
     if (mode != RLT_PRECISION_FP32 && mode != RLT_PRECISION_BF16X3 && mode != RLT_PRECISION_BF16X6) return RLT_E_ARG;
-    g_precision = mode;
+    g_default = mode;
     return 0;
 }
-int rlt_get_precision(void) { return rlt_precision(); }
+int rlt_get_precision(void) { return default_precision(); }
 
 int rlt_abi_version(void) { return RLT_ABI_VERSION; }
 

@@ -579,25 +579,31 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint32_t seed, i
 
 }  // namespace
 
-// 0 = exact fp32 MFMA kernels (parity mode), 1 = split-bf16 kernels of attention3.hip
-static int attn_mode_any() {
+// RLT_ATTN_MODE=fp32|bf16x3 forces the attention family into one mode whatever the call's precision (A/B runs): -1 = not set
+static int attn_forced() {
     static const int forced = [] {
         const char* e = getenv("RLT_ATTN_MODE");
         if (!e) return -1;
         return (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : 0;
     }();
-    return forced >= 0 ? forced : (rlt_precision() == RLT_PRECISION_BF16X3 ? 1 : 0);      // bf16x6 mode: the exact fp32 kernels
+    return forced;
+}
+// 0 = exact fp32 MFMA kernels (parity mode) or, in bf16x6 mode, the six-product kernels (attn6_use), 1 = split-bf16 kernels of
+// attention3.hip
+static int attn_mode_any() {
+    const int forced = attn_forced();
+    return forced >= 0 ? forced : (rlt_precision() == RLT_PRECISION_BF16X3 ? 1 : 0);
 }
 // head dims 16 / 32 / 64 have split-bf16 kernels; 128 (PLECut: d_model 256, 2 heads, models/PLECut.py:56) runs on the
 // exact-fp32 kernels in either mode (a correct, unhurried instantiation: it is not on a benchmarked configuration)
 static int attn_mode(int HD) { return HD <= 64 ? attn_mode_any() : 0; }
 static bool hd_ok(int HD) { return HD == 16 || HD == 32 || HD == 64 || HD == 128; }
-// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dims 16 / 32 / 64); RLT_ATTN6=0 keeps the
-// exact-fp32 kernels everywhere (A/B runs)
+// bf16x6 mode: the six-product kernels of attention6.hip where they exist (head dims 16 / 32 / 64); RLT_ATTN6=0 - or a forced
+// RLT_ATTN_MODE - keeps them out (A/B runs)
 static bool attn6_use(int HD, float drop_p) {
     static const bool on = [] { const char* e = getenv("RLT_ATTN6"); return !e || atoi(e) != 0; }();
     (void)drop_p;
-    return on && rlt_precision() == RLT_PRECISION_BF16X6 && HD <= 64;
+    return on && attn_forced() < 0 && rlt_precision() == RLT_PRECISION_BF16X6 && HD <= 64;
 }
 // RLT_ATTN6_IMG=1: ... staged from pre-split tile images (a prepare pass per call, LDS-DMA in the kernels) instead of every
 // workgroup splitting its tiles itself.  Off by default: measured at 4096 x 60 positions it takes the 176-352 split instructions per
@@ -639,7 +645,8 @@ int rlt_attention_dropout_mask_range(uint32_t seed, int pair0, int npair, int B,
 // ---- workspace layout of the backward pass: [ delta (S,H,B) floats, padded to 1 KiB | dO tile records (bf16x3) ]
 static size_t delta_bytes(int S, int B, int H) { return ((size_t)S * H * B * sizeof(float) + 1023) / 1024 * 1024; }
 
-size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD) {
+size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision) {
+    RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
@@ -647,7 +654,8 @@ size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD) {
 }
 
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
-                           float* out, float* lse, void* images, size_t images_bytes, void* stream) {
+                           float* out, float* lse, void* images, size_t images_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(qkv && out && lse && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(hd_ok(HD));
     if (!(rlt_aligned16(qkv) && rlt_aligned16(out))) return RLT_E_ALIGN;
@@ -662,7 +670,8 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
         return rlt_attn3_run(0, a, HD, images, nullptr, st);
     }
     if (attn6_use(HD, drop_p)) {
-        if (attn6_img(HD) && images && images_bytes >= rlt_attn6_images_bytes(S, B, H, HD, 3)) {
+        if (attn6_img(HD) && images) {       // the backward kernels will stage from these images: they must all be written
+            if (images_bytes < rlt_attn6_images_bytes(S, B, H, HD, 3)) return RLT_E_WORKSPACE;
             if (!rlt_aligned16(images)) return RLT_E_ALIGN;
             a.img = images;
             const int rc = rlt_attn6_run(3, a, HD, st);          // Q / K / V tile images (Q for the backward pass)
@@ -677,7 +686,8 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
     return launch_fwd<16>(a, st);
 }
 
-size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD) {
+size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, int precision) {
+    RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1)
@@ -690,14 +700,16 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
     RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0);
     RLT_CHECK_SHAPE(hd_ok(HD));
     const bool split = attn_mode(HD) == 1 && images;
-    if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1) : 0)) return RLT_E_WORKSPACE;
+    const bool img6 = !split && attn6_img(HD) && images;      // bwd_part hands ws + delta to the kernels as the dO images
+    if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1)
+                                                 : img6 ? rlt_attn6_images_bytes(S, B, H, HD, 1) : 0)) return RLT_E_WORKSPACE;
     hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
     if (!split) {
         hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, out, dout, S, B, H, HD, (float*)ws);
         int rc = RLT_LAUNCH_RESULT();
-        if (!rc && attn6_img(HD) && images && ws_bytes >= delta_bytes(S, B, H) + rlt_attn6_images_bytes(S, B, H, HD, 1)) {
+        if (!rc && img6) {
             AttnArgs a{};                                         // bf16x6 mode: the dO tile images behind delta
             a.dout = dout; a.S = S; a.B = B; a.H = H;
             a.dimg = (uint8_t*)ws + delta_bytes(S, B, H);
@@ -713,7 +725,8 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
 }
 
 int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
-                                   const void* images, void* ws, size_t ws_bytes, void* stream) {
+                                   const void* images, void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     return bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, -1.f, stream);
 }
 
@@ -748,22 +761,25 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
 }
 
 int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
-                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     return bwd_part(1, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
 }
 
 int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
-                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
+                              int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     return bwd_part(2, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
 }
 
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
-                           void* ws, size_t ws_bytes, void* stream) {
+                           void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     int rc = bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, drop_p, stream);     // knows whether dO^T is needed
-    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
     return rc;
 }
 

@@ -451,7 +451,8 @@ __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
     auto seg_x = [&](int t) {
         const uint16_t* img = Ki + (t & 1) * IMG6;
         auto frag = [&](int g) {
-            const int off = ((g >> 2) * 32 + l31) * LDR + 8 * hh + 16 * (g & 3);          // g = sub * 4 + ks   (HD / 16 = 4 k steps)
+            constexpr int KS_ = HD / 16;                                                    // g = sub * KS_ + ks
+            const int off = ((g / KS_) * 32 + l31) * LDR + 8 * hh + 16 * (g % KS_);
             Frag3 f;
             f.h = *reinterpret_cast<const bf16x8*>(img + off);
             f.m = *reinterpret_cast<const bf16x8*>(img + PL + off);
@@ -838,11 +839,13 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     const size_t shm = (size_t)2 * img6<HD>() * sizeof(uint16_t) + (which == 1 ? 2 * KT * sizeof(float) : 0) + KT * sizeof(uint32_t);
     int rc;
     static const bool pp = [] { const char* e = getenv("RLT_A6_PP"); return !e || atoi(e) != 0; }();    // RLT_A6_PP=0: the two-workgroup form
-    if (which == 0 && HD == 64 && pp) {       // ping-pong form: one 512-thread workgroup per CU, 256 queries
-        const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
-        if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP, IMG>, shm_pp))) return rc;
-        hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP, IMG>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
-        return RLT_LAUNCH_RESULT();
+    if constexpr (HD == 64) {                 // ping-pong form (instantiated for head dim 64 only): one 512-thread workgroup per CU, 256 queries
+        if (which == 0 && pp) {
+            const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
+            if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP, IMG>, shm_pp))) return rc;
+            hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP, IMG>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
+            return RLT_LAUNCH_RESULT();
+        }
     }
     if (which == 0) {
         if ((rc = rlt_allow_lds(attn6_fwd_kernel<HD, DROP, IMG>, shm))) return rc;

@@ -25,7 +25,27 @@ static inline int rlt_allow_lds(K kernel, size_t bytes) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-int rlt_precision();     // api.hip: RLT_PRECISION_FP32 / RLT_PRECISION_BF16X3 (env RLT_PRECISION, rlt_set_precision)
+// Precision mode of the MFMA contractions seen by the code of one entry-point call (api.hip).  Every entry point whose
+// arithmetic or buffer layout depends on the mode takes an `int precision` argument and opens a scope with it first thing:
+// RLT_PRECISION_FP32 / _BF16X3 / _BF16X6 select the mode for THAT call (and for the library calls it makes itself: they pass
+// RLT_PRECISION_DEFAULT and inherit the scope); RLT_PRECISION_DEFAULT outside any scope reads the process default
+// (rlt_set_precision, env RLT_PRECISION).  The scope is a thread-local value: calls on different threads - or one after the
+// other on one thread - with different modes do not see each other, and nothing but rlt_set_precision writes shared state.
+int rlt_precision();
+struct RltPrecScope {
+    int saved; bool set;
+    explicit RltPrecScope(int p);
+    ~RltPrecScope();
+    RltPrecScope(const RltPrecScope&) = delete;
+    RltPrecScope& operator=(const RltPrecScope&) = delete;
+};
+static inline bool rlt_precision_arg_ok(int p) {
+    return p == RLT_PRECISION_DEFAULT || p == RLT_PRECISION_FP32 || p == RLT_PRECISION_BF16X3 || p == RLT_PRECISION_BF16X6;
+}
+// first statement of an entry point with a `precision` argument: a code outside the four above is RLT_E_ARG (workspace
+// queries: 0 bytes)
+#define RLT_PREC_SCOPE(p)    if (!rlt_precision_arg_ok(p)) return RLT_E_ARG; RltPrecScope rlt_prec_scope_(p)
+#define RLT_PREC_SCOPE_SZ(p) if (!rlt_precision_arg_ok(p)) return 0;         RltPrecScope rlt_prec_scope_(p)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

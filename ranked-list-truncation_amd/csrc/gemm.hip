@@ -1548,9 +1548,10 @@ size_t rlt_gemm_workspace(int ta, int tb, int M, int N, int K) {
 int rlt_gemm(int ta, int tb, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, const float* bias2, int flags,
-             void* ws, size_t ws_bytes, void* stream) {
+             void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     return rlt_gemm_ex(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, nullptr, 0, 1.0f, nullptr,
-                       0.0f, 0u, ws, ws_bytes, stream);
+                       0.0f, 0u, ws, ws_bytes, RLT_PRECISION_DEFAULT, stream);
 }
 
 static int gemm_run(int ta, int tb, int M, int N, int K,
@@ -1626,7 +1627,8 @@ int rlt_gemm_ex(int ta, int tb, int M, int N, int K,
                 const float* bias, const float* bias2, int flags,
                 const float* relu_mask, int ldmask, float mask_scale, float* colsum_a,
                 float drop_p, uint32_t seed,
-                void* ws, size_t ws_bytes, void* stream) {
+                void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     return gemm_run(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, flags, relu_mask, ldmask, mask_scale, colsum_a,
                     drop_p, seed, nullptr, nullptr, ws, ws_bytes, stream);
 }
@@ -1637,7 +1639,8 @@ int rlt_gemm_bits(int ta, int tb, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, int flags, float drop_p, uint32_t seed,
                   uint32_t* relu_bits_out, const uint32_t* mask_bits_in, float mask_scale,
-                  void* stream) {
+                  int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG((relu_bits_out != nullptr) != (mask_bits_in != nullptr));
     RLT_CHECK_ARG(!relu_bits_out || (flags & RLT_GEMM_RELU));
     RLT_CHECK_ARG(drop_p == 0.f || relu_bits_out);

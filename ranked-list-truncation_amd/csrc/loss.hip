@@ -430,21 +430,42 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
         } else {
             // utils/losses.py:232-233, JS: (q ln(q/m) + p ln(p/m)) / 2 with m = (p + q) / 2.  In log2 units, with
             // s = p + q: q (log2 q - log2 s) + p (log2 p - log2 s) + s per position, scaled by ln 2 / 2 once per list;
-            // log2 of max(x, 2^-126): x = 0 contributes 0 (0 * finite), as the reference's 0 log 0 = 0.  (A denormal p
-            // also reads as 2^-126 here: its loss term is exact to 1e-36, its gradient (ln p - ln m) / 2 saturates at
-            // ln 2^-126 = -87.3 where the reference has up to -103; the general pass above has the exact form.)
+            // log2 of max(x, 2^-126): x = 0 contributes 0 (0 * finite), as the reference's 0 log 0 = 0.  v_log_f32 reads a DENORMAL
+            // p as zero, where the reference's gradient (ln p - ln m) / 2 is finite down to -103: a wavefront that holds one
+            // (a vote on the lane minima; a softmax over 300 logits can underflow that far, it is rare) takes the second loop,
+            // which scales such a p into the normal range first - the form of safe_log, as in the general pass above.
             // d/dp = (ln p - ln m) / 2: the gradient flows through log m AND the target p
             const float cg = 0.5f * 0.6931471805599453f * a.gscale;
+            float pmin = p[0];
 #pragma unroll
-            for (int n = 0; n < N; ++n) {
-                const float sm = p[n] + q[n];
-                const float l2s = __builtin_amdgcn_logf(sm);
-                const float dq_ = __builtin_amdgcn_logf(fmaxf(q[n], 1.17549435e-38f)) - l2s;
-                const float dp_ = __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f)) - l2s;
-                part = __builtin_fmaf(q[n], dq_, part);
-                part = __builtin_fmaf(p[n], dp_, part);
-                part += sm;
-                dpv[n] = __builtin_fmaf(dp_, cg, cg);
+            for (int n = 1; n < N; ++n) pmin = fminf(pmin, p[n]);
+            if (__builtin_amdgcn_ballot_w64(pmin < 1.17549435e-38f && pmin > 0.f) == 0) {
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const float sm = p[n] + q[n];
+                    const float l2s = __builtin_amdgcn_logf(sm);
+                    const float dq_ = __builtin_amdgcn_logf(fmaxf(q[n], 1.17549435e-38f)) - l2s;
+                    const float dp_ = __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f)) - l2s;
+                    part = __builtin_fmaf(q[n], dq_, part);
+                    part = __builtin_fmaf(p[n], dp_, part);
+                    part += sm;
+                    dpv[n] = __builtin_fmaf(dp_, cg, cg);
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const float sm = p[n] + q[n];
+                    const float l2s = __builtin_amdgcn_logf(sm);
+                    const float dq_ = __builtin_amdgcn_logf(fmaxf(q[n], 1.17549435e-38f)) - l2s;
+                    const bool den = p[n] < 1.17549435e-38f && p[n] > 0.f;
+                    const float l2p = den ? __builtin_amdgcn_logf(p[n] * 4294967296.f) - 32.f
+                                          : __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f));
+                    const float dp_ = l2p - l2s;
+                    part = __builtin_fmaf(q[n], dq_, part);
+                    part = __builtin_fmaf(p[n], dp_, part);
+                    part += sm;
+                    dpv[n] = __builtin_fmaf(dp_, cg, cg);
+                }
             }
             if (!last_ok) part -= 4.f;                        // the 4 positions beyond the list carry p = 1, q = 0: s = 1 each
             part *= 0.5f * 0.6931471805599453f;

@@ -507,7 +507,8 @@ static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w
 }
 
 int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
-                       float* h_out, float* c_out, void* stream) {
+                       float* h_out, float* c_out, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
     if (!(rlt_aligned16(gates) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(h_out) && rlt_aligned16(c_out)))
         return RLT_E_ALIGN;
@@ -518,7 +519,8 @@ int rlt_bilstm_rec_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_re
 int rlt_bilstm_rec_fwd_x(const float* x, int I, const float* w_ih_fwd, const float* b_ih_fwd, const float* b_hh_fwd,
                          const float* w_ih_rev, const float* b_ih_rev, const float* b_hh_rev,
                          const float* w_hh_fwd, const float* w_hh_rev, int S, int B,
-                         float* gates, float* h_out, float* c_out, void* stream) {
+                         float* gates, float* h_out, float* c_out, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w_ih_fwd && b_ih_fwd && b_hh_fwd && w_ih_rev && b_ih_rev && b_hh_rev);
     RLT_CHECK_ARG(gates && w_hh_fwd && w_hh_rev && h_out && c_out && S > 0 && B > 0);
     RLT_CHECK_SHAPE(I >= 1 && I <= 3);
@@ -533,7 +535,8 @@ int rlt_bilstm_rec_fwd_x(const float* x, int I, const float* w_ih_fwd, const flo
 }
 
 int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev,
-                       const float* d_hout, int S, int B, void* stream) {
+                       const float* d_hout, int S, int B, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(gates && c && w_hh_fwd && w_hh_rev && d_hout && S > 0 && B > 0);
     if (!(rlt_aligned16(gates) && rlt_aligned16(c) && rlt_aligned16(w_hh_fwd) && rlt_aligned16(w_hh_rev) && rlt_aligned16(d_hout)))
         return RLT_E_ALIGN;

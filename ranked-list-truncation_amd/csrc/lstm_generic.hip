@@ -122,7 +122,7 @@ int unpack2g(const float* in, size_t n, float* a, float* b, hipStream_t st) {
 int gemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
          int flags, float* colsum_a, const GScratch& k, void* stream) {
     return rlt_gemm_ex(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, nullptr, nullptr, flags, nullptr, 0, 1.f, colsum_a, 0.f, 0u,
-                       k.ws, k.ws_bytes, stream);
+                       k.ws, k.ws_bytes, RLT_PRECISION_DEFAULT, stream);
 }
 inline int cell_grid(int B, int Hd) { const int g = (2 * B * Hd + 255) / 256; return g < 2048 ? g : 2048; }
 
@@ -134,7 +134,7 @@ int layer_fwd(const float* x, int I, int Hd, const rlt_lstm_layer_weights& w, in
     RLT_TRY(pack2g(w.b_ih[0], w.b_ih[1], G4, k.bcat, st));
     RLT_TRY(pack2g(w.b_hh[0], w.b_hh[1], G4, k.bcat + G8, st));
     RLT_TRY(rlt_gemm_ex(0, 1, T, G8, I, x, I, k.wcat, I, gates, G8, k.bcat, k.bcat + G8, 0, nullptr, 0, 1.f, nullptr, 0.f, 0u,
-                        k.ws, k.ws_bytes, stream));
+                        k.ws, k.ws_bytes, RLT_PRECISION_DEFAULT, stream));
     for (int step = 0; step < S; ++step) {
         const int s_f = step, s_r = S - 1 - step;
         if (step > 0) {         // pre-activations += h_{t-1} W_hh^T, per direction
@@ -202,7 +202,8 @@ size_t rlt_bilstm_generic_bytes(int stash, int S, int B, int I, int hidden) {
 }
 
 int rlt_bilstm_generic_fwd(const float* x, int I, int hidden, const rlt_lstm_layer_weights* w, int S, int B, float* h_out,
-                           void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, void* stream) {
+                           void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w && h_out && stash && ws && I > 0 && hidden > 0 && S > 0 && B > 0 && wok(w[0]) && wok(w[1]));
     const size_t T = (size_t)S * B;
     RLT_CHECK_SHAPE(T * 8 * hidden <= 0x7fffffffu);
@@ -215,7 +216,8 @@ int rlt_bilstm_generic_fwd(const float* x, int I, int hidden, const rlt_lstm_lay
 
 int rlt_bilstm_generic_bwd(const float* x, int I, int hidden, const rlt_lstm_layer_weights* w, const float* h_out,
                            const float* dh_out, int S, int B, void* stash, size_t stash_bytes, float* dx,
-                           const rlt_lstm_layer_grads* g, void* ws, size_t ws_bytes, void* stream) {
+                           const rlt_lstm_layer_grads* g, void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w && h_out && dh_out && stash && g && ws && I > 0 && hidden > 0 && S > 0 && B > 0);
     RLT_CHECK_ARG(wok(w[0]) && wok(w[1]) && gok(g[0]) && gok(g[1]));
     const size_t T = (size_t)S * B;

@@ -51,7 +51,7 @@ inline EncStash enc_stash(const EncDims& d, void* base) {
     s.bits = d.bits ? c.take<uint32_t>(rlt_gemm_bits_words((int)T, d.FF) * sizeof(uint32_t)) : nullptr;
     s.ff = c.take(T * d.E * f);
     s.st2 = c.take(T * 2 * f);
-    s.images_bytes = rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD);
+    s.images_bytes = rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT);
     s.images = s.images_bytes ? c.take<uint8_t>(s.images_bytes) : nullptr;
     s.bytes = c.off;
     return s;
@@ -94,7 +94,7 @@ inline EncScratch enc_scratch(const EncDims& d, bool drop, void* base) {
     w.dr1 = drop ? c.take(T * d.E * f) : nullptr;
     w.datt = c.take(T * d.E * f);
     w.dqkv = c.take(T * 3 * d.E * f);
-    w.attn_ws_bytes = rlt_list_attention_bwd_workspace(d.S, d.B, d.H, d.HD);
+    w.attn_ws_bytes = rlt_list_attention_bwd_workspace(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT);
     w.attn_ws = c.take<uint8_t>(w.attn_ws_bytes);
     if (c.off < end_ffn) c.off = end_ffn;
     w.ln_ws_bytes = rlt_add_layernorm_bwd_workspace((int)T, d.E);
@@ -110,7 +110,7 @@ inline EncScratch enc_scratch(const EncDims& d, bool drop, void* base) {
 inline int gemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, int flags, float* colsum_a, void* ws, size_t ws_bytes, void* st) {
     return rlt_gemm_ex(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, flags, nullptr, 0, 1.f, colsum_a, 0.f, 0u,
-                       ws, ws_bytes, st);
+                       ws, ws_bytes, RLT_PRECISION_DEFAULT, st);
 }
 
 // ---------------------------------------------------------------------------------- BiLSTM stack
@@ -179,15 +179,15 @@ int lstm_layer_fwd(const float* x, int I, const rlt_lstm_layer_weights& w, int S
     const int T = S * B;
     if (I <= 3)            // narrow input (layer 0): the projection is formed inside the recurrence
         return rlt_bilstm_rec_fwd_x(x, I, w.w_ih[0], w.b_ih[0], w.b_hh[0], w.w_ih[1], w.b_ih[1], w.b_hh[1], w.w_hh[0], w.w_hh[1],
-                                    S, B, gates, h, c, stream);
+                                    S, B, gates, h, c, RLT_PRECISION_DEFAULT, stream);
     hipStream_t st = rlt_stream(stream);
     // input projections of both directions as one product (x is read once), biases b_ih + b_hh folded in
     RLT_TRY(pack2(w.w_ih[0], w.w_ih[1], (size_t)512 * I, sc.wcat, st));
     RLT_TRY(pack2(w.b_ih[0], w.b_ih[1], 512, sc.bcat, st));
     RLT_TRY(pack2(w.b_hh[0], w.b_hh[1], 512, sc.bcat + 1024, st));
     RLT_TRY(rlt_gemm_ex(0, 1, T, 1024, I, x, I, sc.wcat, I, gates, 1024, sc.bcat, sc.bcat + 1024, 0, nullptr, 0, 1.f, nullptr,
-                        0.f, 0u, sc.ws, sc.ws_bytes, stream));
-    return rlt_bilstm_rec_fwd(gates, w.w_hh[0], w.w_hh[1], S, B, h, c, stream);
+                        0.f, 0u, sc.ws, sc.ws_bytes, RLT_PRECISION_DEFAULT, stream));
+    return rlt_bilstm_rec_fwd(gates, w.w_hh[0], w.w_hh[1], S, B, h, c, RLT_PRECISION_DEFAULT, stream);
 }
 
 // gates <- d(pre-activation gates) in place; weight gradients written (=); dx (T,I) written when not NULL
@@ -195,7 +195,7 @@ int lstm_layer_bwd(const float* x, int I, const rlt_lstm_layer_weights& w, const
                    const float* dh, int S, int B, float* dx, const rlt_lstm_layer_grads& g, const LstmScratch& sc, void* stream) {
     const int T = S * B;
     hipStream_t st = rlt_stream(stream);
-    RLT_TRY(rlt_bilstm_rec_bwd(gates, c, w.w_hh[0], w.w_hh[1], dh, S, B, stream));
+    RLT_TRY(rlt_bilstm_rec_bwd(gates, c, w.w_hh[0], w.w_hh[1], dh, S, B, RLT_PRECISION_DEFAULT, stream));
     const float* dA = gates;
     if (I <= 3) {          // dW_ih of both directions and the bias gradients in ONE streaming pass over dA
         RLT_TRY(rlt_narrow_dw(dA, 1024, x, I, I, T, 1024, sc.dwcat, sc.dbcat, sc.ws, sc.ws_bytes, stream));
@@ -236,7 +236,8 @@ bool lstm_grads_ok(const rlt_lstm_layer_grads& g) {
 
 extern "C" {
 
-size_t rlt_workspace_bytes(int op, int S, int B, int E, int H, int FF, int train_dropout) {
+size_t rlt_workspace_bytes(int op, int S, int B, int E, int H, int FF, int train_dropout, int precision) {
+    RLT_PREC_SCOPE_SZ(precision);
     if (op == RLT_OP_ENCODER_STASH || op == RLT_OP_ENCODER_BWD_WS || op == RLT_OP_ENCODER_FWD_WS) {
         EncDims d;
         if (enc_dims(S, B, E, H, FF, d)) return 0;
@@ -254,7 +255,8 @@ size_t rlt_workspace_bytes(int op, int S, int B, int E, int H, int FF, int train
 
 int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, int B, int E, int H, int FF, float eps,
                           float drop_p, const uint32_t* seeds, float* y, void* stash, size_t stash_bytes,
-                          void* ws, size_t ws_bytes, void* stream) {
+                          void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w && y && stash && drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds));
     RLT_CHECK_ARG(w->in_proj_weight && w->in_proj_bias && w->out_proj_weight && w->out_proj_bias && w->norm1_weight &&
                   w->norm1_bias && w->linear1_weight && w->linear1_bias && w->linear2_weight && w->linear2_bias &&
@@ -268,7 +270,7 @@ int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, i
                    s_ffn = drop_p > 0.f ? seeds[2] : 0u, s_ln2 = drop_p > 0.f ? seeds[3] : 0u;
     // in_proj -> list-axis attention -> out_proj -> x + dropout1(.) -> norm1
     RLT_TRY(gemm(0, 1, T, 3 * E, E, x, E, w->in_proj_weight, E, s.qkv, 3 * E, w->in_proj_bias, 0, nullptr, ws, ws_bytes, stream));
-    RLT_TRY(rlt_list_attention_fwd(s.qkv, S, B, H, d.HD, drop_p, s_attn, s.att, s.lse, s.images, s.images_bytes, stream));
+    RLT_TRY(rlt_list_attention_fwd(s.qkv, S, B, H, d.HD, drop_p, s_attn, s.att, s.lse, s.images, s.images_bytes, RLT_PRECISION_DEFAULT, stream));
     RLT_TRY(gemm(0, 1, T, E, E, s.att, E, w->out_proj_weight, E, s.proj, E, w->out_proj_bias, 0, nullptr, ws, ws_bytes, stream));
     RLT_TRY(rlt_add_layernorm_fwd(x, s.proj, w->norm1_weight, w->norm1_bias, T, E, eps, drop_p, s_ln1, s.h1, s.st1, stream));
     // linear1 -> ReLU -> dropout -> linear2 -> h1 + dropout2(.) -> norm2
@@ -276,10 +278,10 @@ int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, i
         // 1-bit mask (passed the ReLU and kept by the dropout) for the backward dH product, which then reads T*FF/8
         // bytes instead of the 4*T*FF of `hid`
         RLT_TRY(rlt_gemm_bits(0, 1, T, FF, E, s.h1, E, w->linear1_weight, E, s.hid, FF, w->linear1_bias, RLT_GEMM_RELU,
-                              drop_p, s_ffn, s.bits, nullptr, 1.f, stream));
+                              drop_p, s_ffn, s.bits, nullptr, 1.f, RLT_PRECISION_DEFAULT, stream));
     } else {
         RLT_TRY(rlt_gemm_ex(0, 1, T, FF, E, s.h1, E, w->linear1_weight, E, s.hid, FF, w->linear1_bias, nullptr, RLT_GEMM_RELU,
-                            nullptr, 0, 1.f, nullptr, drop_p, s_ffn, ws, ws_bytes, stream));
+                            nullptr, 0, 1.f, nullptr, drop_p, s_ffn, ws, ws_bytes, RLT_PRECISION_DEFAULT, stream));
     }
     RLT_TRY(gemm(0, 1, T, E, FF, s.hid, FF, w->linear2_weight, FF, s.ff, E, w->linear2_bias, 0, nullptr, ws, ws_bytes, stream));
     return rlt_add_layernorm_fwd(s.h1, s.ff, w->norm2_weight, w->norm2_bias, T, E, eps, drop_p, s_ln2, y, s.st2, stream);
@@ -287,7 +289,8 @@ int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, i
 
 int rlt_encoder_layer_bwd(const float* x, const rlt_encoder_weights* w, int S, int B, int E, int H, int FF, float eps,
                           float drop_p, const uint32_t* seeds, const float* dy, const void* stash, size_t stash_bytes,
-                          float* dx, const rlt_encoder_grads* g, void* ws, size_t ws_bytes, void* stream) {
+                          float* dx, const rlt_encoder_grads* g, void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     (void)eps;
     RLT_CHECK_ARG(x && w && dy && stash && dx && g && ws && drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds));
     RLT_CHECK_ARG(g->in_proj_weight && g->in_proj_bias && g->out_proj_weight && g->out_proj_bias && g->norm1_weight &&
@@ -310,10 +313,10 @@ int rlt_encoder_layer_bwd(const float* x, const rlt_encoder_weights* w, int S, i
     // dH = (dY W2) * (H > 0) [/ (1-p)]: a dropped element has H == 0, so one mask covers ReLU and dropout
     if (d.bits) {
         RLT_TRY(rlt_gemm_bits(0, 0, T, FF, E, dr2, E, w->linear2_weight, FF, k.dhid, FF, nullptr, 0, 0.f, 0u, nullptr, s.bits,
-                              keep_scale, stream));
+                              keep_scale, RLT_PRECISION_DEFAULT, stream));
     } else {
         RLT_TRY(rlt_gemm_ex(0, 0, T, FF, E, dr2, E, w->linear2_weight, FF, k.dhid, FF, nullptr, nullptr, 0, s.hid, FF, keep_scale,
-                            nullptr, 0.f, 0u, k.gemm_ws, k.gemm_ws_bytes, stream));
+                            nullptr, 0.f, 0u, k.gemm_ws, k.gemm_ws_bytes, RLT_PRECISION_DEFAULT, stream));
     }
     RLT_TRY(gemm(1, 0, FF, E, T, k.dhid, FF, s.h1, E, g->linear1_weight, E, nullptr, 0, g->linear1_bias, k.gemm_ws, k.gemm_ws_bytes, stream));
     // dh1 = dz2 + dhid W1, accumulated in place
@@ -325,14 +328,15 @@ int rlt_encoder_layer_bwd(const float* x, const rlt_encoder_weights* w, int S, i
     RLT_TRY(gemm(1, 0, E, E, T, dr1, E, s.att, E, g->out_proj_weight, E, nullptr, 0, g->out_proj_bias, k.gemm_ws, k.gemm_ws_bytes, stream));
     RLT_TRY(gemm(0, 0, T, E, E, dr1, E, w->out_proj_weight, E, k.datt, E, nullptr, 0, nullptr, k.gemm_ws, k.gemm_ws_bytes, stream));
     RLT_TRY(rlt_list_attention_bwd(s.qkv, s.att, k.datt, s.lse, S, B, H, d.HD, drop_p, s_attn, s.images, k.dqkv,
-                                   k.attn_ws, k.attn_ws_bytes, stream));
+                                   k.attn_ws, k.attn_ws_bytes, RLT_PRECISION_DEFAULT, stream));
     RLT_TRY(gemm(1, 0, 3 * E, E, T, k.dqkv, 3 * E, x, E, g->in_proj_weight, E, nullptr, 0, g->in_proj_bias, k.gemm_ws, k.gemm_ws_bytes, stream));
     // dx = dz1 + dqkv W_in, accumulated in place
     return gemm(0, 0, T, E, 3 * E, k.dqkv, 3 * E, w->in_proj_weight, E, dx, E, nullptr, RLT_GEMM_ACCUMULATE, nullptr, k.gemm_ws, k.gemm_ws_bytes, stream);
 }
 
 int rlt_bilstm_fwd(const float* x, int I, const rlt_lstm_layer_weights* w, int S, int B, float* h_out,
-                   void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, void* stream) {
+                   void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w && h_out && stash && ws && I > 0 && S > 0 && B > 0 && lstm_weights_ok(w[0]) && lstm_weights_ok(w[1]));
     const size_t T = (size_t)S * B;
     RLT_CHECK_SHAPE(T <= 0x7fffffffu);
@@ -345,7 +349,8 @@ int rlt_bilstm_fwd(const float* x, int I, const rlt_lstm_layer_weights* w, int S
 
 int rlt_bilstm_bwd(const float* x, int I, const rlt_lstm_layer_weights* w, const float* h_out, const float* dh_out, int S, int B,
                    void* stash, size_t stash_bytes, float* dx, const rlt_lstm_layer_grads* g,
-                   void* ws, size_t ws_bytes, void* stream) {
+                   void* ws, size_t ws_bytes, int precision, void* stream) {
+    RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(x && w && h_out && dh_out && stash && g && ws && I > 0 && S > 0 && B > 0);
     RLT_CHECK_ARG(lstm_weights_ok(w[0]) && lstm_weights_ok(w[1]) && lstm_grads_ok(g[0]) && lstm_grads_ok(g[1]));
     const size_t T = (size_t)S * B;

@@ -18,7 +18,7 @@ METRIC_F1, METRIC_DCG = 0, 1
 LOSS_EXPECT, LOSS_CE, LOSS_KL, LOSS_JS = 0, 1, 2, 3
 GEMM_RELU, GEMM_ACCUMULATE = 1, 2
 HEAD_SOFTMAX, HEAD_SIGMOID, HEAD_IDENTITY = 0, 1, 2
-PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X6 = 0, 1, 2
+PRECISION_DEFAULT, PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X6 = -1, 0, 1, 2
 _PRECISION_NAMES = {PRECISION_FP32: "fp32", PRECISION_BF16X3: "bf16x3", PRECISION_BF16X6: "bf16x6"}
 
 P = c_void_p
@@ -49,10 +49,10 @@ _SIGNATURES = {
     "rlt_gemm_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rlt_gemm_bits_words": (c_size_t, [c_int, c_int]),
     "rlt_gemm_bits": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_float, c_uint32,
-                              P, P, c_float, P]),
-    "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P]),
+                              P, P, c_float, c_int, P]),
+    "rlt_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_size_t, c_int, P]),
     "rlt_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int, c_float,
-                            P, c_float, c_uint32, P, c_size_t, P]),
+                            P, c_float, c_uint32, P, c_size_t, c_int, P]),
     "rlt_dropout_mask": (c_int, [c_uint32, c_size_t, c_int, c_float, P, P]),
     "rlt_attention_dropout_mask": (c_int, [c_uint32, c_int, c_int, c_int, c_float, P, P]),
     "rlt_attention_dropout_mask_range": (c_int, [c_uint32, c_int, c_int, c_int, c_float, P, P]),
@@ -66,16 +66,16 @@ _SIGNATURES = {
     "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_uint32, P, P, P]),
     "rlt_add_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
     "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_uint32, P, P, P, P, c_int, P, c_size_t, P]),
-    "rlt_list_attention_fwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, P]),
-    "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, P]),
-    "rlt_list_attention_bwd_prepare": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
-    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
-    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P]),
-    "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
-    "rlt_bilstm_rec_fwd_x": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
-    "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "rlt_list_attention_fwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, c_int, P]),
+    "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, c_int, P]),
+    "rlt_list_attention_bwd_prepare": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, P]),
+    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
+    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
+    "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, c_int, P]),
+    "rlt_bilstm_rec_fwd_x": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, c_int, P]),
+    "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "rlt_to_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),
     "rlt_from_position_major": (c_int, [P, c_int, c_int, c_int, P, P]),
     "rlt_choopy_embed": (c_int, [P, P, c_int, c_int, c_int, P, P]),
@@ -89,14 +89,14 @@ _SIGNATURES = {
     "rlt_mmoe_mix_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "rlt_adam_step": (c_int, [P, P, P, P, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float, P]),
     # path-level entry points (one call per module forward / backward)
-    "rlt_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "rlt_encoder_layer_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, c_size_t, P]),
-    "rlt_encoder_layer_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, P, P, c_size_t, P]),
-    "rlt_bilstm_fwd": (c_int, [P, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, P]),
-    "rlt_bilstm_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, P]),
+    "rlt_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rlt_encoder_layer_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, c_size_t, c_int, P]),
+    "rlt_encoder_layer_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, c_size_t, P, P, P, c_size_t, c_int, P]),
+    "rlt_bilstm_fwd": (c_int, [P, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, c_int, P]),
+    "rlt_bilstm_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, c_int, P]),
     "rlt_bilstm_generic_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "rlt_bilstm_generic_fwd": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, P]),
-    "rlt_bilstm_generic_bwd": (c_int, [P, c_int, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, P]),
+    "rlt_bilstm_generic_fwd": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, c_size_t, P, c_size_t, c_int, P]),
+    "rlt_bilstm_generic_bwd": (c_int, [P, c_int, c_int, P, P, P, c_int, c_int, P, c_size_t, P, P, P, c_size_t, c_int, P]),
 }
 OP_ENCODER_STASH, OP_ENCODER_FWD_WS, OP_ENCODER_BWD_WS, OP_BILSTM_STASH, OP_BILSTM_WS = 1, 2, 3, 4, 5
 ENCODER_FIELDS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "norm1_weight", "norm1_bias",
@@ -151,17 +151,25 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.rlt_abi_version() != 2:
+    if lib.rlt_abi_version() != 3:
         raise RuntimeError("librlt_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
-def set_precision(mode):
-    """'fp32' (exact fp32 MFMA products), 'bf16x3' (split-bf16 products, the default) or 'bf16x6' (fp32-faithful
-    six-product split for the GEMM family, exact-fp32 attention and BiLSTM)."""
+def precision_code(mode):
+    """'fp32' | 'bf16x6' | 'bf16x3' | an RLT_PRECISION_* code -> the code."""
     code = {v: k for k, v in _PRECISION_NAMES.items()}.get(mode, mode)
-    check(load().rlt_set_precision(int(code)), "rlt_set_precision")
+    if code not in _PRECISION_NAMES:
+        raise ValueError(f"unknown precision mode {mode!r}: one of {sorted(_PRECISION_NAMES.values())}")
+    return int(code)
+
+
+def set_precision(mode):
+    """The PROCESS DEFAULT of the library: 'bf16x6' (fp32-faithful six-product split on the bf16 MFMA: the default), 'fp32'
+    (exact fp32 products on the f32 MFMA) or 'bf16x3' (opt-in fast mode, 16 operand bits).  Calls that name their own mode
+    (`ops.precision(...)`) do not read it."""
+    check(load().rlt_set_precision(precision_code(mode)), "rlt_set_precision")
 
 
 def get_precision():

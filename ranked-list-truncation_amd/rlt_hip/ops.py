@@ -61,6 +61,34 @@ def next_seed():
     return int((x * 0xBF58476D1CE4E5B9 >> 32) & 0xFFFFFFFF)
 
 
+_CALL_PRECISION = [N.PRECISION_DEFAULT]
+
+
+class precision:
+    """`with ops.precision('fp32'):` - every library call issued inside (the forward of the modules called there) runs in
+    that mode, whatever the process default (native.set_precision) is; each tape node remembers the mode of its forward and
+    gives it to its backward (the stash layout depends on it).  Re-entrant: nested scopes restore the outer one."""
+
+    def __init__(self, mode):
+        self.code = N.PRECISION_DEFAULT if mode is None else N.precision_code(mode)
+
+    def __enter__(self):
+        self.prev = _CALL_PRECISION[0]
+        _CALL_PRECISION[0] = self.code
+        return self
+
+    def __exit__(self, *exc):
+        _CALL_PRECISION[0] = self.prev
+        return False
+
+
+def current_precision():
+    """The RLT_PRECISION_* code a forward issued now runs in: the enclosing `precision(...)` scope's, else the process
+    default read once, so that forward and backward of a tape node agree even if the default is changed in between."""
+    c = _CALL_PRECISION[0]
+    return c if c >= 0 else int(N.load().rlt_get_precision())
+
+
 def _launch(name, fn):
     t = KernelTimer.active
     if t is None:
@@ -71,7 +99,7 @@ def _launch(name, fn):
 
 # ------------------------------------------------------------------------------ raw helpers
 def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=0, a_off=0, b_off=0, c_off=0,
-         relu_mask=None, ldmask=0, colsum_a=None, mask_scale=1.0, drop_p=0.0, seed=0):
+         relu_mask=None, ldmask=0, colsum_a=None, mask_scale=1.0, drop_p=0.0, seed=0, prec=None):
     """C[M,N] (+)= op(A) op(B) (+bias); *_off are element offsets into the tensors.
     relu_mask: C = mask > 0 ? C*mask_scale : 0 (fused ReLU/dropout backward); colsum_a (M): row sums of
     op(A) (ta=1 only); drop_p/seed: dropout on the output."""
@@ -81,16 +109,17 @@ def gemm(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, bias2=None, flags=
     call("rlt_gemm_ex", ta, tb, M, Nn, K,
          N.c_void_p(A.data_ptr() + a_off * esz), lda, N.c_void_p(B.data_ptr() + b_off * esz), ldb,
          N.c_void_p(C.data_ptr() + c_off * esz), ldc, ptr(bias), ptr(bias2), flags,
-         ptr(relu_mask), ldmask, mask_scale, ptr(colsum_a), drop_p, seed, ptr(ws), ws_bytes, stream())
+         ptr(relu_mask), ldmask, mask_scale, ptr(colsum_a), drop_p, seed, ptr(ws), ws_bytes,
+         current_precision() if prec is None else prec, stream())
 
 
 def gemm_bits(ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, bits_out=None, bits_in=None, mask_scale=1.0,
-              drop_p=0.0, seed=0):
+              drop_p=0.0, seed=0, prec=None):
     """rlt_gemm_bits: ReLU (+ dropout) forward that also emits a 1-bit mask of the surviving elements (bits_out,
     int32 (ceil(M/32), N): `alloc_relu_bits(M, N, device)`), or the masked backward product that consumes it (bits_in,
     mask_scale = 1/(1-p))."""
     call("rlt_gemm_bits", ta, tb, M, Nn, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), flags, drop_p, seed,
-         ptr(bits_out), ptr(bits_in), mask_scale, stream())
+         ptr(bits_out), ptr(bits_in), mask_scale, current_precision() if prec is None else prec, stream())
 
 
 def alloc_relu_bits(M, Nn, device):
@@ -119,7 +148,8 @@ class LinearFn(Function):
         T, K = x.shape
         Nn = w.shape[0]
         y = _empty((T, Nn), x)
-        gemm(0, 1, T, Nn, K, x, K, w, K, y, Nn, bias=b, flags=N.GEMM_RELU if relu else 0)
+        ctx.prec = current_precision()
+        gemm(0, 1, T, Nn, K, x, K, w, K, y, Nn, bias=b, flags=N.GEMM_RELU if relu else 0, prec=ctx.prec)
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -136,11 +166,11 @@ class LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _empty((T, K), x)
-            gemm(0, 0, T, K, Nn, dy, Nn, w, K, dx, K)
+            gemm(0, 0, T, K, Nn, dy, Nn, w, K, dx, K, prec=ctx.prec)
         if ctx.needs_input_grad[1]:
             dw = _empty((Nn, K), x)
             db = _empty((Nn,), x) if ctx.needs_input_grad[2] else None
-            gemm(1, 0, Nn, K, T, dy, Nn, x, K, dw, K, colsum_a=db)      # db rides on the dW product
+            gemm(1, 0, Nn, K, T, dy, Nn, x, K, dw, K, colsum_a=db, prec=ctx.prec)      # db rides on the dW product
         elif ctx.needs_input_grad[2]:
             db = _empty((Nn,), x)
             colsum(dy, Nn, T, Nn, db)
@@ -160,9 +190,10 @@ class FFNFn(Function):
         T, E = x.shape
         Fh = w1.shape[0]
         h = _empty((T, Fh), x)          # relu output, already dropped when drop_p > 0
-        gemm(0, 1, T, Fh, E, x, E, w1, E, h, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=seed)
+        ctx.prec = pr = current_precision()
+        gemm(0, 1, T, Fh, E, x, E, w1, E, h, Fh, bias=b1, flags=N.GEMM_RELU, drop_p=drop_p, seed=seed, prec=pr)
         y = _empty((T, w2.shape[0]), x)
-        gemm(0, 1, T, w2.shape[0], Fh, h, Fh, w2, Fh, y, w2.shape[0], bias=b2)
+        gemm(0, 1, T, w2.shape[0], Fh, h, Fh, w2, Fh, y, w2.shape[0], bias=b2, prec=pr)
         ctx.save_for_backward(x, w1, w2, h)
         ctx.drop_p = drop_p
         return y
@@ -173,17 +204,18 @@ class FFNFn(Function):
         T, E = x.shape
         Fh, Eo = w1.shape[0], w2.shape[0]
         dy = N.f32c(dy)
+        pr = ctx.prec
         dw2, db2 = _empty((Eo, Fh), x), _empty((Eo,), x)
-        gemm(1, 0, Eo, Fh, T, dy, Eo, h, Fh, dw2, Fh, colsum_a=db2)
+        gemm(1, 0, Eo, Fh, T, dy, Eo, h, Fh, dw2, Fh, colsum_a=db2, prec=pr)
         dh = _empty((T, Fh), x)
         # dH = (dY W2) * (H > 0) [/ (1-p)]: a dropped element has H == 0, so one mask covers ReLU and dropout
-        gemm(0, 0, T, Fh, Eo, dy, Eo, w2, Fh, dh, Fh, relu_mask=h, ldmask=Fh, mask_scale=1.0 / (1.0 - ctx.drop_p))
+        gemm(0, 0, T, Fh, Eo, dy, Eo, w2, Fh, dh, Fh, relu_mask=h, ldmask=Fh, mask_scale=1.0 / (1.0 - ctx.drop_p), prec=pr)
         dw1, db1 = _empty((Fh, E), x), _empty((Fh,), x)
-        gemm(1, 0, Fh, E, T, dh, Fh, x, E, dw1, E, colsum_a=db1)
+        gemm(1, 0, Fh, E, T, dh, Fh, x, E, dw1, E, colsum_a=db1, prec=pr)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty((T, E), x)
-            gemm(0, 0, T, E, Fh, dh, Fh, w1, E, dx, E)
+            gemm(0, 0, T, E, Fh, dh, Fh, w1, E, dx, E, prec=pr)
         return dx, dw1, db1, dw2, db2, None, None
 
 
@@ -235,10 +267,11 @@ class ListAttentionFn(Function):
         HD = E // H
         out = _empty((S * B, E), qkv)
         lse = _empty((S, H, B), qkv)
-        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+        ctx.prec = pr = current_precision()
+        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, pr)
         images = workspace(img_bytes, qkv.device) if img_bytes else None     # pre-split Q/K/V tile records (bf16x3 mode)
         _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, seed,
-                                         ptr(out), ptr(lse), ptr(images), img_bytes, stream()))
+                                         ptr(out), ptr(lse), ptr(images), img_bytes, pr, stream()))
         ctx.dims = (S, B, H, HD)
         ctx.drop = (drop_p, seed)
         ctx.images = images
@@ -252,14 +285,15 @@ class ListAttentionFn(Function):
         images = ctx.images
         dout = N.f32c(dout)
         dqkv = torch.empty_like(qkv)
-        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
+        pr = ctx.prec
+        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, pr)
         ws = workspace(ws_bytes, qkv.device)
         drop_p, seed = ctx.drop
-        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, stream())
+        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, pr, stream())
         _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
-                                             S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
+                                             S, B, H, HD, drop_p, seed, ptr(dqkv), pr, stream()))
         _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
-                                            S, B, H, HD, drop_p, seed, ptr(dqkv), stream()))
+                                            S, B, H, HD, drop_p, seed, ptr(dqkv), pr, stream()))
         ctx.images = None
         return dqkv, None, None, None, None, None
 
@@ -282,16 +316,17 @@ class EncoderLayerFn(Function):
         if T != S * B or in_w.shape != (3 * E, E) or w2.shape != (E, FF):
             raise RuntimeError(f"encoder layer: x {tuple(x.shape)} does not match S*B = {S * B} / the layer's weights")
         weights = (in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)
-        stash_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0)
-        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 0)
+        pr = current_precision()
+        stash_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0, pr)
+        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 0, pr)
         stash = N.byte_buffer(stash_bytes, x.device)
         ws = N.byte_buffer(ws_bytes, x.device)
         y = _empty((T, E), x)
         sarr = (N.c_uint32 * 4)(*seeds)
         wp = N.encoder_ptrs(weights)
         _launch("encoder_fwd", lambda: call("rlt_encoder_layer_fwd", ptr(x), N.ctypes.byref(wp), S, B, E, H, FF, eps, drop_p, sarr,
-                                            ptr(y), ptr(stash), stash_bytes, ptr(ws), ws_bytes, stream()))
-        ctx.cfg = (S, B, E, H, FF, eps, drop_p, tuple(seeds), stash_bytes)
+                                            ptr(y), ptr(stash), stash_bytes, ptr(ws), ws_bytes, pr, stream()))
+        ctx.cfg = (S, B, E, H, FF, eps, drop_p, tuple(seeds), stash_bytes, pr)
         ctx.stash = stash
         ctx.save_for_backward(x, *weights)
         return y
@@ -299,19 +334,19 @@ class EncoderLayerFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, *weights = ctx.saved_tensors
-        S, B, E, H, FF, eps, drop_p, seeds, stash_bytes = ctx.cfg
+        S, B, E, H, FF, eps, drop_p, seeds, stash_bytes, pr = ctx.cfg
         if ctx.stash is None:
             raise RuntimeError("EncoderLayerFn.backward frees its stash and can run only once")
         dy = N.f32c(dy)
         dx = torch.empty_like(x)
         grads = [torch.empty_like(w) for w in weights]
-        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1 if drop_p > 0 else 0)
+        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1 if drop_p > 0 else 0, pr)
         ws = N.byte_buffer(ws_bytes, x.device)
         sarr = (N.c_uint32 * 4)(*seeds)
         wp, gp = N.encoder_ptrs(weights), N.encoder_ptrs(grads)
         _launch("encoder_bwd", lambda: call("rlt_encoder_layer_bwd", ptr(x), N.ctypes.byref(wp), S, B, E, H, FF, eps, drop_p, sarr,
                                             ptr(dy), ptr(ctx.stash), stash_bytes, ptr(dx), N.ctypes.byref(gp),
-                                            ptr(ws), ws_bytes, stream()))
+                                            ptr(ws), ws_bytes, pr, stream()))
         ctx.stash = None
         return (dx, *grads, None, None, None, None, None, None)
 
@@ -329,19 +364,31 @@ class EncoderLayerKernelsFn(Function):
     adds per layer at B=4096)."""
 
     @staticmethod
-    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, S, B, H, eps, drop_p, seeds):
+    def forward(ctx, *args):
+        ctx.prec = current_precision()
+        with precision(ctx.prec):          # every gemm() below reads the scope
+            return EncoderLayerKernelsFn._forward(ctx, *args)
+
+    @staticmethod
+    def backward(ctx, dy):
+        with precision(ctx.prec):
+            return EncoderLayerKernelsFn._backward(ctx, dy)
+
+    @staticmethod
+    def _forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, S, B, H, eps, drop_p, seeds):
         T, E = x.shape
         HD = E // H
         Fh = w1.shape[0]
+        pr = ctx.prec
         s_attn, s_ln1, s_ffn, s_ln2 = seeds
         qkv = _empty((T, 3 * E), x)
         gemm(0, 1, T, 3 * E, E, x, E, in_w, E, qkv, 3 * E, bias=in_b)
         att = _empty((T, E), x)
         lse = _empty((S, H, B), x)
-        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, pr)
         images = workspace(img_bytes, x.device) if img_bytes else None
         _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, s_attn,
-                                         ptr(att), ptr(lse), ptr(images), img_bytes, stream()))
+                                         ptr(att), ptr(lse), ptr(images), img_bytes, pr, stream()))
         proj = _empty((T, E), x)
         gemm(0, 1, T, E, E, att, E, out_w, E, proj, E, bias=out_b)
         h1 = _empty((T, E), x)
@@ -369,9 +416,10 @@ class EncoderLayerKernelsFn(Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def _backward(ctx, dy):
         x, in_w, out_w, n1_w, w1, w2, n2_w, qkv, att, lse, proj, st1, h1, hid, ff, st2 = ctx.saved_tensors
         S, B, H, HD, eps, drop_p, (s_attn, s_ln1, s_ffn, s_ln2) = ctx.cfg
+        pr = ctx.prec
         T, E = x.shape
         Fh = w1.shape[0]
         dy = N.f32c(dy)
@@ -409,13 +457,13 @@ class EncoderLayerKernelsFn(Function):
         # attention
         images = ctx.images
         dqkv = torch.empty_like(qkv)
-        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD)
+        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, pr)
         ws = workspace(ws_bytes, x.device)
-        call("rlt_list_attention_bwd_prepare", ptr(att), ptr(datt), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, stream())
+        call("rlt_list_attention_bwd_prepare", ptr(att), ptr(datt), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, pr, stream())
         _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws),
-                                             S, B, H, HD, drop_p, s_attn, ptr(dqkv), stream()))
+                                             S, B, H, HD, drop_p, s_attn, ptr(dqkv), pr, stream()))
         _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws),
-                                            S, B, H, HD, drop_p, s_attn, ptr(dqkv), stream()))
+                                            S, B, H, HD, drop_p, s_attn, ptr(dqkv), pr, stream()))
         ctx.images = None
         # in_proj
         dw_in, db_in = _empty((3 * E, E), x), _empty((3 * E,), x)
@@ -465,9 +513,10 @@ class BiLSTMFn(Function):
             raise RuntimeError(f"BiLSTM input has {I} features x {T} rows; the layers were built for "
                                f"{w[0].shape[1]} features, hidden {Hd} and S*B = {S * B} rows")
         fast = Hd == 128
+        pr = current_precision()
         if fast:
-            stash_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, I, 0, 0, 0)
-            ws_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, I, 0, 0, 0)
+            stash_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, I, 0, 0, 0, pr)
+            ws_bytes = query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, I, 0, 0, 0, pr)
         else:
             stash_bytes = query("rlt_bilstm_generic_bytes", 1, S, B, I, Hd)
             ws_bytes = query("rlt_bilstm_generic_bytes", 0, S, B, I, Hd)
@@ -477,10 +526,10 @@ class BiLSTMFn(Function):
         wp = N.lstm_ptrs([w[0:8], w[8:16]])
         if fast:
             _launch("bilstm_fwd", lambda: call("rlt_bilstm_fwd", ptr(x), I, wp, S, B, ptr(h), ptr(stash), stash_bytes,
-                                               ptr(ws), ws_bytes, stream()))
+                                               ptr(ws), ws_bytes, pr, stream()))
         else:
-            call("rlt_bilstm_generic_fwd", ptr(x), I, Hd, wp, S, B, ptr(h), ptr(stash), stash_bytes, ptr(ws), ws_bytes, stream())
-        ctx.cfg = (S, B, I, Hd, stash_bytes, ws_bytes)
+            call("rlt_bilstm_generic_fwd", ptr(x), I, Hd, wp, S, B, ptr(h), ptr(stash), stash_bytes, ptr(ws), ws_bytes, pr, stream())
+        ctx.cfg = (S, B, I, Hd, stash_bytes, ws_bytes, pr)
         ctx.stash = stash
         ctx.save_for_backward(x, h, *w)
         return h
@@ -490,7 +539,7 @@ class BiLSTMFn(Function):
         if ctx.stash is None:
             raise RuntimeError("BiLSTMFn.backward overwrites its stash in place and can run only once")
         x, h, *w = ctx.saved_tensors
-        S, B, I, Hd, stash_bytes, ws_bytes = ctx.cfg
+        S, B, I, Hd, stash_bytes, ws_bytes, pr = ctx.cfg
         dh = N.f32c(dh)
         grads = [torch.empty_like(t) for t in w]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -498,10 +547,10 @@ class BiLSTMFn(Function):
         wp, gp = N.lstm_ptrs([w[0:8], w[8:16]]), N.lstm_ptrs([grads[0:8], grads[8:16]])
         if Hd == 128:
             _launch("bilstm_bwd", lambda: call("rlt_bilstm_bwd", ptr(x), I, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
-                                               ptr(dx), gp, ptr(ws), ws_bytes, stream()))
+                                               ptr(dx), gp, ptr(ws), ws_bytes, pr, stream()))
         else:
             call("rlt_bilstm_generic_bwd", ptr(x), I, Hd, wp, ptr(h), ptr(dh), S, B, ptr(ctx.stash), stash_bytes,
-                 ptr(dx), gp, ptr(ws), ws_bytes, stream())
+                 ptr(dx), gp, ptr(ws), ws_bytes, pr, stream())
         ctx.stash = None
         return (dx, None, None, *grads)
 

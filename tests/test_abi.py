@@ -25,26 +25,26 @@ def test_header_symbols_are_exported_and_bound(native):
     lib = native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rlt_abi_version() == 2
+    assert lib.rlt_abi_version() == 3
     assert b"workspace" in lib.rlt_error_string(-3)
 
 
 def test_workspace_queries_need_no_gpu(native):
     assert native.query("rlt_gemm_workspace", 1, 0, 2048, 256, 1228800) > 0     # split-K slabs for dW
     assert native.query("rlt_gemm_workspace", 0, 1, 1228800, 2048, 256) == 0
-    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64) >= 300 * 4096 * 4 * 4
+    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64, native.PRECISION_DEFAULT) >= 300 * 4096 * 4 * 4
     assert native.query("rlt_colsum_workspace", 1000, 64) > 0
 
 
 def test_argument_errors_are_reported_not_crashed(native):
     lib = native.load()
-    assert lib.rlt_gemm(0, 1, 0, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None, 0, None) == -1
+    assert lib.rlt_gemm(0, 1, 0, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, -1, None) == -1
+    assert lib.rlt_list_attention_fwd(None, 1, 1, 1, 64, 0.0, 0, None, None, None, 0, -1, None) == -1
     assert lib.rlt_heads_fwd(None, None, None, None, 1, 1, 1, 64, None, None) == -1
     # entry points added for the narrow (input_size <= 3) LSTM layer and the 1-bit ReLU mask
-    assert lib.rlt_bilstm_rec_fwd_x(None, 3, None, None, None, None, None, None, None, None, 1, 1, None, None, None, None) == -1
+    assert lib.rlt_bilstm_rec_fwd_x(None, 3, None, None, None, None, None, None, None, None, 1, 1, None, None, None, -1, None) == -1
     assert lib.rlt_narrow_dw(None, 4, None, 3, 3, 1, 4, None, None, None, 0, None) == -1
-    assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, 0.0, 0, None, None, 1.0, None) == -1
+    assert lib.rlt_gemm_bits(0, 1, 8, 32, 8, None, 8, None, 8, None, 32, None, 0, 0.0, 0, None, None, 1.0, -1, None) == -1
     assert lib.rlt_pair_softmax_fwd(None, 1, 1, 0.0, 0, None, None) == -1
     assert lib.rlt_wass_loss_fwd(None, None, 2, 2, 1e-3, 100, 0.1, None, None, 0, None) == -1
     assert native.query("rlt_wass_loss_workspace", 63, 100) > 2 * 63 * 63 * 4
@@ -63,27 +63,81 @@ def test_path_level_entry_points(native):
     lib = N.load()
     S, B, E, H, FF = 300, 4096, 256, 4, 2048
     T = S * B
-    stash = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0)
+    D = N.PRECISION_DEFAULT
+    stash = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0, D)
     rup = lambda n: (n + 255) // 256 * 256
     floats = rup(T * 3 * E * 4) + 4 * rup(T * E * 4) + rup(S * H * B * 4) + 2 * rup(T * 2 * 4) + rup(T * FF * 4)
     bits = rup(N.query("rlt_gemm_bits_words", T, FF) * 4)
-    images = rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H))
+    images = rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, D))
     assert stash == floats + bits + images
-    ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0)
-    ws1 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1)
+    ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0, D)
+    ws1 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1, D)
     assert ws1 - ws0 >= T * E * 4                       # train-mode dropout keeps the branch gradients apart
     assert ws0 >= T * E * 4 + T * FF * 4                # dz2 + dhid
-    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, 3, 0, 0, 0) == 2 * (rup(T * 1024 * 4) + rup(T * 256 * 4)) + rup(T * 256 * 4)
-    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, 3, 0, 0, 0) > T * 256 * 4
-    assert N.query("rlt_workspace_bytes", 99, S, B, E, H, FF, 0) == 0
-    assert N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 250, 4, FF, 0) == 0          # E % H != 0
-    assert lib.rlt_encoder_layer_fwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_encoder_layer_bwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, None, None, 0, None) == -1
-    assert lib.rlt_bilstm_fwd(None, 3, None, 1, 1, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_bilstm_bwd(None, 3, None, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
-    assert lib.rlt_bilstm_generic_fwd(None, 3, 64, None, 1, 1, None, None, 0, None, 0, None) == -1
-    assert lib.rlt_bilstm_generic_bwd(None, 3, 64, None, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
+    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_STASH, S, B, 3, 0, 0, 0, D) == 2 * (rup(T * 1024 * 4) + rup(T * 256 * 4)) + rup(T * 256 * 4)
+    assert N.query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, 3, 0, 0, 0, D) > T * 256 * 4
+    assert N.query("rlt_workspace_bytes", 99, S, B, E, H, FF, 0, D) == 0
+    assert N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 250, 4, FF, 0, D) == 0          # E % H != 0
+    assert lib.rlt_encoder_layer_fwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, 0, D, None) == -1
+    assert lib.rlt_encoder_layer_bwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, None, None, 0, D, None) == -1
+    assert lib.rlt_bilstm_fwd(None, 3, None, 1, 1, None, None, 0, None, 0, D, None) == -1
+    assert lib.rlt_bilstm_bwd(None, 3, None, None, None, 1, 1, None, 0, None, None, None, 0, D, None) == -1
+    assert lib.rlt_bilstm_generic_fwd(None, 3, 64, None, 1, 1, None, None, 0, None, 0, D, None) == -1
+    assert lib.rlt_bilstm_generic_bwd(None, 3, 64, None, None, None, 1, 1, None, 0, None, None, None, 0, D, None) == -1
     assert N.query("rlt_bilstm_generic_bytes", 1, 300, 8, 3, 64) == 2 * (rup(2400 * 512 * 4) + rup(2400 * 128 * 4)) + rup(2400 * 128 * 4)
+
+
+def test_precision_is_a_call_argument_and_the_default_is_reference_faithful(native):
+    """ABI v3: the mode is an argument of every entry point that depends on it; the process
+    default is only what RLT_PRECISION_DEFAULT resolves to, it is bf16x6 (fp32-faithful) unless the environment or
+    rlt_set_precision says otherwise, and a bad code is an argument error.  Workspace layouts follow the ARGUMENT: the
+    split-bf16 tile records exist in bf16x3 mode only, whatever the default is."""
+    N = native
+    lib = N.load()
+    keep = lib.rlt_get_precision()
+    try:
+        if "RLT_PRECISION" not in os.environ:
+            assert N.get_precision() == "bf16x6"
+        S, B, H, HD = 300, 4096, 4, 64
+        for default in ("fp32", "bf16x3", "bf16x6"):
+            N.set_precision(default)
+            assert N.get_precision() == default
+            img3 = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_BF16X3)
+            assert img3 > 0                                                   # Q / K / V tile records
+            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_FP32) == 0
+            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT) == (img3 if default == "bf16x3" else 0)
+            st3 = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 256, H, 2048, 0, N.PRECISION_BF16X3)
+            st6 = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 256, H, 2048, 0, N.PRECISION_BF16X6)
+            assert st3 - st6 == (img3 + 255) // 256 * 256
+        # a code outside {-1, 0, 1, 2}: argument error / 0 bytes, before anything else is looked at
+        assert lib.rlt_gemm(0, 1, 8, 8, 8, None, 8, None, 8, None, 8, None, None, 0, None, 0, 7, None) == -1
+        assert lib.rlt_encoder_layer_fwd(None, None, 1, 1, 64, 1, 64, 1e-5, 0.0, None, None, None, 0, None, 0, 3, None) == -1
+        assert N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 256, H, 2048, 0, 5) == 0
+        assert lib.rlt_set_precision(-1) == -1 and lib.rlt_set_precision(3) == -1
+        with pytest.raises(ValueError):
+            N.precision_code("fp64")
+    finally:
+        lib.rlt_set_precision(keep)
+
+
+def test_precision_scope_of_the_python_wrappers(native):
+    """ops.precision(...) scopes nest and restore; outside any scope the process default is what a forward would use."""
+    from rlt_hip import ops
+    N = native
+    keep = N.load().rlt_get_precision()
+    try:
+        N.set_precision("bf16x6")
+        assert ops.current_precision() == N.PRECISION_BF16X6
+        with ops.precision("fp32"):
+            assert ops.current_precision() == N.PRECISION_FP32
+            with ops.precision("bf16x3"):
+                assert ops.current_precision() == N.PRECISION_BF16X3
+            assert ops.current_precision() == N.PRECISION_FP32
+            N.set_precision("bf16x3")                      # the default does not leak into a scope
+            assert ops.current_precision() == N.PRECISION_FP32
+        assert ops.current_precision() == N.PRECISION_BF16X3
+    finally:
+        N.load().rlt_set_precision(keep)
 
 
 def test_models_mirror_reference_state_dict():

@@ -41,17 +41,17 @@ def attention(B=4096, S=60, H=4, HD=64, drop=0.0):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(S, H, B, device=dev)
     unit = B * B * HD * S * H / 1e9     # GFLOP per "2*B*B*HD" product /2
-    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
     images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
-    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD)
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
     ws = torch.empty(wb // 4 + 4, device=dev)
-    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop, 7, ptr(out), ptr(lse), ptr(images), ib, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop, 7, ptr(out), ptr(lse), ptr(images), ib, N.PRECISION_DEFAULT, stream()))
     print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_prep B{B} S{S} HD{HD}: {ms:8.3f} ms", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_dkv  B{B} S{S} HD{HD}: {ms:8.3f} ms  {8 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
 
 
@@ -140,9 +140,9 @@ def lstm(B=4096, S=300):
     c = torch.empty(T, 256, device=dev)
     dh = torch.randn(T, 256, device=dev)
     fl = 2.0 * 512 * 128 * T * 2 / 1e9
-    ms = timeit(lambda: call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), stream()), reps=2)
+    ms = timeit(lambda: call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), N.PRECISION_DEFAULT, stream()), reps=2)
     print(f"bilstm_fwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, stream()), reps=2)
+    ms = timeit(lambda: call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, N.PRECISION_DEFAULT, stream()), reps=2)
     print(f"bilstm_bwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
 
 
@@ -160,14 +160,14 @@ def overlap(B=4096, S=300):
     h = torch.empty(T, 256, device=dev)
     c = torch.empty(T, 256, device=dev)
     dh = torch.randn(T, 256, device=dev)
-    call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), stream())
+    call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), N.PRECISION_DEFAULT, stream())
     hid = torch.randn(T, 2048, device=dev)
     dy = torch.randn(T, 256, device=dev)
     dw = torch.empty(2048, 256, device=dev)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
     def rec():
-        call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, stream())
+        call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, N.PRECISION_DEFAULT, stream())
 
     def gemm_tn():
         ops.gemm(1, 0, 2048, 256, T, hid, 2048, dy, 256, dw, 256)

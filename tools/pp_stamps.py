@@ -12,11 +12,11 @@ dev = torch.device("cuda")
 B, S, H, HD = 4096, 8, 4, 64
 E = H * HD
 qkv = torch.randn(S * B, 3 * E, device=dev); out = torch.empty(S * B, E, device=dev); lse = torch.empty(S, H, B, device=dev)
-ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD)
+ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
 images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
 print("image workspace bytes:", ib)
 for _ in range(3):
-    call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 7, ptr(out), ptr(lse), ptr(images), ib, stream())
+    call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 7, ptr(out), ptr(lse), ptr(images), ib, N.PRECISION_DEFAULT, stream())
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["RLT_HIP_LIB"])
 buf = (ctypes.c_ulonglong * 128)()
