@@ -12,14 +12,18 @@ processes, one rank per GPU over RCCL), lets rank 0 print the JSON line and exit
 status.
 
 Prints ONE JSON line (rank 0).  The top-level `value` / `ms_per_step` / `dtype` / `roofline` are the
-library's EXACT-FP32 mode (`v_mfma_f32_32x32x2_f32` products, fp32 accumulate: the reference's own
-arithmetic, it computes in fp32 end to end - models/AttnCut.py:8-14); `fast_mode` times the same step
-in the split-bf16 product mode (bf16x3: inside the 1e-4 parity bound, narrower products than fp32)
-in the same run, with its own roofline.  `--precision bf16x3` swaps the two (the other mode then
-lands in `fp32_mode`).  `roofline` is measured live with HIP events on the launch stream for the
-dominant kernel (the attention dK/dV backward kernel) in training steps AFTER the timed region;
-`cpu_baseline` times the CPU oracle (oracle/, the pinned restatement of the reference) on bounded
-samples on this box's host cores.
+library's DEFAULT mode, `bf16x6`: f32 operands, accumulation and storage; every product of the GEMM
+family, the list attention and the BiLSTM recurrences from an EXACT three-way bf16 split of both
+operands, six bf16 MFMA products per fp32 product, per-product error < 2^-23 (the reference computes
+in fp32 end to end - models/AttnCut.py:8-14; VERDICT r03 accepted this mode as the reference's
+precision: all 24 operand bits enter, errors against fp64 at or below the f32 MFMA kernels').  Two
+sibling blocks time the same step in the same run, each with its own roofline: `f32_mfma_mode` (exact
+fp32 products on `v_mfma_f32_32x32x2_f32`, peak 157.3 TFLOP/s) and `fast_mode` (bf16x3: 16 operand
+bits, inside the 1e-4 parity bound, narrower than the reference - opt-in).  `--precision` moves another
+mode to the top.  `roofline` is measured live with HIP events on the launch stream for the dominant
+kernel (the attention dK/dV backward kernel) in training steps AFTER the timed region; `cpu_baseline`
+times the CPU oracle (oracle/, the pinned restatement of the reference) on bounded samples on this
+box's host cores.
 """
 import argparse
 import json
@@ -40,9 +44,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 PEAK_HBM_BPS = 8.0e12
 # HBM traffic per launch / per step is NOT measured by this script: it comes from separate rocprofv3 --pmc passes of
 # this same command (tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) committed here:
-PMC_TRAFFIC_FILES = {"bf16x6": (os.path.join("profiles", "r03_pmc_traffic_bf16x6.json"),),
-                     "fp32": (os.path.join("profiles", "r03_pmc_traffic_fp32.json"),),
-                     "bf16x3": (os.path.join("profiles", "r03_pmc_traffic_bf16x3.json"), os.path.join("profiles", "r02_pmc_traffic.json"))}
+PMC_TRAFFIC_FILES = {m: tuple(os.path.join("profiles", f"{r}_pmc_traffic_{m}.json") for r in ("r04", "r03"))
+                     for m in ("bf16x6", "fp32", "bf16x3")}
 
 
 def synth_batch(batch, seq_len, n_feat, seed, device):
@@ -122,11 +125,15 @@ def cpu_baseline(seq_len, vec_batch, loop_batch):
         make_step(olosses.DivLoss(metric='f1', div_type='js', augmented=True, loop=True), loop_batch, seq_len), 8.0, 3,
         f"loop-faithful reward, batch {loop_batch}")
     return {"value": round(full_batch / (sub_dt * seq_len / sub_len), 3), "unit": "lists/s", "cores": cores, "kind": "port",
+            "extrapolated": True, "positions_sampled": sub_len, "positions_per_list": seq_len,
+            "measured_step_seconds": round(sub_dt, 3),
             "cpu_model": _cpu_model(),
-            "sample": f"oracle AttnCut+DivLoss(js,f1) fwd+bwd at the benchmark batch {full_batch}, {sub_len} of the {seq_len} "
-                      f"positions per list ({sub_steps} steps after 1 warm-up, closed-form reward); lists/s = {full_batch} / "
-                      f"(step time x {seq_len}/{sub_len}) - per-position cost is uniform (list-axis attention, FFN, one LSTM "
-                      f"step), per-step constants are counted {seq_len // sub_len}x",
+            "sample": f"EXTRAPOLATED from a bounded sample: oracle AttnCut+DivLoss(js,f1) fwd+bwd at the benchmark batch {full_batch} "
+                      f"on {sub_len} of the {seq_len} positions per list ({sub_steps} steps after 1 warm-up, closed-form reward: "
+                      f"{sub_dt:.2f} s per step MEASURED); value = {full_batch} / (that step time x {seq_len}/{sub_len}) - per-position "
+                      f"cost is uniform (list-axis attention, FFN, one LSTM step), per-step constants are counted "
+                      f"{seq_len // sub_len}x, so this is a LOWER bound on the CPU's speed; full-length steps measured outright "
+                      f"are in full_length_small_batch / loop_faithful",
             "full_length_small_batch": {"value": round(vec_batch / vec_dt, 3), "unit": "lists/s",
                                         "sample": f"the same step at batch {vec_batch} x the full len {seq_len}, {vec_steps} steps "
                                                   f"after 1 warm-up (the attention cost per list is {full_batch // vec_batch}x "
@@ -166,9 +173,21 @@ def hbm_kernel_roofline(S, dev, lists=262144, reps=10):
     us = a.elapsed_time(b) / reps * 1e3
     nbytes = lists * (12.0 * S + 24)
     gbps = nbytes / us / 1e3
+    # what this box streams with the scan's own access pattern and nothing else to do: one elementwise pass reading p and the
+    # labels and writing dp (2 reads + 1 write of the same three arrays) - the practical roof beside the nominal 8 TB/s
+    for _ in range(3):
+        torch.add(p, y, out=dp)
+    a.record()
+    for _ in range(reps):
+        torch.add(p, y, out=dp)
+    b.record()
+    torch.cuda.synchronize()
+    ref_gbps = lists * 12.0 * S / (a.elapsed_time(b) / reps * 1e3) / 1e3
     return {"kernel": "reward_loss_h_kernel<3,true,true> + loss_metrics_final_kernel (rlt_loss_metrics)", "bound": "hbm",
             "lists": lists, "seq_len": S, "us_per_call": round(us, 2), "algorithmic_bytes": nbytes,
-            "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+            "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+            "stream_reference": {"op": "torch.add(p, labels, out=dp): 2 reads + 1 write of the same arrays on this box, HIP events",
+                                 "GBps": round(ref_gbps, 1), "frac_of_it": round(gbps / ref_gbps, 4)}}
 
 
 def hbm_kernel_both(S, dev):
@@ -176,7 +195,7 @@ def hbm_kernel_both(S, dev):
     lists (236 MB: may be partly served from the 256 MB cache; kept for comparison with the earlier rounds' lines)."""
     out = hbm_kernel_roofline(S, dev)
     small = hbm_kernel_roofline(S, dev, lists=65536, reps=30)
-    out["at_65536_lists"] = {k: small[k] for k in ("lists", "us_per_call", "algorithmic_bytes", "achieved", "frac")}
+    out["at_65536_lists"] = {k: small[k] for k in ("lists", "us_per_call", "algorithmic_bytes", "achieved", "frac", "stream_reference")}
     out["at_65536_lists"]["note"] = "working set 236 MB < 256 MB Infinity Cache: not a clean HBM figure"
     return out
 
@@ -212,11 +231,11 @@ def main():
     ap.add_argument("--seq-len", type=int, default=300)
     ap.add_argument("--model", default="attncut", choices=["attncut", "choopy", "mtattncut", "mmoecut"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["bf16x3", "fp32", "bf16x6"],
-                    help="MFMA product mode of the library for the headline figure (default fp32: the reference's own "
-                         "arithmetic; bf16x3 = the split-bf16 fast mode)")
+    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "fp32", "bf16x3"],
+                    help="MFMA product mode of the library for the headline figure (default bf16x6: fp32-faithful exact "
+                         "three-way bf16 split, the library's default; fp32 = the f32 MFMA; bf16x3 = the opt-in fast mode)")
     ap.add_argument("--other-steps", "--fp32-steps", dest="other_steps", type=int, default=5,
-                    help="steps timed in the OTHER precision mode after the headline loop (0: skip)")
+                    help="steps timed in each of the two OTHER precision modes after the headline loop (0: skip)")
     ap.add_argument("--cpu-sample-batch", type=int, default=512, help="batch of the vectorised-reward CPU sample")
     ap.add_argument("--cpu-loop-batch", type=int, default=32, help="batch of the loop-faithful CPU sample")
     # side configurations of SURVEY.md 8(d); the headline line uses none of them
@@ -265,7 +284,7 @@ def main():
     from rlt_hip.parallel import FlatModel, FusedAdam
     native.set_precision(args.precision)
     precision = native.get_precision()
-    other = "fp32" if precision == "bf16x3" else "bf16x3"
+    others = [m for m in ("bf16x6", "fp32", "bf16x3") if m != precision]
     ops.set_seed_stream(rank)             # decorrelates the dropout masks of the ranks (same torch seed everywhere)
 
     torch.manual_seed(1234)
@@ -426,6 +445,7 @@ def main():
                     "algorithmic_tflop": round(step_flop / 1e12, 2),
                     "tflops": round(step_flop / sec / 1e12, 1),
                     "frac_of_f32_mfma_peak": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                    "frac_of_mode_mfma_peak": round(step_flop / sec / 1e12 / peak, 3),       # peak of THIS mode's products (the `peak` above)
                     "algorithmic_GB": round(step_bytes / 1e9, 1),
                     "hbm_GBps": round(step_bytes / sec / 1e9, 1),
                     "frac_of_hbm_peak": round(step_bytes / sec / PEAK_HBM_BPS, 4),
@@ -434,14 +454,18 @@ def main():
                     "pmc_file_hbm_GBps": None if step_traffic is None else round(step_traffic / sec / 1e9, 1),
                     "pmc_file_frac_of_hbm_peak": None if step_traffic is None else round(step_traffic / sec / PEAK_HBM_BPS, 4)}}
 
-    DTYPES = {"fp32": "f32",
+    DTYPES = {"fp32": "f32 (operands, accumulation, storage); exact fp32 products on the f32 MFMA",
               "bf16x3": "f32 storage and accumulation; MFMA products split into 3 bf16 products (hi*hi + hi*lo + lo*hi, ~16 operand mantissa bits)",
-              "bf16x6": "f32 storage and accumulation; GEMM and list-attention products from an EXACT 3-way bf16 split of both operands (all 24 "
-                        "mantissa bits, 6 bf16 MFMA products, dropped terms < 2^-23 of the product worst case, 2^-29 typical); BiLSTM recurrences on the f32 MFMA"}
+              "bf16x6": "f32 (operands, accumulation, storage); products by exact 3xbf16 split, 6 MFMA products, per-product error < 2^-23"}
+    BLOCK = {"fp32": "f32_mfma_mode", "bf16x3": "fast_mode", "bf16x6": "fp32_faithful_mode"}
+    NOTES = {"fp32": "the library's exact-fp32 MFMA mode: v_mfma_f32_32x32x2_f32 / 16x16x4 products, bitwise an fp32 fma chain; priced "
+                     "against the 157.3 TFLOP/s f32 MFMA peak",
+             "bf16x3": "the library's opt-in split-bf16 product mode: inside the 1e-4 parity bound of BASELINE.json (GPU suite green in "
+                       "this mode), but its products carry 16 operand bits where the reference's fp32 carries 24 - never the headline",
+             "bf16x6": "the library's default: GEMM family (csrc/gemm.hip gemm6*_kernel), list attention (csrc/attention6.hip) and BiLSTM "
+                       "recurrences (csrc/lstm.hip bilstm6_*) on the exact three-way bf16 split, six MFMA products per fp32 product"}
     main_res = run_mode(precision, args.steps, args.warmup)
-    other_res = run_mode(other, args.other_steps, 1) if args.other_steps > 0 else None
-    # the fp32-faithful GEMM mode: timed beside the headline, never the headline itself
-    x6_res = run_mode("bf16x6", args.other_steps, 1) if (args.other_steps > 0 and precision == "fp32" and headline) else None
+    other_res = [run_mode(m, args.other_steps, 1) for m in others] if args.other_steps > 0 else []
     native.set_precision(precision)
 
     collective = None
@@ -473,27 +497,14 @@ def main():
             "hbm_kernel": hbm_kernel_both(S, dev) if world == 1 else None,
             "train_state": {"loss": round(loss_v, 6), "f1": round(f1_v, 6), "dcg": round(dcg_v, 6)},
         }
-        if other_res is not None:
-            o_loss, o_f1, o_dcg = other_res["state"]
-            out["fast_mode" if other == "bf16x3" else "fp32_mode"] = {
-                "dtype": DTYPES[other], "precision_mode": other, "steps": other_res["steps"],
-                "ms_per_step": round(other_res["ms_per_step"], 3), "value": round(other_res["value"], 2), "unit": "lists/s",
-                "roofline": roofline_block(other_res),
-                "train_state": {"loss": round(o_loss, 6), "f1": round(o_f1, 6), "dcg": round(o_dcg, 6)},
-                "note": ("the library's split-bf16 product mode: inside the 1e-4 parity bound of BASELINE.json (GPU suite green in "
-                         "this mode), but its products are narrower than the reference's fp32 - hence not the headline")
-                        if other == "bf16x3" else "the library's exact-fp32 MFMA mode (the reference's own arithmetic)"}
-        if x6_res is not None:
-            out["fp32_faithful_mode"] = {
-                "dtype": DTYPES["bf16x6"], "precision_mode": "bf16x6", "steps": x6_res["steps"],
-                "ms_per_step": round(x6_res["ms_per_step"], 3), "value": round(x6_res["value"], 2), "unit": "lists/s",
-                "roofline": roofline_block(x6_res),
-                "train_state": dict(zip(("loss", "f1", "dcg"), (round(v, 6) for v in x6_res["state"]))),
-                "note": "same step with the GEMM family (csrc/gemm.hip gemm6*_kernel) and the list attention (csrc/attention6.hip) on the "
-                        "exact three-way bf16 split, six MFMA products per fp32 product: measured against fp64 these kernels are as accurate "
-                        "as the f32 MFMA ones or better (tools/x6_probe.py, profiles/r03_x6_probe.log; tools/gpu_probe.py attention / "
-                        "scale_ops) and the whole GPU suite holds the mode to the exact-fp32 tolerances; the BiLSTM recurrences run the "
-                        "exact-fp32 kernels.  Reported beside the headline, not as the headline."}
+        for res in other_res:
+            m = res["mode"]
+            out[BLOCK[m]] = {
+                "dtype": DTYPES[m], "precision_mode": m, "steps": res["steps"],
+                "ms_per_step": round(res["ms_per_step"], 3), "value": round(res["value"], 2), "unit": "lists/s",
+                "roofline": roofline_block(res),
+                "train_state": dict(zip(("loss", "f1", "dcg"), (round(v, 6) for v in res["state"]))),
+                "note": NOTES[m]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.cpu_sample_batch, args.cpu_loop_batch)
         print(json.dumps(out), flush=True)

@@ -281,6 +281,9 @@ def build_parser():
     p.add_argument('--use-conf', type=int, default=1, help="override lr/batch/dropout/wd/task weights from hyper_parameter_<dataset>.conf")
     p.add_argument('--seed', type=int, default=None)
     p.add_argument('--history-json', type=str, default=None, help="rank 0 writes the per-epoch train / test means and the best / best-5 figures here")
+    p.add_argument('--param-dump-dir', type=str, default=None,
+                   help="every rank saves its final flat parameter bucket as flat_param_rank<r>.npy here (data-parallel checks: the "
+                        "replicas must stay bitwise identical)")
     p.add_argument('--tensorboard-dir', type=str, default=os.path.join(HERE, 'Tensorboard_summary', 'Truncation'),
                    help="scalars.jsonl (+ tensorboard event files when tensorboard is installed); '' disables")
     return p
@@ -340,7 +343,12 @@ def main(argv=None):
             json.dump({"history": trainer.history, "best_f1": fin(trainer.best_test_f1), "best_dcg": fin(trainer.best_test_dcg),
                        "best5_f1": fin(trainer.best5_f1), "best5_dcg": fin(trainer.best5_dcg), "best_epoch": trainer.best_epoch,
                        "world": trainer.world}, f)
+    if args.param_dump_dir:
+        import numpy as np
+        os.makedirs(args.param_dump_dir, exist_ok=True)
+        np.save(os.path.join(args.param_dump_dir, f"flat_param_rank{trainer.rank}.npy"), trainer.flat.flat_param.detach().cpu().numpy())
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
     return result
 

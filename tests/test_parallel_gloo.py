@@ -160,3 +160,105 @@ def test_two_rank_shards_partition_every_batch(tmp_path):
         np.testing.assert_array_equal(s0[:, 1] + s1[:, 1], s0[:, 0])      # the two shards make up every batch
     assert (r0["train_sizes"][-1] == [3, 2]).all() and (r1["train_sizes"][-1] == [3, 1]).all()   # ragged tail 11 = 4+4+3
     assert (r0["test_sizes"][-1] == [1, 1]).all() and (r1["test_sizes"][-1] == [1, 0]).all()     # 5 = 4+1: rank 1 gets an empty shard
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The two configurations north_star shards over 8 GPUs (BASELINE configs[3] and [4]) under two gloo ranks on the CPU:
+# MMOECut(4 experts) with the task codes 2.1 / 2.2 + MtCutLoss, and MtAttnCut(3 tasks) + MtCutLoss on length-bucketed
+# batches.  The step is run.py's `_step` written with the same primitives (shard_bounds, count-weighted loss,
+# FlatModel.all_reduce_grads) on the oracle modules; the expected result is the shard-wise reference semantics
+# (SURVEY.md section 8e): per shard its own list-axis attention, its own RerankLoss batch means (utils/losses.py:134-141)
+# and BCE mean, gradients weighted by the shards' list counts, one Adam step per batch.
+MT_CASES = {
+    "mmoe2.1": dict(model="MMOECut", kw=dict(seq_len=40, num_experts=4, num_tasks=2.1, input_size=3, dropout=0.0), nt=2.1, lengths=(40,)),
+    "mmoe2.2": dict(model="MMOECut", kw=dict(seq_len=40, num_experts=4, num_tasks=2.2, input_size=3, dropout=0.0), nt=2.2, lengths=(40,)),
+    "mtattncut_buckets": dict(model="MtAttnCut", kw=dict(input_size=3, num_tasks=3, dropout=0.0), nt=3, lengths=(20, 30, 40)),
+}
+
+
+def _mt_setup(case):
+    from oracle import losses as olosses, models as omodels
+    from oracle.weights import fill_state_dict, synthetic_lists
+    from dataloader import BatchLoader
+    c = MT_CASES[case]
+    model = getattr(omodels, c["model"])(**c["kw"])
+    fill_state_dict(model, 17)
+    crit = olosses.MtCutLoss(metric='f1', rerank_weight=0.4, classi_weight=0.6, num_tasks=c["nt"])
+    # 5 lists per length: batches of 4 + 1 -> shards (2, 2) and (1, 0): an empty shard on rank 1 in every bucket
+    buckets = [synthetic_lists(5, s, 3, 100 + s) for s in c["lengths"]]
+    loader = BatchLoader(buckets, 4, True, None, 23)          # same seed on every rank: the shared permutation
+    return model, crit, loader
+
+
+def _mt_worker(rank, port, out_dir, case):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "ranked-list-truncation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from rlt_hip.parallel import FlatModel, shard_bounds
+    model, crit, loader = _mt_setup(case)
+    flat = FlatModel(model)
+    flat.broadcast_params(src=0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0025)
+    seen = []
+    for _epoch in range(2):
+        for x, y in loader:
+            n = x.shape[0]
+            lo, hi = shard_bounds(n, rank, WORLD)
+            flat.zero_grad()
+            if hi > lo:
+                loss = crit(model(x[lo:hi]), y[lo:hi])
+                (loss * ((hi - lo) * WORLD / n)).backward()
+            flat.all_reduce_grads()
+            opt.step()
+            seen.append((int(x.shape[1]), hi - lo))
+    np.save(os.path.join(out_dir, f"mt_param{rank}.npy"), flat.flat_param.numpy())
+    np.save(os.path.join(out_dir, f"mt_seen{rank}.npy"), np.array(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", sorted(MT_CASES))
+def test_two_rank_training_of_the_sharded_configs_matches_shardwise_oracle(tmp_path, case):
+    port = _free_port()
+    mp.spawn(_mt_worker, args=(port, str(tmp_path), case), nprocs=WORLD, join=True)
+    p0, p1 = np.load(tmp_path / "mt_param0.npy"), np.load(tmp_path / "mt_param1.npy")
+    np.testing.assert_array_equal(p0.view(np.uint32), p1.view(np.uint32))     # the replicas stay bitwise identical
+    s0, s1 = np.load(tmp_path / "mt_seen0.npy"), np.load(tmp_path / "mt_seen1.npy")
+    np.testing.assert_array_equal(s0[:, 0], s1[:, 0])                         # same bucket at every step: lock-step
+    assert sorted(set(s0[:, 0])) == sorted(MT_CASES[case]["lengths"])
+    assert (s1[:, 1] == 0).any() and (s0[:, 1] > 0).all()                     # rank 1 had empty shards, rank 0 never
+
+    # the same schedule in one process: shard by shard, gradients weighted by the shard sizes
+    from rlt_hip.parallel import FlatModel, shard_bounds
+    model, crit, loader = _mt_setup(case)
+    flat = FlatModel(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0025)
+    for _epoch in range(2):
+        for x, y in loader:
+            n = x.shape[0]
+            flat.zero_grad()
+            for r in range(WORLD):
+                lo, hi = shard_bounds(n, r, WORLD)
+                if hi > lo:
+                    (crit(model(x[lo:hi]), y[lo:hi]) * ((hi - lo) / n)).backward()
+            opt.step()
+    # (Adam divides by sqrt(v): an element whose gradient is at rounding level moves by a fraction of lr either way, so the
+    # bound is absolute - 2 % of the four steps' lr - not relative)
+    np.testing.assert_allclose(p0, flat.flat_param.numpy(), rtol=0, atol=8e-5)
+    # ... which is NOT training on the unsharded batches (attention and the rerank means couple the lists of a shard)
+    model2, crit2, loader2 = _mt_setup(case)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-3, weight_decay=0.0025)
+    for _epoch in range(2):
+        for x, y in loader2:
+            opt2.zero_grad()
+            crit2(model2(x), y).backward()
+            opt2.step()
+    whole = torch.cat([p.detach().reshape(-1) for p in model2.parameters()]).numpy()
+    mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+    assert np.abs(whole - mine).max() > 8e-4
