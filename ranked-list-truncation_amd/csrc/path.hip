@@ -6,6 +6,8 @@
 // launch sequence, the in-place accumulation order and the stash reuse.  Everything is stream-ordered; the caller owns
 // the stash (forward -> backward) and the scratch workspace, whose sizes rlt_workspace_bytes() reports.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -13,9 +15,22 @@ constexpr size_t ALIGN = 256;
 inline size_t rup(size_t b) { return (b + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct Cursor {              // carves 256-byte aligned regions out of a caller-owned buffer
-    uint8_t* base; size_t off;
-    explicit Cursor(void* p) : base((uint8_t*)p), off(0) {}
-    template <typename T = float> T* take(size_t bytes) { T* p = (T*)(base ? base + off : nullptr); off += rup(bytes); return p; }
+    uint8_t* base; size_t off, cap;
+    // cap = the caller's byte count when known.  The entry points compare the total against it before any launch; the
+    // sanitizer / debug build (rlt_hip/build.py: build_sanitized, -DRLT_BOUNDS_CHECK) additionally aborts at the first region
+    // that would leave the buffer, naming it - a layout bug then fails at its line, not as a GPU fault later.
+    explicit Cursor(void* p, size_t cap_ = (size_t)-1) : base((uint8_t*)p), off(0), cap(cap_) {}
+    template <typename T = float> T* take(size_t bytes) {
+        T* p = (T*)(base ? base + off : nullptr);
+#ifdef RLT_BOUNDS_CHECK
+        if (base && cap != (size_t)-1 && off + bytes > cap) {
+            fprintf(stderr, "rlt bounds check: region of %zu bytes at offset %zu leaves a %zu-byte buffer\n", bytes, off, cap);
+            abort();
+        }
+#endif
+        off += rup(bytes);
+        return p;
+    }
 };
 
 // ---------------------------------------------------------------------------------- encoder layer
@@ -37,8 +52,8 @@ struct EncStash {
     void* images; size_t images_bytes;
     size_t bytes;
 };
-inline EncStash enc_stash(const EncDims& d, void* base) {
-    Cursor c(base);
+inline EncStash enc_stash(const EncDims& d, void* base, size_t cap = (size_t)-1) {
+    Cursor c(base, cap);
     EncStash s{};
     const size_t T = d.T, f = sizeof(float);
     s.qkv = c.take(T * 3 * d.E * f);
@@ -81,8 +96,8 @@ inline size_t enc_gemm_ws(const EncDims& d) {
     up(rlt_gemm_workspace(0, 0, T, d.E, 3 * d.E));
     return m;
 }
-inline EncScratch enc_scratch(const EncDims& d, bool drop, void* base) {
-    Cursor c(base);
+inline EncScratch enc_scratch(const EncDims& d, bool drop, void* base, size_t cap = (size_t)-1) {
+    Cursor c(base, cap);
     EncScratch w{};
     const size_t T = d.T, f = sizeof(float);
     w.dz2 = c.take(T * d.E * f);
@@ -117,8 +132,8 @@ inline int gemm(int ta, int tb, int M, int N, int K, const float* A, int lda, co
 // stash of the 2-layer stack: per layer activated gates (T,1024) and cell states (T,256); the hidden states of layer 0
 // (T,256) - the input of layer 1.  The backward overwrites the gate stashes in place with d(pre-activations).
 struct LstmStash { float *gates[2], *c[2], *h0; size_t bytes; };
-inline LstmStash lstm_stash(size_t T, void* base) {
-    Cursor cur(base);
+inline LstmStash lstm_stash(size_t T, void* base, size_t cap = (size_t)-1) {
+    Cursor cur(base, cap);
     LstmStash s{};
     for (int l = 0; l < 2; ++l) {
         s.gates[l] = cur.take(T * 1024 * sizeof(float));
@@ -131,8 +146,8 @@ inline LstmStash lstm_stash(size_t T, void* base) {
 // scratch: packed [w_ih_f ; w_ih_r] (1024, I<=256) and packed biases 2 x 1024 | dh0 (T,256) | packed dW_ih (1024, 256) |
 // packed db (1024) | narrow-dW / split-K workspace
 struct LstmScratch { float *wcat, *bcat, *dh0, *dwcat, *dbcat; void* ws; size_t ws_bytes, bytes; };
-inline LstmScratch lstm_scratch(size_t T, int I, void* base) {
-    Cursor cur(base);
+inline LstmScratch lstm_scratch(size_t T, int I, void* base, size_t cap = (size_t)-1) {
+    Cursor cur(base, cap);
     LstmScratch w{};
     const int Imax = I > 256 ? I : 256;
     w.wcat = cur.take((size_t)1024 * Imax * sizeof(float));
@@ -263,8 +278,8 @@ int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, i
                   w->norm2_weight && w->norm2_bias);
     EncDims d;
     RLT_TRY(enc_dims(S, B, E, H, FF, d));
-    const EncStash s = enc_stash(d, stash);
-    if (stash_bytes < s.bytes || ws_bytes < enc_gemm_ws(d) || (enc_gemm_ws(d) && !ws)) return RLT_E_WORKSPACE;
+    if (stash_bytes < enc_stash(d, nullptr).bytes || ws_bytes < enc_gemm_ws(d) || (enc_gemm_ws(d) && !ws)) return RLT_E_WORKSPACE;
+    const EncStash s = enc_stash(d, stash, stash_bytes);
     const int T = (int)d.T;
     const uint32_t s_attn = drop_p > 0.f ? seeds[0] : 0u, s_ln1 = drop_p > 0.f ? seeds[1] : 0u,
                    s_ffn = drop_p > 0.f ? seeds[2] : 0u, s_ln2 = drop_p > 0.f ? seeds[3] : 0u;
@@ -299,9 +314,9 @@ int rlt_encoder_layer_bwd(const float* x, const rlt_encoder_weights* w, int S, i
     EncDims d;
     RLT_TRY(enc_dims(S, B, E, H, FF, d));
     const bool drop = drop_p > 0.f;
-    const EncStash s = enc_stash(d, const_cast<void*>(stash));
-    const EncScratch k = enc_scratch(d, drop, ws);
-    if (stash_bytes < s.bytes || ws_bytes < k.bytes) return RLT_E_WORKSPACE;
+    if (stash_bytes < enc_stash(d, nullptr).bytes || ws_bytes < enc_scratch(d, drop, nullptr).bytes) return RLT_E_WORKSPACE;
+    const EncStash s = enc_stash(d, const_cast<void*>(stash), stash_bytes);
+    const EncScratch k = enc_scratch(d, drop, ws, ws_bytes);
     const int T = (int)d.T;
     const uint32_t s_attn = drop ? seeds[0] : 0u, s_ln1 = drop ? seeds[1] : 0u, s_ln2 = drop ? seeds[3] : 0u;
     const float keep_scale = 1.f / (1.f - drop_p);
@@ -340,9 +355,9 @@ int rlt_bilstm_fwd(const float* x, int I, const rlt_lstm_layer_weights* w, int S
     RLT_CHECK_ARG(x && w && h_out && stash && ws && I > 0 && S > 0 && B > 0 && lstm_weights_ok(w[0]) && lstm_weights_ok(w[1]));
     const size_t T = (size_t)S * B;
     RLT_CHECK_SHAPE(T <= 0x7fffffffu);
-    const LstmStash s = lstm_stash(T, stash);
-    const LstmScratch k = lstm_scratch(T, I, ws);
-    if (stash_bytes < s.bytes || ws_bytes < k.bytes) return RLT_E_WORKSPACE;
+    if (stash_bytes < lstm_stash(T, nullptr).bytes || ws_bytes < lstm_scratch(T, I, nullptr).bytes) return RLT_E_WORKSPACE;
+    const LstmStash s = lstm_stash(T, stash, stash_bytes);
+    const LstmScratch k = lstm_scratch(T, I, ws, ws_bytes);
     RLT_TRY(lstm_layer_fwd(x, I, w[0], S, B, s.gates[0], s.c[0], s.h0, k, stream));
     return lstm_layer_fwd(s.h0, 256, w[1], S, B, s.gates[1], s.c[1], h_out, k, stream);
 }
@@ -355,9 +370,9 @@ int rlt_bilstm_bwd(const float* x, int I, const rlt_lstm_layer_weights* w, const
     RLT_CHECK_ARG(lstm_weights_ok(w[0]) && lstm_weights_ok(w[1]) && lstm_grads_ok(g[0]) && lstm_grads_ok(g[1]));
     const size_t T = (size_t)S * B;
     RLT_CHECK_SHAPE(T <= 0x7fffffffu);
-    const LstmStash s = lstm_stash(T, stash);
-    const LstmScratch k = lstm_scratch(T, I, ws);
-    if (stash_bytes < s.bytes || ws_bytes < k.bytes) return RLT_E_WORKSPACE;
+    if (stash_bytes < lstm_stash(T, nullptr).bytes || ws_bytes < lstm_scratch(T, I, nullptr).bytes) return RLT_E_WORKSPACE;
+    const LstmStash s = lstm_stash(T, stash, stash_bytes);
+    const LstmScratch k = lstm_scratch(T, I, ws, ws_bytes);
     RLT_TRY(lstm_layer_bwd(s.h0, 256, w[1], h_out, s.gates[1], s.c[1], dh_out, S, B, k.dh0, g[1], k, stream));
     return lstm_layer_bwd(x, I, w[0], s.h0, s.gates[0], s.c[0], k.dh0, S, B, dx, g[0], k, stream);
 }

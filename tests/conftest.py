@@ -30,3 +30,22 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_DURATIONS = []
+
+
+def pytest_runtest_logreport(report):
+    if report.when == "call" and "gpu" in report.keywords:
+        _DURATIONS.append((report.duration, report.nodeid))
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Seconds per GPU test, longest first, and their sum against the driver's 900 s step limit - so that the next
+    overrun is visible before it is a timeout."""
+    if not _DURATIONS:
+        return
+    total = sum(d for d, _ in _DURATIONS)
+    terminalreporter.write_sep("-", f"GPU tests: {total:.0f} s in {len(_DURATIONS)} tests (driver limit 900 s)")
+    for d, nodeid in sorted(_DURATIONS, reverse=True)[:25]:
+        terminalreporter.write_line(f"{d:7.1f} s  {nodeid.split('::', 1)[-1]}")

@@ -43,6 +43,13 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     rccl_one_rank  bench.py and run.py as children of torch.distributed.run with ONE rank over RCCL (RLT_FORCE_DIST=1):
                 init_process_group("nccl", device_id), broadcast, all-reduce(AVG) of the flat bucket, NCCL barrier execute;
                 results equal the run without a process group
+    trainer_dp_mt  the two configurations north_star shards (BASELINE configs[3], [4]) under two ranks: MMOECut(4 experts, tasks
+                2.1 / 2.2) and MtAttnCut(3) on length buckets 100 / 200 / 300 vs the shard-wise oracle; replicas bitwise equal
+    x6_adversarial  bf16x6 vs the f32 MFMA kernels on adversarial operands (low significand bits all ones / worst split, one
+                sign; cancelling sums), K = 16 ... 1,228,800, GEMM and attention: err_x6 <= 1.25 err_f32 against fp64
+    precision_argument  two modes side by side in one process through the call argument == the same mode as process default
+    determinism  the 4096 x 300 AttnCut and 8192 x 300 Choopy steps twice from one state in each mode: gradient bucket, p, k bitwise
+    bench_two_ranks  bench.py --gpus 2 (its own torch.distributed.run child, two gloo ranks on this GPU): the N > 1 JSON line
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
     models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
@@ -71,7 +78,8 @@ def probe():
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
                   "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
-MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging"]
+MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging",
+             "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "trainer_dp_mt"]
 
 
 def _run(probe, name):
@@ -89,20 +97,22 @@ def test_section(probe, name):
     _run(probe, name)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32", "bf16x3"])
 @pytest.mark.parametrize("name", MODE_DEPENDENT)
 def test_section_by_precision(probe, name, precision):
-    """All three MFMA precision modes of the library: the default split-bf16 mode, the exact-fp32 mode and the
-    fp32-faithful six-product mode (bf16x6: GEMM family and the head-dim-64 list attention on an EXACT three-way bf16 split
-    of both operands, everything else on the exact-fp32 kernels).  Model-level tolerances are identical in all three;
-    op-level MFMA tolerances are 6x looser for bf16x3 ONLY (tools/gpu_probe.py: mfma_tol) - bf16x6 is held to the
-    exact-fp32 tolerances everywhere."""
+    """All three MFMA precision modes of the library: the default fp32-faithful six-product mode (bf16x6: GEMM family, list
+    attention at head dims 16 / 32 / 64 and the BiLSTM recurrences on an EXACT three-way bf16 split of both operands), the
+    exact-fp32 MFMA mode and the opt-in split-bf16 mode.  Model-level tolerances are identical in all three; op-level MFMA
+    tolerances are 6x looser for bf16x3 ONLY (tools/gpu_probe.py: mfma_tol) - bf16x6 is held to the exact-fp32 tolerances
+    everywhere.  The mode is set as the process DEFAULT here (what RLT_PRECISION_DEFAULT resolves to); the sections
+    precision_argument / x6_adversarial pass it as the call argument instead."""
     from rlt_hip import native
+    keep = native.get_precision()
     native.set_precision(precision)
     try:
         _run(probe, name)
     finally:
-        native.set_precision("bf16x3")
+        native.set_precision(keep)
 
 
 def test_full_size_models(probe):

@@ -2055,6 +2055,242 @@ def rccl_one_rank():
         report("rccl_one_rank: run.py per-epoch means, nccl 1 rank == no process group", worst, 0)
 
 
+def _low_mantissa(x, pattern):
+    """x with the low 16 bits of every fp32 significand replaced by `pattern` (the sign, exponent and the 7 bits the first
+    bf16 plane keeps stay): 0xFFFF = 'low mantissa bytes all ones' (VERDICT r03 item 1a); 0x7F40 makes BOTH residual planes of
+    the three-way split as large as they can be (m = half an ulp of h, l = half an ulp of m), i.e. the dropped m l' + l m'
+    terms maximal."""
+    return ((x.contiguous().view(torch.int32) & ~0xFFFF) | pattern).view(torch.float32)
+
+
+@section
+def x6_adversarial():
+    """bf16x6 against the f32 MFMA kernels on ADVERSARIAL operands, both measured against fp64 on the same inputs (VERDICT
+    r03 item 1a): low significand bits all ones / at the split's worst case with all operands of one sign (the dropped terms
+    of every product point the same way), and alternating-sign sums whose terms cancel by >= 1e4.  Contraction lengths
+    16, 64, 256, 2048 (NT products) and 1,228,800 (the split-K weight-gradient product); list attention at head dims 16 /
+    64 over 256 and 2048 lists (contractions over hd and over the lists).  Error = max |x - x64| / max sum_k |a_k b_k| (the size
+    of the terms, so that a cancelling sum is not graded against its tiny result).  Asserted: err_x6 <= 1.25 err_f32 (plus
+    2^-27, one sixteenth of an fp32 ulp of the terms, for the cases where both are at rounding level).  The mode is an
+    argument of each call here (ops.precision): the two run side by side in one process, the default untouched."""
+    FLOOR = 2.0 ** -27
+
+    def both(fn):
+        outs = {}
+        for mode in ("fp32", "bf16x6"):
+            with ops.precision(mode):
+                outs[mode] = fn()
+        return outs["fp32"], outs["bf16x6"]
+
+    def grade(name, got32, got6, ref, scale):
+        e32 = float((got32.double() - ref).abs().max() / scale)
+        e6 = float((got6.double() - ref).abs().max() / scale)
+        print(f"     {name}: err f32-MFMA {e32:.3e}, bf16x6 {e6:.3e}, ratio {e6 / max(e32, 1e-300):.2f}", flush=True)
+        report(f"x6 adversarial {name}: err_x6 <= 1.25 err_f32mfma", e6, 1.25 * e32 + FLOOR)
+        report(f"x6 adversarial {name}: f32-MFMA itself at fp32 level", e32, 3e-6)
+
+    g = torch.Generator(device=dev).manual_seed(77)
+    # ---- GEMM family
+    for K in (16, 64, 256, 2048, 1228800):
+        big = K > 4096
+        M, Nn = (256, 256) if big else (512, 256)
+        for tag in ("ones", "worst-split", "cancel"):
+            if tag == "cancel":
+                u = torch.rand(K // 2, generator=g, device=dev) + 0.5
+                a_row = torch.stack([u, -u], 1).reshape(1, K)                       # +u0 -u0 +u1 -u1 ...
+                A = a_row * (1.0 + 0.05 * torch.rand(M, 1, generator=g, device=dev))
+                Bm = (torch.rand(Nn, 1, generator=g, device=dev) + 0.5) * (1.0 + 1e-4 * torch.randn(Nn, K, generator=g, device=dev))
+            else:
+                pat = 0xFFFF if tag == "ones" else 0x7F40
+                A = _low_mantissa(torch.rand(M, K, generator=g, device=dev) + 0.5, pat)
+                Bm = _low_mantissa(torch.rand(Nn, K, generator=g, device=dev) + 0.5, pat)
+            Ad, Bd = A.to(dev), Bm.to(dev)
+            ref = Ad.double() @ Bd.double().t()
+            scale = float((Ad.double().abs() @ Bd.double().abs().t()).max())
+            if tag == "cancel":
+                canc = float(((Ad.double().abs() @ Bd.double().abs().t()) / ref.abs().clamp_min(1e-300)).median())
+                report(f"x6 adversarial gemm K{K} cancel: cancellation factor >= 1e4 (median {canc:.1e})", 0.0 if canc >= 1e4 else 1.0, 0)
+            if big:      # dW-shaped: C[M,N] = A^T B with the long axis contracted (TN, split-K slabs)
+                At, Bt = Ad.t().contiguous(), Bd.t().contiguous()          # stored [K, M], [K, N]
+
+                def run():
+                    C = torch.empty(M, Nn, device=dev)
+                    ops.gemm(1, 0, M, Nn, K, At, M, Bt, Nn, C, Nn)
+                    return C
+            else:
+                def run():
+                    C = torch.empty(M, Nn, device=dev)
+                    ops.gemm(0, 1, M, Nn, K, Ad, K, Bd, K, C, Nn)
+                    return C
+            c32, c6 = both(run)
+            grade(f"gemm {'TN' if big else 'NT'} {M}x{Nn}x{K} {tag}", c32, c6, ref, scale)
+            del Ad, Bd, ref
+    # ---- list attention: contraction over hd (scores) and over the B lists (P V, dK, dV)
+    for (B, HD) in ((256, 16), (256, 64), (2048, 16), (2048, 64)):
+        S, H = 2, 2
+        E = H * HD
+        for tag in ("ones", "worst-split", "cancel"):
+            if tag == "cancel":      # nearly uniform weights over values of alternating sign: P V cancels by ~1e4 sqrt(B)
+                q = 0.01 * torch.randn(B, S, E, generator=g, device=dev)
+                k = 0.01 * torch.randn(B, S, E, generator=g, device=dev)
+                sign = (1.0 - 2.0 * (torch.arange(B, device=dev) % 2)).view(B, 1, 1)
+                v = sign * (1.0 + 1e-4 * torch.randn(B, S, E, generator=g, device=dev))
+            else:
+                pat = 0xFFFF if tag == "ones" else 0x7F40
+                q = _low_mantissa(0.25 * (torch.rand(B, S, E, generator=g, device=dev) + 0.5), pat)
+                k = _low_mantissa(0.25 * (torch.rand(B, S, E, generator=g, device=dev) + 0.5), pat)
+                v = _low_mantissa(torch.rand(B, S, E, generator=g, device=dev) + 0.5, pat)
+            qkv = torch.cat([q, k, v], dim=2)
+            dout = _low_mantissa(torch.rand(B, S, E, generator=g, device=dev) + 0.5, 0x7F40) if tag != "cancel" else torch.randn(B, S, E, generator=g, device=dev)
+            qr = qkv.to(dev).double().requires_grad_(True)
+            orf = _attn_ref(qr, H)
+            orf.backward(dout.to(dev).double())
+
+            def run():
+                qd = _pm(qkv).to(dev).requires_grad_(True)
+                od = ops.list_attention(qd, S, B, H)
+                od.backward(_pm(dout).to(dev))
+                return _unpm(od.detach(), B, S), _unpm(qd.grad, B, S)
+            (o32, g32), (o6, g6) = both(run)
+            vabs = float(qkv[..., 2 * E:].abs().max())
+            grade(f"attn B{B} hd{HD} {tag}: out", o32, o6, orf.detach(), vabs)       # sum_k P_k |v_k| <= max |v|
+            for nm, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+                gref = qr.grad[..., sl]
+                grade(f"attn B{B} hd{HD} {tag}: {nm}", g32[..., sl], g6[..., sl], gref, float(gref.abs().max()))
+            del qr, orf
+
+
+@section
+def precision_argument():
+    """The mode is a call argument (ABI v3): two encoder layers and two BiLSTM stacks run in one process in DIFFERENT modes
+    (ops.precision scopes; the process default is a third one and stays untouched), each tape node keeps its forward's mode
+    for its backward, and every result equals - bit for bit - the same computation with that mode as the process default."""
+    from models._common import ParamTree
+    keep = N.get_precision()
+    try:
+        B, S, E, H = 70, 5, 256, 4
+        torch.manual_seed(3)
+        layer = torch.nn.TransformerEncoderLayer(d_model=E, nhead=H, dropout=0.0)
+        lstm = torch.nn.LSTM(3, 128, num_layers=2, batch_first=True, bidirectional=True)
+        x, dy = torch.randn(S * B, E), torch.randn(S * B, E)
+        x3, dh = torch.randn(S * B, 3), torch.randn(S * B, 256)
+
+        def run_all(scope_mode):
+            """forward under the scope, backward OUTSIDE it (the tape node must remember)"""
+            pl, pt = ParamTree(layer).to(dev), ParamTree(lstm).to(dev)
+            xin, x3in = x.clone().to(dev).requires_grad_(True), x3.clone().to(dev).requires_grad_(True)
+            with ops.precision(scope_mode):
+                y = ops.encoder_layer(xin, pl, S, B, H, 0.0)
+                h = ops.bilstm(x3in, pt, S, B)
+            y.backward(dy.to(dev))
+            h.backward(dh.to(dev))
+            return [y.detach(), xin.grad, h.detach(), x3in.grad] + [q.grad for _, q in pl.named_parameters()] + [q.grad for _, q in pt.named_parameters()]
+
+        want = {}
+        for mode in ("fp32", "bf16x6", "bf16x3"):
+            N.set_precision(mode)
+            want[mode] = run_all(None)                       # the mode as the process default
+        for default in ("bf16x3", "fp32"):
+            N.set_precision(default)
+            for mode in ("fp32", "bf16x6", "bf16x3"):
+                got = run_all(mode)
+                worst = max(float((a - b).abs().max()) for a, b in zip(got, want[mode]))
+                report(f"precision argument: {mode} as an argument under default {default} == {mode} as the default (max |diff|)", worst, 0)
+            report(f"precision argument: the default is still {default}", 0.0 if N.get_precision() == default else 1.0, 0)
+        d36 = max(float((a - b).abs().max()) for a, b in zip(want["bf16x3"], want["bf16x6"]))
+        report("precision argument: the modes do differ (bf16x3 vs bf16x6 results, max |diff| > 0)", 0.0 if d36 > 0 else 1.0, 0)
+    finally:
+        N.set_precision(keep)
+
+
+@section
+def determinism():
+    """Run-to-run determinism, asserted: BASELINE configs[1] (AttnCut 4096 x 300) and configs[2]
+    (Choopy 8192 x 300), one full training step (forward, loss + cut metrics, backward) run TWICE from the same state in each
+    precision mode: the flat gradient bucket, the cut distribution and the cut positions must be bitwise equal.  No kernel
+    of the path uses float atomics; every cross-workgroup sum (split-K slabs, LayerNorm / head / bias partials, the loss
+    partials) is reduced in a fixed order - this is the property those designs were paid for (attention.hip header)."""
+    import gc
+    import models as hm
+    from utils import losses as hl
+    from utils.metrics import Metric
+    from rlt_hip.parallel import FlatModel
+    from bench import synth_batch
+    keep = N.get_precision()
+    try:
+        for name, B, S in (("attncut", 4096, 300), ("choopy", 8192, 300)):
+            torch.manual_seed(11)
+            if name == "attncut":
+                model, crit, nf = hm.AttnCut(input_size=3, dropout=0.0).to(dev), hl.DivLoss(metric="f1", div_type="js", augmented=True), 3
+            else:
+                model, crit, nf = hm.Choopy(seq_len=S, dropout=0.0).to(dev), hl.ChoopyLoss(metric="f1"), 1
+            flat = FlatModel(model)
+            x, y = synth_batch(B, S, nf, 20240, dev)
+            for mode in ("bf16x6", "fp32", "bf16x3"):
+                N.set_precision(mode)
+                runs = []
+                for _ in range(2):
+                    flat.zero_grad()
+                    model.train()
+                    out = model(x)
+                    loss, k, f1, dcg = Metric.step(crit, out, y)
+                    loss.backward()
+                    torch.cuda.synchronize()
+                    runs.append((flat.flat_grad.clone(), out.detach().clone(), k.clone(), loss.detach().clone()))
+                    del out, loss
+                (g0, p0, k0, l0), (g1, p1, k1, l1) = runs
+                bits = lambda t: t.contiguous().view(torch.int32)
+                report(f"determinism {name} {B}x{S} {mode}: flat_grad elements differing between two runs", float((bits(g0) != bits(g1)).sum()), 0)
+                report(f"determinism {name} {B}x{S} {mode}: p elements differing", float((bits(p0) != bits(p1)).sum()), 0)
+                report(f"determinism {name} {B}x{S} {mode}: cut positions differing", float((k0 != k1).sum()), 0)
+                report(f"determinism {name} {B}x{S} {mode}: loss bits differing", float((bits(l0) != bits(l1)).sum()), 0)
+                report(f"determinism {name} {B}x{S} {mode}: gradient is finite and non-zero", 0.0 if bool(torch.isfinite(g0).all()) and float(g0.abs().max()) > 0 else 1.0, 0)
+                del runs, g0, g1, p0, p1
+            del model, flat, x, y
+            gc.collect()
+            torch.cuda.empty_cache()
+    finally:
+        N.set_precision(keep)
+
+
+@section
+def bench_two_ranks():
+    """`bench.py --gpus 2` end to end: the parent never touches the GPU and starts its own two ranks under
+    torch.distributed.run (spawn_ranks); here both ranks share this box's one GPU over gloo (RLT_DIST_BACKEND=gloo
+    RLT_BENCH_DEVICE=0 - the rehearsal form; the driver's 8-GPU run uses one GPU per rank over RCCL).  Asserted: exit status,
+    exactly one JSON line, n_gpus, collective.ranks, the global batch, value = all ranks' lists / the max-over-ranks time,
+    no single-GPU-only blocks, a finite training state."""
+    import json
+    import subprocess
+    bench_py = os.path.join(REPO, "bench.py")
+    steps, batch = 3, 96
+    env = dict(os.environ, RLT_DIST_BACKEND="gloo", RLT_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--batch", str(batch), "--steps", str(steps), "--warmup", "1",
+                          "--other-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    report("bench --gpus 2: exit status", float(res.returncode), 0)
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    report("bench --gpus 2: exactly one JSON line on stdout", abs(len(lines) - 1), 0)
+    if res.returncode or len(lines) != 1:
+        print(res.stdout[-1500:], res.stderr[-3000:])
+        return
+    d = json.loads(lines[0])
+    report("bench --gpus 2: n_gpus == 2", abs(d["n_gpus"] - 2), 0)
+    report("bench --gpus 2: collective.ranks == 2", abs((d["collective"] or {}).get("ranks", 0) - 2), 0)
+    report("bench --gpus 2: collective.backend == gloo (rehearsal)", 0.0 if (d["collective"] or {}).get("backend") == "gloo" else 1.0, 0)
+    report("bench --gpus 2: config.global_batch == 2 x 96", abs(d["config"]["global_batch"] - 2 * batch), 0)
+    report("bench --gpus 2: config.parallelism == dp2", 0.0 if d["config"]["parallelism"] == "dp2" else 1.0, 0)
+    report("bench --gpus 2: scaling == weak", 0.0 if d["scaling"] == "weak" else 1.0, 0)
+    elapsed = d["ms_per_step"] * 1e-3 * steps
+    report("bench --gpus 2: value == global batch x steps / elapsed", abs(d["value"] - 2 * batch * steps / elapsed) / d["value"], 1e-3)
+    report("bench --gpus 2: hbm_kernel is None (single-GPU block)", 0.0 if d.get("hbm_kernel") is None else 1.0, 0)
+    report("bench --gpus 2: no cpu_baseline block off rank-0-at-N=1", 0.0 if "cpu_baseline" not in d else 1.0, 0)
+    vals = [d["train_state"][k] for k in ("loss", "f1", "dcg")]
+    report("bench --gpus 2: finite training state", 0.0 if all(math.isfinite(v) for v in vals) else 1.0, 0)
+    report("bench --gpus 2: headline precision is the library default bf16x6", 0.0 if d.get("precision_mode") == "bf16x6" else 1.0, 0)
+
+
 if __name__ == "__main__":
     want = [w for w in sys.argv[1:] if not w.startswith("--")]
     for w in sys.argv[1:]:
