@@ -1303,6 +1303,258 @@ int launch_gemm6b(GemmArgs g, int ns, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
+// ======================================================================================================
+// gemm6c: the 256 x 256 six-product tile with the split of the next K tile BEHIND the MFMAs.
+// gemm6b above holds one K tile of 32 as six 16 KB planes (96 KB: no room for a second copy) and alternates a multiply
+// phase with a split phase in which both wavefronts of every SIMD do vector work only (~15-20 % of its K loop).  Here the
+// unit is the MFMA k-step: a k-step buffer is [A_h | A_m | A_l | B_h | B_m | B_l] x 256 rows x 16 k = 48 KB, THREE of them
+// rotate (144 KB), and the loop runs in slots of one k-step (48 MFMAs per wavefront, one barrier):
+//   slot u multiplies k-step u out of buffer u % 3;
+//   an ODD slot also splits the staged register tile (a K tile of 32 = the next two k-steps) into buffers (u+1) % 3 and
+//   (u+2) % 3 - both free: their last readers ran before the barrier that opened this slot - piece by piece behind its MFMA
+//   groups, then issues the global loads of the register tile after that one (consumed two slots later: one whole slot plus
+//   of latency cover from a single staging set);
+//   an EVEN slot only multiplies.
+// Rows are 32 bytes (16 bf16): logical row r sits at physical row phys6(r) (the two low 2-bit fields swapped) and its two
+// 16-byte chunks are XOR-swizzled with bit 3 of the physical row, which makes the ds_read_b128 fragment reads and the
+// ds_write_b64 stores of BOTH staging maps conflict-free (derivation: DESIGN.md 4.2).
+// Staging maps (every wave-level load covers whole 128-byte lines):
+//   K-contiguous operand: the 8 lanes tid & 7 read the 8 float4 of one row's K tile; lanes 0-3 of a row group hold k-step 0
+//   of the tile in their loads 0 / 2 and k-step 1 in their loads 1 / 3, lanes 4-7 the other way round (kq = (tid & 7) ^ 4 i):
+//   one select per register pair at stash time puts k-step 0 in registers 0 / 2 for every lane (8 v_cndmask per float4 pair -
+//   against half-line loads, which double the L2 requests the 256-wide tiles were built to save);
+//   MN-contiguous operand: wavefronts 0-3 hold the 16 k rows of k-step 0 (a 4 x 4 block per thread), wavefronts 4-7 those of
+//   k-step 1 (wavefronts w and w + 4 share a SIMD, so every SIMD splits the same amount).
+// PERSIST (no split-K, A stored [M][K], more tiles than workgroups): the workgroups walk the output tiles as ONE stream of
+// k-steps, the first K tile of the next output tile is staged in the last odd slot of the current one and its second K tile
+// is in flight during the epilogue - at K = 256 (8 K tiles: five of the eight big products of the encoder layer) the
+// prologue and the 256 KB epilogue of a tile were uncovered time.
+constexpr int HB6 = 256 * 16;                  // bf16 elements of one plane of a k-step buffer
+constexpr int KB6 = 6 * HB6;                   // one k-step buffer (48 KB)
+__device__ __forceinline__ int phys6(int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); }
+
+struct Stage6c { float4 v[4]; };
+template <bool KC>
+__device__ __forceinline__ void load6c(const float* __restrict__ P, int ld, int mn0, int k0, int tid, Stage6c& st) {
+    if (KC) {
+        const int t = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pr = (t & 1) | ((i & 1) << 1) | ((t >> 1) << 2) | ((i >> 1) << 7);       // physical LDS row
+            const int kq = (tid & 7) ^ ((i & 1) << 2);
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(mn0 + phys6(pr)) * ld + k0 + 4 * kq);
+        }
+    } else {
+        const int half = tid >> 8, t2 = tid & 255, kb = t2 & 3, mb = t2 >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            st.v[i] = *reinterpret_cast<const float4*>(P + (size_t)(k0 + 16 * half + 4 * kb + i) * ld + mn0 + 4 * mb);
+    }
+}
+// piece `part` (0..3) of the split + LDS store of a staged operand tile.  T0 / T1: the h plane of this operand in the
+// buffers of the tile's k-step 0 / k-step 1 (the m and l planes follow at + HB6, + 2 HB6).
+template <bool KC>
+__device__ __forceinline__ void stash6c_part(uint16_t* __restrict__ T0, uint16_t* __restrict__ T1, int tid, const Stage6c& st, int part) {
+    uint2 hi, mid, lo;
+    uint16_t* dst;
+    if (KC) {
+        // part -> register pair (part >> 1), k-step (part & 1) of the tile
+        const int hb = (tid >> 2) & 1, t = tid >> 3, j = 2 * (part >> 1) + (part & 1);       // register index after the swap
+        const float4 a = st.v[2 * (part >> 1)], b = st.v[2 * (part >> 1) + 1];
+        const bool second = ((part & 1) ^ hb) != 0;                                          // this lane's k-step `part & 1` sits in load j ^ hb
+        const float4 x = make_float4(second ? b.x : a.x, second ? b.y : a.y, second ? b.z : a.z, second ? b.w : a.w);
+        const int pr = (t & 1) | (((j ^ hb) & 1) << 1) | ((t >> 1) << 2) | ((j >> 1) << 7);
+        const int kq4 = tid & 3;
+        dst = ((part & 1) ? T1 : T0) + pr * 16 + 8 * ((kq4 >> 1) ^ ((pr >> 3) & 1)) + 4 * (kq4 & 1);
+        split4x3(x.x, x.y, x.z, x.w, hi, mid, lo);
+    } else {
+        const int half = tid >> 8, t2 = tid & 255, kb = t2 & 3, mb = t2 >> 2;
+        const float* f0 = reinterpret_cast<const float*>(&st.v[0]);
+        const float* f1 = reinterpret_cast<const float*>(&st.v[1]);
+        const float* f2 = reinterpret_cast<const float*>(&st.v[2]);
+        const float* f3 = reinterpret_cast<const float*>(&st.v[3]);
+        const int pr = ((4 * mb) & ~15) | (part << 2) | (mb & 3);                             // phys6(4 mb + part)
+        dst = (half ? T1 : T0) + pr * 16 + 8 * ((kb >> 1) ^ ((pr >> 3) & 1)) + 4 * (kb & 1);
+        split4x3(f0[part], f1[part], f2[part], f3[part], hi, mid, lo);
+    }
+    *reinterpret_cast<uint2*>(dst) = hi;
+    *reinterpret_cast<uint2*>(dst + HB6) = mid;
+    *reinterpret_cast<uint2*>(dst + 2 * HB6) = lo;
+}
+
+template <bool TA, bool TB, bool PERSIST>
+__global__ __launch_bounds__(512) void gemm6c_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);          // [3][A_h | A_m | A_l | B_h | B_m | B_l]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    int bid, zslab;
+    decode_block(g, bid, zslab);                     // g.tiles_* count 256 x 256 tiles here
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    int m0 = tm * BM2, n0 = tn * BN2;
+    const int kbeg = zslab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg) / BK3;              // register tiles (K tiles of 32) per output tile; >= 2 (host-checked)
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stage6c sa, sb;
+    constexpr bool AKC = !TA, BKC = TB;
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pl = phys6(l31);
+    const int csw = 8 * (hh ^ ((pl >> 3) & 1));      // element offset of this lane's 16-byte chunk inside its row
+    const int arow = (wm * 64 + pl) * 16 + csw, brow = 3 * HB6 + (wn * 128 + pl) * 16 + csw;
+
+    // tile of the stream after the current one (PERSIST): decode_block's XCD-aware remap of id + gridDim.x
+    int vid = blockIdx.x, nm0 = m0, nn0 = n0;
+    bool has_next = false;
+    auto decode_next = [&]() {
+        const int nwg = g.tiles_m * g.tiles_n;
+        vid += gridDim.x;
+        has_next = PERSIST && vid < nwg;
+        if (has_next) {
+            const int q = nwg >> 3, r = nwg & 7, xcd = vid & 7, jj = vid >> 3;
+            const int nb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jj;
+            const int ntm = nb / g.tiles_n;
+            nm0 = ntm * BM2; nn0 = (nb - ntm * g.tiles_n) * BN2;
+        }
+    };
+    // register tile `ti` of the stream position: ti < nt -> this output tile; nt, nt + 1 -> the next one's tiles 0, 1 (or, at the
+    // end of the stream, a harmless re-read of the last tile: the fetch is unconditional so that hipcc's vmcnt counts stay exact)
+    auto fetch = [&](int ti) {
+        const bool wrap = PERSIST && has_next && ti >= nt;
+        const int k0 = kbeg + (wrap ? ti - nt : min(ti, nt - 1)) * BK3;
+        load6c<AKC>(g.A, g.lda, wrap ? nm0 : m0, k0, tid, sa);
+        load6c<BKC>(g.B, g.ldb, wrap ? nn0 : n0, k0, tid, sb);
+    };
+    auto add_cs = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { csum.x += sa.v[i].x; csum.y += sa.v[i].y; csum.z += sa.v[i].z; csum.w += sa.v[i].w; }
+    };
+
+    // one slot: the 48 MFMAs of k-step buffer `buf`; STASH: pieces of the staged register tile go behind the MFMA groups into
+    // buffers b1 (its k-step 0) and b2 (its k-step 1), then the loads of register tile `fetch_ti` are issued
+    auto slot = [&](auto stash_tag, int buf, int b1, int b2, bool do_stash, int fetch_ti) {
+        constexpr bool STASH = decltype(stash_tag)::value;
+        const uint16_t* base = lds + buf * KB6;
+        uint16_t* t1 = lds + b1 * KB6;
+        uint16_t* t2 = lds + b2 * KB6;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(base + arow + q * HB6 + i * 32 * 16);
+        auto load_b = [&](int j, int s_) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[s_][q] = *reinterpret_cast<const bf16x8*>(base + brow + q * HB6 + j * 32 * 16);
+        };
+        load_b(0, 0);
+        if (STASH && do_stash && want_cs) add_cs();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) load_b(j + 1, (j + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j & 1][1], c, 0, 0, 0);   // m m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j & 1][0], c, 0, 0, 0);   // l h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j & 1][2], c, 0, 0, 0);   // h l'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j & 1][0], c, 0, 0, 0);   // m h'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j & 1][1], c, 0, 0, 0);   // h m'
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j & 1][0], c, 0, 0, 0);   // h h'
+                acc[i][j] = c;
+                if (STASH && do_stash) {               // piece 2 j + i of eight: A pieces 0..3, then B pieces 0..3
+                    const int piece = 2 * j + i;
+                    if (piece < 4) stash6c_part<AKC>(t1, t2, tid, sa, piece);
+                    else stash6c_part<BKC>(t1 + 3 * HB6, t2 + 3 * HB6, tid, sb, piece - 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (STASH) fetch(fetch_ti);
+    };
+
+    // prologue: register tile 0 into buffers 0 and 1, register tile 1 in flight
+    fetch(0);
+    if (want_cs) add_cs();
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+        stash6c_part<AKC>(lds, lds + KB6, tid, sa, part);
+        stash6c_part<BKC>(lds + 3 * HB6, lds + KB6 + 3 * HB6, tid, sb, part);
+    }
+    if (PERSIST) decode_next();
+    fetch(1);
+    __syncthreads();
+
+    int u = 0;                                         // k-steps of the stream so far, modulo 3: the buffer of this slot
+    while (true) {
+        for (int ti = 0; ti < nt; ++ti) {
+            const int b0 = u, b1 = u == 2 ? 0 : u + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            slot(BoolTag<false>{}, b0, 0, 0, false, 0);                                   // even slot: k-step 2 ti
+            __syncthreads();
+            // odd slot: k-step 2 ti + 1 out of b1; stages register tile ti + 1 into b2 and b0, fetches tile ti + 2
+            slot(BoolTag<true>{}, b1, b2, b0, ti + 1 < nt || has_next, ti + 2);
+            __syncthreads();
+            u = b2;
+        }
+        write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
+        if (!PERSIST || !has_next) break;
+        m0 = nm0; n0 = nn0;
+        decode_next();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    if (want_cs) {          // threads 4 mb + kb and 256 + 4 mb + kb (kb < 4) hold partial sums of columns 4 mb .. 4 mb + 3
+        float4* red = reinterpret_cast<float4*>(gsm);
+        __syncthreads();
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[4 * tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const float4 o = red[(j >> 2) * 256 + 4 * tid + (j & 3)];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)zslab * g.M : g.colsum) + m0 + 4 * tid;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+template <bool TA, bool TB>
+int launch_gemm6c(GemmArgs g, int ns, hipStream_t st) {
+    const size_t shm = (size_t)3 * KB6 * sizeof(uint16_t);
+    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
+    if constexpr (!TA) {
+        static const int persist_wgs = [] { const char* e = getenv("RLT_GEMM6_PERSIST"); return e ? atoi(e) : 256; }();   // 0: off
+        const long long tiles = (long long)g.tiles_m * g.tiles_n;
+        if (persist_wgs > 0 && ns == 1 && tiles > persist_wgs && persist_wgs % 8 == 0) {
+            int rc = rlt_allow_lds(gemm6c_kernel<TA, TB, true>, shm);
+            if (rc) return rc;
+            hipLaunchKernelGGL((gemm6c_kernel<TA, TB, true>), dim3(persist_wgs), dim3(512), shm, st, g);
+            return RLT_LAUNCH_RESULT();
+        }
+    }
+    int rc = rlt_allow_lds(gemm6c_kernel<TA, TB, false>, shm);
+    if (rc) return rc;
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
+    hipLaunchKernelGGL((gemm6c_kernel<TA, TB, false>), grid, dim3(512), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+
 // the bf16x6 tile needs M % 256 == 0, N % 128 == 0, whole 32-wide K tiles per slab and the branch-free loader
 // preconditions; other shapes of that mode run on the exact f32 MFMA kernel (more exact still)
 bool gemm6_ok(const GemmArgs& g) {
@@ -1590,7 +1842,15 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     int rc = 0;
     static const bool x6_small_only = getenv("RLT_GEMM6_SMALL") != nullptr;      // A/B switch: 256 x 128 tiles everywhere
-    if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only) {
+    static const bool x6_no_c = [] { const char* e = getenv("RLT_GEMM6C"); return e && atoi(e) == 0; }();   // A/B switch: RLT_GEMM6C=0 -> gemm6b
+    if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only && !x6_no_c && g.kchunk / BK3 >= 2 &&
+        (min(g.K, g.kchunk) / BK3) >= 2 && (g.K % g.kchunk == 0 || (g.K % g.kchunk) / BK3 >= 2)) {
+        // (every K slab holds at least two K tiles of 32: the k-step pipeline stages one register tile ahead)
+        if (!ta && tb) rc = launch_gemm6c<false, true>(g, ns, st);
+        else if (!ta && !tb) rc = launch_gemm6c<false, false>(g, ns, st);
+        else if (ta && !tb) rc = launch_gemm6c<true, false>(g, ns, st);
+        else rc = launch_gemm6c<true, true>(g, ns, st);
+    } else if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only) {
         if (!ta && tb) rc = launch_gemm6b<false, true>(g, ns, st);
         else if (!ta && !tb) rc = launch_gemm6b<false, false>(g, ns, st);
         else if (ta && !tb) rc = launch_gemm6b<true, false>(g, ns, st);
