@@ -1506,6 +1506,9 @@ __global__ __launch_bounds__(512) void gemm6c_kernel(GemmArgs g) {
             __syncthreads();
             u = b2;
         }
+#ifdef RLT_G6C_NOSTORE      // timing-only ablation (tools/build_variant.py): no output (results are wrong by design)
+        if (acc[0][0][0] == 123.456f)
+#endif
         write_output_t<4>(g, acc, m0 + wm * 64, n0 + wn * 128, true, l31, hh, zslab);
         if (!PERSIST || !has_next) break;
         m0 = nm0; n0 = nn0;

@@ -397,6 +397,7 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
         }
         // ---- q = exp(r / tau) / sum (utils/losses.py:226-228; no maximum subtracted, like the reference) ----------
         float q[N];
+        float l2z = 0.f;
         if (a.kind != RLT_LOSS_EXPECT) {
             float zs = 0.f;
 #pragma unroll
@@ -405,7 +406,9 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 if (n >= N - 4 && !last_ok) q[n] = 0.f;
                 zs += q[n];
             }
-            const float iz = fast_rcp(half_sum(zs, upper));
+            const float zsum = half_sum(zs, upper);
+            const float iz = fast_rcp(zsum);
+            l2z = __builtin_amdgcn_logf(zsum);                // log2 q_n = r_n c_exp - log2 Z: no v_log_f32 per position for q
 #pragma unroll
             for (int n = 0; n < N; ++n) q[n] *= iz;
         }
@@ -444,7 +447,9 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 for (int n = 0; n < N; ++n) {
                     const float sm = p[n] + q[n];
                     const float l2s = __builtin_amdgcn_logf(sm);
-                    const float dq_ = __builtin_amdgcn_logf(fmaxf(q[n], 1.17549435e-38f)) - l2s;
+                    // log2 q from the exponent it was formed with (exact where v_log_f32 of the rounded q has 1 ulp; a q that
+                    // underflowed to 0 - or a position beyond the list - multiplies it by 0); clamped like the log form was
+                    const float dq_ = fmaxf(__builtin_fmaf(rv[n], c_exp, -l2z), -126.f) - l2s;
                     const float dp_ = __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f)) - l2s;
                     part = __builtin_fmaf(q[n], dq_, part);
                     part = __builtin_fmaf(p[n], dp_, part);

@@ -488,6 +488,177 @@ __global__ __launch_bounds__(512) void bilstm3_bwd8_kernel(float* __restrict__ g
     }
 }
 
+// ======================================================================================================
+// fp32-FAITHFUL forward recurrence ("bf16x6"): h W_hh^T on the exact three-way bf16 split of both
+// operands (x = h + m + l, 8 + 8 + 8 significand bits), six MFMA products per fp32 product, fp32 accumulate - the scheme of
+// gemm6*_kernel / attention6.hip; per (block, k-step) 6 x 32 matrix cycles against the 8 x 64 of the f32 MFMA.
+// Where W_hh lives: its three planes are 384 KB per direction; the register file of a CU holds 512 KB.  512 threads = 8
+// wavefronts x 16 hidden units (two 32-row MFMA blocks: rows = 4 gates x 8 units), a 256-register budget: the h and m planes
+// stay in registers as A operands (128 VGPRs), the l plane - used by ONE of the six products, l h' - sits in LDS in
+// fragment order (128 KB: every wavefront reads back exactly the 1 KB pieces it wrote, conflict-free), read once per
+// (block, k-step).  h_{t-1} is exchanged through ONE 24 KB tile of three planes (LDS is full: 152 KB), so a step has two
+// barriers (all fragments read | new h written); rows of 256 bytes, 16-byte chunks XOR-swizzled with the list index.
+// Layer 0 (XIN): the input projection x W_ih^T + b_ih + b_hh rides on the same accumulators as one more k-step whose A
+// fragments (W_ih columns, the bias sum, zeros; all three planes in registers) meet B = (x0, x1, x2, 1, 0...) - exact like
+// every other product of the mode; the pre-activations never exist in memory.  Gate nonlinearities: hardware exp2 / rcp forms
+// (abs error ~1e-7, measured against the libm forms of the f32 kernel in every fp32-tolerance test of the suite).
+__device__ __forceinline__ void split4x3_(float a, float b, float c, float d, uint2& hi, uint2& mid, uint2& lo) {
+    hi.x = pk2(a, b);
+    hi.y = pk2(c, d);
+    asm("" : "+v"(hi.x), "+v"(hi.y));          // keep the packed pair, do not re-convert (see split4)
+    const float ra = a - __builtin_bit_cast(float, hi.x << 16), rb = b - __builtin_bit_cast(float, hi.x & 0xffff0000u);
+    const float rc = c - __builtin_bit_cast(float, hi.y << 16), rd = d - __builtin_bit_cast(float, hi.y & 0xffff0000u);
+    mid.x = pk2(ra, rb);
+    mid.y = pk2(rc, rd);
+    asm("" : "+v"(mid.x), "+v"(mid.y));
+    lo.x = pk2(ra - __builtin_bit_cast(float, mid.x << 16), rb - __builtin_bit_cast(float, mid.x & 0xffff0000u));
+    lo.y = pk2(rc - __builtin_bit_cast(float, mid.y << 16), rd - __builtin_bit_cast(float, mid.y & 0xffff0000u));
+}
+__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4x3_(x[0], x[1], x[2], x[3], h0, m0, l0);
+    split4x3_(x[4], x[5], x[6], x[7], h1, m1, l1);
+    h = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    m = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+    l = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+// the six products, smallest terms first
+__device__ __forceinline__ f32x16 mfma6(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+constexpr int WL6_BYTES = 8 * 2 * 8 * 64 * 16;          // l plane of W_hh in fragment order
+constexpr int HX6_PLANE = LISTS * 256;                   // one plane of the h tile: 32 lists x 128 bf16
+constexpr size_t LSTM6_LDS = (size_t)WL6_BYTES + 3 * HX6_PLANE;
+
+template <bool XIN>
+__global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                          const float* __restrict__ w_hh_r, int S, int B,
+                                                          float* __restrict__ h_out, float* __restrict__ c_out, XIn xi) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm6[];
+    uint4* wl_s = reinterpret_cast<uint4*>(sm6);
+    uint8_t* hx = sm6 + WL6_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * LISTS + l31;
+    const bool valid = b < B;
+
+    // A operand, block blk: row l31 <-> (gate l31 >> 3, unit 16 w + 8 blk + (l31 & 7)); fragment ks covers k = 16 ks + 8 hh + j
+    bf16x8 wh[2][8], wm[2][8];
+    bf16x8 wxh[2], wxm[2], wxl[2];                        // XIN: the input-projection k-step (W_ih columns, b_ih + b_hh, zeros)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int row = (l31 >> 3) * HID + 16 * w + 8 * blk + (l31 & 7);
+        const float* wp = (dir ? w_hh_r : w_hh_f) + (size_t)row * HID + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4*>(wp + 16 * ks);
+            const float4 v1 = *reinterpret_cast<const float4*>(wp + 16 * ks + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            bf16x8 wl;
+            split8x3(x, wh[blk][ks], wm[blk][ks], wl);
+            wl_s[((w * 2 + blk) * 8 + ks) * 64 + lane] = __builtin_bit_cast(uint4, wl);
+        }
+        if (XIN) {
+            const float* wr = xi.w_ih[dir] + (size_t)row * xi.I;
+            const bool lo_half = hh == 0;
+            const float x[8] = {lo_half ? wr[0] : 0.f, (lo_half && xi.I > 1) ? wr[1] : 0.f, (lo_half && xi.I > 2) ? wr[2] : 0.f,
+                                lo_half ? xi.b_ih[dir][row] + xi.b_hh[dir][row] : 0.f, 0.f, 0.f, 0.f, 0.f};
+            split8x3(x, wxh[blk], wxm[blk], wxl[blk]);
+        }
+    }
+    for (int i = tid; i < 3 * HX6_PLANE / 16; i += 512) reinterpret_cast<uint4*>(hx)[i] = make_uint4(0u, 0u, 0u, 0u);   // h_0 = 0
+    float c[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[blk][u] = 0.f;
+    const int sw = l31 & 15;
+    const uint8_t* hrow = hx + l31 * 256;
+    __syncthreads();
+
+    for (int t = 0; t < S; ++t) {
+        const int s = dir ? S - 1 - t : t;
+        const size_t tok = (size_t)s * B + (valid ? b : 0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + 16 * w + 4 * hh;
+        float4 gin[2][4];
+        float xv[3] = {0.f, 0.f, 0.f};
+        if (XIN) {            // (invalid lists read list 0's row, never stored)
+            const float* xr = xi.x + tok * xi.I;
+            xv[0] = xr[0];
+            if (xi.I > 1) xv[1] = xr[1];
+            if (xi.I > 2) xv[2] = xr[2];
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)    // unconditional; consumed after the MFMAs
+                    gin[blk][g] = *reinterpret_cast<const float4*>(grow + g * HID + 8 * blk);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int co = ((2 * ks + hh) ^ sw) * 16;
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(hrow + co);
+            const bf16x8 xm = *reinterpret_cast<const bf16x8*>(hrow + HX6_PLANE + co);
+            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(hrow + 2 * HX6_PLANE + co);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 wl = __builtin_bit_cast(bf16x8, wl_s[((w * 2 + blk) * 8 + ks) * 64 + lane]);
+                acc[blk] = mfma6(wh[blk][ks], wm[blk][ks], wl, xh, xm, xl, acc[blk]);
+            }
+        }
+        if (XIN) {            // + x_t W_ih^T + b_ih + b_hh: B = (x0, x1, x2, 1, 0, 0, 0, 0) in the lanes of k-half 0
+            const bool lo_half = hh == 0;
+            const float x[8] = {lo_half ? xv[0] : 0.f, lo_half ? xv[1] : 0.f, lo_half ? xv[2] : 0.f, lo_half ? 1.f : 0.f, 0.f, 0.f, 0.f, 0.f};
+            bf16x8 xh, xm, xl;
+            split8x3(x, xh, xm, xl);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) acc[blk] = mfma6(wxh[blk], wxm[blk], wxl[blk], xh, xm, xl, acc[blk]);
+        }
+        __syncthreads();                                   // every wavefront has read its fragments of h_{t-1}
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const float* gi_ = reinterpret_cast<const float*>(&gin[blk][0]);
+            float act[16], hnew[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = fsigmoid(acc[blk][u] + (XIN ? 0.f : gi_[u]));
+                const float fg = fsigmoid(acc[blk][4 + u] + (XIN ? 0.f : gi_[4 + u]));
+                const float gg = ftanh(acc[blk][8 + u] + (XIN ? 0.f : gi_[8 + u]));
+                const float og = fsigmoid(acc[blk][12 + u] + (XIN ? 0.f : gi_[12 + u]));
+                c[blk][u] = fg * c[blk][u] + ig * gg;
+                hnew[u] = og * ftanh(c[blk][u]);
+                act[u] = ig; act[4 + u] = fg; act[8 + u] = gg; act[12 + u] = og;
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(grow + g * HID + 8 * blk) = make_float4(act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]);
+                const int ucol = 16 * w + 8 * blk + 4 * hh;
+                *reinterpret_cast<float4*>(c_out + (tok * 2 + dir) * HID + ucol) = make_float4(c[blk][0], c[blk][1], c[blk][2], c[blk][3]);
+                *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+            }
+            uint2 h2, m2, l2;
+            split4x3_(hnew[0], hnew[1], hnew[2], hnew[3], h2, m2, l2);
+            uint8_t* dst = hx + l31 * 256 + (((2 * w + blk) ^ sw) * 16) + 8 * hh;
+            *reinterpret_cast<uint2*>(dst) = h2;
+            *reinterpret_cast<uint2*>(dst + HX6_PLANE) = m2;
+            *reinterpret_cast<uint2*>(dst + 2 * HX6_PLANE) = l2;
+        }
+        __syncthreads();                                   // h_t is in place
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -496,7 +667,14 @@ static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w
                              float* h_out, float* c_out, const XIn& xi, void* stream) {
     const dim3 grid(rlt_cdiv(B, LISTS), 2), block(1024);
     hipStream_t st = rlt_stream(stream);
-    if (rlt_precision() == RLT_PRECISION_BF16X3) {
+    static const bool lstm6_on = [] { const char* e = getenv("RLT_LSTM6"); return !e || atoi(e) != 0; }();      // RLT_LSTM6=0: the f32 MFMA kernels (A/B runs)
+    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on) {
+        int rc = rlt_allow_lds(bilstm6_fwd_kernel<true>, LSTM6_LDS);
+        if (!rc) rc = rlt_allow_lds(bilstm6_fwd_kernel<false>, LSTM6_LDS);
+        if (rc) return rc;
+        if (xi.x) hipLaunchKernelGGL(bilstm6_fwd_kernel<true>, grid, dim3(512), LSTM6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+        else hipLaunchKernelGGL(bilstm6_fwd_kernel<false>, grid, dim3(512), LSTM6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+    } else if (rlt_precision() == RLT_PRECISION_BF16X3) {
         if (xi.x) hipLaunchKernelGGL(bilstm3_fwd_kernel<true>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
         else hipLaunchKernelGGL(bilstm3_fwd_kernel<false>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
     } else {

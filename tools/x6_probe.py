@@ -27,13 +27,18 @@ def timeit(fn, reps=10, warm=3):
 
 
 def main():
-    T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096 * 300
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    modes = ("fp32", "bf16x3", "bf16x6")
+    for a in sys.argv[1:]:
+        if a.startswith("--modes="):
+            modes = tuple(a.split("=", 1)[1].split(","))
+    T = int(pos[0]) if pos else 4096 * 300
     shapes = [("in_proj fwd NT", 0, 1, T, 768, 256), ("out_proj fwd NT", 0, 1, T, 256, 256), ("ffn1 fwd NT", 0, 1, T, 2048, 256),
               ("ffn2 fwd NT", 0, 1, T, 256, 2048), ("ffn1 dX NN", 0, 0, T, 256, 2048), ("ffn2 dX NN", 0, 0, T, 2048, 256),
               ("ffn1 dW TN", 1, 0, 2048, 256, T), ("ffn2 dW TN", 1, 0, 256, 2048, T), ("in_proj dW TN", 1, 0, 768, 256, T),
               ("lstm dWhh TN", 1, 0, 512, 128, T), ("lstm in NT", 0, 1, T, 1024, 256)]
     g = torch.Generator(device=dev).manual_seed(1)
-    tot = {m: 0.0 for m in ("fp32", "bf16x3", "bf16x6")}
+    tot = {m: 0.0 for m in modes}
     for name, ta, tb, M, Nn, K in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
         Bm = torch.randn((Nn, K) if tb else (K, Nn), device=dev, generator=g) / (K ** 0.5 if K < 10000 else 1.0)
@@ -50,7 +55,7 @@ def main():
             rows = torch.randint(0, M, (4096,), device=dev, generator=g)
             ref = A[rows].double() @ (Bm.double().t() if tb else Bm.double()) + bias.double()
         line = f"{name:16s} {M}x{Nn}x{K}:"
-        for mode in ("fp32", "bf16x3", "bf16x6"):
+        for mode in modes:
             N.set_precision(mode)
             ms = timeit(lambda: ops.gemm(ta, tb, M, Nn, K, A, A.shape[1], Bm, Bm.shape[1], C, Nn, bias=bias, colsum_a=cs))
             err = float((C[rows].double() - ref).abs().max() / ref.abs().max())
@@ -59,7 +64,7 @@ def main():
         print(line, flush=True)
         del A, Bm, C, ref
     print("sum of the products above: " + ", ".join(f"{m} {v:.2f} ms" for m, v in tot.items()))
-    N.set_precision("bf16x3")
+    N.set_precision("bf16x6")
 
 
 if __name__ == "__main__":
