@@ -536,17 +536,23 @@ constexpr int WL6_BYTES = 8 * 2 * 8 * 64 * 16;          // l plane of W_hh in fr
 constexpr int HX6_PLANE = LISTS * 256;                   // one plane of the h tile: 32 lists x 128 bf16
 constexpr size_t LSTM6_LDS = (size_t)WL6_BYTES + 3 * HX6_PLANE;
 
-template <bool XIN>
-__global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+// FULL: every workgroup holds 32 lists (B % 32 == 0): the stores are unconditional - behind an `if (valid)` hipcc loses the exact
+// load / store counts at the join and waits with vmcnt(0), i.e. for the write acknowledgements of the step's stores.
+template <bool XIN, bool FULL>
+__global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ gates, const float* __restrict__ pre,
+                                                          const float* __restrict__ w_hh_f,
                                                           const float* __restrict__ w_hh_r, int S, int B,
                                                           float* __restrict__ h_out, float* __restrict__ c_out, XIn xi) {
+    // `pre` = `gates` (the pre-activations are overwritten in place by the activated gates, each row read one step before it is
+    // written): a second name for the same buffer, so that hipcc's memory-counter bookkeeping does not tie the loads of the
+    // next row to the stores of this one
     extern __shared__ __attribute__((aligned(16))) uint8_t sm6[];
     uint4* wl_s = reinterpret_cast<uint4*>(sm6);
     uint8_t* hx = sm6 + WL6_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
     const int b = blockIdx.x * LISTS + l31;
-    const bool valid = b < B;
+    const bool valid = FULL || b < B;
 
     // A operand, block blk: row l31 <-> (gate l31 >> 3, unit 16 w + 8 blk + (l31 & 7)); fragment ks covers k = 16 ks + 8 hh + j
     bf16x8 wh[2][8], wm[2][8];
@@ -582,24 +588,62 @@ __global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ ga
     const uint8_t* hrow = hx + l31 * 256;
     __syncthreads();
 
-    for (int t = 0; t < S; ++t) {
-        const int s = dir ? S - 1 - t : t;
-        const size_t tok = (size_t)s * B + (valid ? b : 0);
-        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + 16 * w + 4 * hh;
-        float4 gin[2][4];
-        float xv[3] = {0.f, 0.f, 0.f};
-        if (XIN) {            // (invalid lists read list 0's row, never stored)
-            const float* xr = xi.x + tok * xi.I;
+    // Operands of a step that do not depend on the recurrence - the stashed pre-activations (layer 1) or the list's input row
+    // (layer 0) - are fetched one step ahead, and the fetch of step t + 1 is issued BETWEEN the activations of step t (which
+    // consume the registers) and its stores: vmcnt counts loads and stores in order, so loads issued behind the 12 stores of a
+    // step would wait for the write acknowledgements of those stores before they could be consumed - one exposed HBM
+    // write latency per step; in front of them, `s_waitcnt vmcnt(12)` lets the stores drain behind the next MFMA phase.
+    float4 gin[2][4];
+    float xv[3] = {0.f, 0.f, 0.f};
+    auto tok_of = [&](int t) { return (size_t)(dir ? S - 1 - t : t) * B + (valid ? b : 0); };
+    auto fetch = [&](int t) {              // (invalid lists read list 0's row, never stored)
+        const size_t tk = tok_of(t);
+        if (XIN) {
+            const float* xr = xi.x + tk * xi.I;
             xv[0] = xr[0];
             if (xi.I > 1) xv[1] = xr[1];
             if (xi.I > 2) xv[2] = xr[2];
         } else {
+            const float* gr = pre + tk * (8 * HID) + dir * 4 * HID + 16 * w + 4 * hh;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)    // unconditional; consumed after the MFMAs
-                    gin[blk][g] = *reinterpret_cast<const float4*>(grow + g * HID + 8 * blk);
+                for (int g = 0; g < 4; ++g) gin[blk][g] = *reinterpret_cast<const float4*>(gr + g * HID + 8 * blk);
         }
+    };
+    fetch(0);
+    asm volatile("" ::: "memory");             // (the loads stay in front of the stores below: hipcc sinks them into the loop preheader otherwise)
+    if (FULL) {
+        // the loop is entered with the same picture of outstanding operations as its back edge carries - 8 loads followed by
+        // the 12 stores of a step - so that hipcc's merged count at the loop head is vmcnt(12), not the vmcnt(0) the bare
+        // preheader (8 loads, nothing behind them) would force on every iteration.  The 12 stores go to step 0's own output
+        // rows, which step 0 overwrites (same wavefront, same addresses, program order).
+        const size_t tok = tok_of(0);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + 16 * w + 4 * hh;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            if (!XIN) {        // (layer 1 reads the gate rows as its pre-activations: only c / h rows are free to touch - those of
+                               //  the first three steps, each overwritten by its own step before anything reads it)
+                const int ucol = 16 * w + 8 * blk + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const size_t tq = tok_of(q < S ? q : S - 1);
+                    *reinterpret_cast<float4*>(c_out + (tq * 2 + dir) * HID + ucol) = z;
+                    *reinterpret_cast<float4*>(h_out + tq * (2 * HID) + dir * HID + ucol) = z;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + g * HID + 8 * blk) = z;
+                const int ucol = 16 * w + 8 * blk + 4 * hh;
+                *reinterpret_cast<float4*>(c_out + (tok * 2 + dir) * HID + ucol) = z;
+                *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) = z;
+            }
+        }
+    }
+    for (int t = 0; t < S; ++t) {
+        const size_t tok = tok_of(t);
+        float* grow = gates + tok * (8 * HID) + dir * 4 * HID + 16 * w + 4 * hh;
         f32x16 acc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -626,10 +670,10 @@ __global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ ga
             for (int blk = 0; blk < 2; ++blk) acc[blk] = mfma6(wxh[blk], wxm[blk], wxl[blk], xh, xm, xl, acc[blk]);
         }
         __syncthreads();                                   // every wavefront has read its fragments of h_{t-1}
+        float act[2][16], hnew[2][4];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const float* gi_ = reinterpret_cast<const float*>(&gin[blk][0]);
-            float act[16], hnew[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float ig = fsigmoid(acc[blk][u] + (XIN ? 0.f : gi_[u]));
@@ -637,19 +681,27 @@ __global__ __launch_bounds__(512) void bilstm6_fwd_kernel(float* __restrict__ ga
                 const float gg = ftanh(acc[blk][8 + u] + (XIN ? 0.f : gi_[8 + u]));
                 const float og = fsigmoid(acc[blk][12 + u] + (XIN ? 0.f : gi_[12 + u]));
                 c[blk][u] = fg * c[blk][u] + ig * gg;
-                hnew[u] = og * ftanh(c[blk][u]);
-                act[u] = ig; act[4 + u] = fg; act[8 + u] = gg; act[12 + u] = og;
+                hnew[blk][u] = og * ftanh(c[blk][u]);
+                act[blk][u] = ig; act[blk][4 + u] = fg; act[blk][8 + u] = gg; act[blk][12 + u] = og;
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t + 1 < S ? t + 1 : t);                      // unconditional (the last step re-reads its own row): exact vmcnt counts
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(grow + g * HID + 8 * blk) = make_float4(act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]);
+                    *reinterpret_cast<float4*>(grow + g * HID + 8 * blk) =
+                        make_float4(act[blk][4 * g], act[blk][4 * g + 1], act[blk][4 * g + 2], act[blk][4 * g + 3]);
                 const int ucol = 16 * w + 8 * blk + 4 * hh;
                 *reinterpret_cast<float4*>(c_out + (tok * 2 + dir) * HID + ucol) = make_float4(c[blk][0], c[blk][1], c[blk][2], c[blk][3]);
-                *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+                *reinterpret_cast<float4*>(h_out + tok * (2 * HID) + dir * HID + ucol) =
+                    make_float4(hnew[blk][0], hnew[blk][1], hnew[blk][2], hnew[blk][3]);
             }
             uint2 h2, m2, l2;
-            split4x3_(hnew[0], hnew[1], hnew[2], hnew[3], h2, m2, l2);
+            split4x3_(hnew[blk][0], hnew[blk][1], hnew[blk][2], hnew[blk][3], h2, m2, l2);
             uint8_t* dst = hx + l31 * 256 + (((2 * w + blk) ^ sw) * 16) + 8 * hh;
             *reinterpret_cast<uint2*>(dst) = h2;
             *reinterpret_cast<uint2*>(dst + HX6_PLANE) = m2;
@@ -669,11 +721,16 @@ static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w
     hipStream_t st = rlt_stream(stream);
     static const bool lstm6_on = [] { const char* e = getenv("RLT_LSTM6"); return !e || atoi(e) != 0; }();      // RLT_LSTM6=0: the f32 MFMA kernels (A/B runs)
     if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on) {
-        int rc = rlt_allow_lds(bilstm6_fwd_kernel<true>, LSTM6_LDS);
-        if (!rc) rc = rlt_allow_lds(bilstm6_fwd_kernel<false>, LSTM6_LDS);
+        auto go = [&](auto kern) {
+            const int rc = rlt_allow_lds(kern, LSTM6_LDS);
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(512), LSTM6_LDS, st, gates, (const float*)gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+            return 0;
+        };
+        const bool full = B % LISTS == 0;
+        const int rc = xi.x ? (full ? go(bilstm6_fwd_kernel<true, true>) : go(bilstm6_fwd_kernel<true, false>))
+                            : (full ? go(bilstm6_fwd_kernel<false, true>) : go(bilstm6_fwd_kernel<false, false>));
         if (rc) return rc;
-        if (xi.x) hipLaunchKernelGGL(bilstm6_fwd_kernel<true>, grid, dim3(512), LSTM6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
-        else hipLaunchKernelGGL(bilstm6_fwd_kernel<false>, grid, dim3(512), LSTM6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
     } else if (rlt_precision() == RLT_PRECISION_BF16X3) {
         if (xi.x) hipLaunchKernelGGL(bilstm3_fwd_kernel<true>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
         else hipLaunchKernelGGL(bilstm3_fwd_kernel<false>, grid, block, 0, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
