@@ -1382,6 +1382,15 @@ __device__ __forceinline__ void stash6c_part(uint16_t* __restrict__ T0, uint16_t
     *reinterpret_cast<uint2*>(dst + 2 * HB6) = lo;
 }
 
+#if defined(RLT_STAMPS)
+// timeline instrumentation (variant builds only, tools/bench_kernels.py g6c_stamps): s_memtime per wavefront at [slot start |
+// last MFMA issued | barrier passed] of the first 40 slots of one workgroup
+__device__ unsigned long long rlt_g6c_stamp_buf[8 * 40 * 3];
+#define RLT_G6C_STAMP(slot_, k_) do { if (blockIdx.x == (gridDim.x / 2 | 1) && (threadIdx.x & 63) == 0 && (slot_) < 40) \
+    rlt_g6c_stamp_buf[((threadIdx.x >> 6) * 40 + (slot_)) * 3 + (k_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RLT_G6C_STAMP(slot_, k_) do {} while (0)
+#endif
 template <bool TA, bool TB, bool PERSIST>
 __global__ __launch_bounds__(512) void gemm6c_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -1496,14 +1505,23 @@ __global__ __launch_bounds__(512) void gemm6c_kernel(GemmArgs g) {
     __syncthreads();
 
     int u = 0;                                         // k-steps of the stream so far, modulo 3: the buffer of this slot
+    int nslot = 0; (void)nslot;
     while (true) {
         for (int ti = 0; ti < nt; ++ti) {
             const int b0 = u, b1 = u == 2 ? 0 : u + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            RLT_G6C_STAMP(nslot, 0);
             slot(BoolTag<false>{}, b0, 0, 0, false, 0);                                   // even slot: k-step 2 ti
+            RLT_G6C_STAMP(nslot, 1);
             __syncthreads();
+            RLT_G6C_STAMP(nslot, 2);
+            ++nslot;
             // odd slot: k-step 2 ti + 1 out of b1; stages register tile ti + 1 into b2 and b0, fetches tile ti + 2
+            RLT_G6C_STAMP(nslot, 0);
             slot(BoolTag<true>{}, b1, b2, b0, ti + 1 < nt || has_next, ti + 2);
+            RLT_G6C_STAMP(nslot, 1);
             __syncthreads();
+            RLT_G6C_STAMP(nslot, 2);
+            ++nslot;
             u = b2;
         }
 #ifdef RLT_G6C_NOSTORE      // timing-only ablation (tools/build_variant.py): no output (results are wrong by design)
@@ -1697,6 +1715,9 @@ int choose_split(int M, int N, int K) {
 }
 
 #if defined(RLT_STAMPS)
+extern "C" int rlt_debug_g6c_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rlt_g6c_stamp_buf), n * sizeof(unsigned long long));
+}
 extern "C" int rlt_debug_gemm_stamps(unsigned long long* host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rlt_gemm_stamp_buf), n * sizeof(unsigned long long));
 }

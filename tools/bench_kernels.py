@@ -235,6 +235,37 @@ def gemm_stamps(T=4096 * 300):
         del A, Bm, C
 
 
+def g6c_stamps(T=4096 * 300):
+    """Slot timeline of one gemm6c workgroup (bf16x6 mode, library built with -DRLT_STAMPS): per wavefront and slot the cycles
+    from slot start to its last MFMA issue, and the wait at the barrier behind it; even slots only multiply, odd slots also
+    split the next register tile."""
+    import ctypes
+    fn = N.load().rlt_debug_g6c_stamps
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    N.set_precision("bf16x6")
+    for name, ta, tb, M, Nn, K in [("ffn1 fwd NT", 0, 1, T, 2048, 256), ("ffn2 fwd NT", 0, 1, T, 256, 2048), ("ffn1 dW TN", 1, 0, 2048, 256, T)]:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((Nn, K) if tb else (K, Nn), device=dev)
+        C = torch.empty(M, Nn, device=dev)
+        ms = timeit(lambda: ops.gemm(ta, tb, M, Nn, K, A, A.shape[1], Bm, Bm.shape[1], C, Nn))
+        buf = (ctypes.c_ulonglong * (8 * 40 * 3))()
+        assert fn(buf, 8 * 40 * 3) == 0
+        v = list(buf)
+        print(f"gemm6c {name} {M}x{Nn}x{K}: {ms:.3f} ms; slots 2..33 of one workgroup: cycles [start->last MFMA issued | barrier wait], slot period")
+        for w in range(8):
+            row = []
+            for sl in range(2, 34):
+                t0, t1, t2 = v[(w * 40 + sl) * 3:(w * 40 + sl) * 3 + 3]
+                nxt = v[(w * 40 + sl + 1) * 3]
+                row.append(f"{t1 - t0:5d}|{t2 - t1:4d}|{nxt - t0:5d}")
+            print(f"   w{w}: " + " ".join(row))
+        ev = [v[(0 * 40 + sl + 1) * 3] - v[(0 * 40 + sl) * 3] for sl in range(2, 34, 2)]
+        od = [v[(0 * 40 + sl + 1) * 3] - v[(0 * 40 + sl) * 3] for sl in range(3, 35, 2)]
+        print(f"   wave 0 mean slot period: even {sum(ev) / len(ev):.0f}, odd {sum(od) / len(od):.0f} cycles (48 MFMAs per wavefront and slot = 3,072 matrix cycles per SIMD)")
+        del A, Bm, C
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attention", "gemms", "lstm"]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
