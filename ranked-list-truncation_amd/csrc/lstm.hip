@@ -74,7 +74,6 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
                                                           const float* __restrict__ w_hh_r, int S, int B, float* __restrict__ h_out,
                                                           float* __restrict__ c_out, XIn xi) {
     __shared__ __attribute__((aligned(16))) float hs[2][LISTS * LDH];
-    __shared__ float4 xtab[XIN ? 4 * HID : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
     const int b = blockIdx.x * LISTS + l31;
@@ -82,16 +81,27 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
 
     // A operand: W_hh rows of this wavefront (gate l31>>3, unit 8w + (l31&7)), k = hh*64 + ks
     float wreg[64];
+    // XIN (layer 0): the input projection x W_ih^T + b_ih + b_hh rides on the same accumulators as TWO more MFMAs - k pairs
+    // (x0, x1) and (x2, 1) against (W_ih[row][0], W_ih[row][1]) and (W_ih[row][2], b_ih[row] + b_hh[row]): exact fp32
+    // products like every other one of the chain.  The LDS table + 16 float4 reads + 48 FMAs per lane and step this replaces
+    // pushed 32 of the 64 W_hh registers into scratch, re-read at every step: 10 GB of scratch reads per launch (the 8.8 GB
+    // against 2.5 GB of VERDICT r03 item 6).
+    float wx0 = 0.f, wx1 = 0.f;
     {
-        const float* wp = (dir ? w_hh_r : w_hh_f) + (size_t)((l31 >> 3) * HID + 8 * w + (l31 & 7)) * HID + hh * 64;
+        const int row = (l31 >> 3) * HID + 8 * w + (l31 & 7);
+        const float* wp = (dir ? w_hh_r : w_hh_f) + (size_t)row * HID + hh * 64;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(wp + 4 * q);
             wreg[4 * q + 0] = v.x; wreg[4 * q + 1] = v.y; wreg[4 * q + 2] = v.z; wreg[4 * q + 3] = v.w;
         }
+        if (XIN) {
+            const float* wr = xi.w_ih[dir] + (size_t)row * xi.I;
+            wx0 = hh == 0 ? wr[0] : (xi.I > 1 ? wr[1] : 0.f);
+            wx1 = hh == 0 ? (xi.I > 2 ? wr[2] : 0.f) : xi.b_ih[dir][row] + xi.b_hh[dir][row];
+        }
     }
     for (int i = tid; i < LISTS * LDH; i += 1024) hs[0][i] = 0.f;      // h_0 = 0
-    if (XIN) xin_table(xi, blockIdx.y, tid, 1024, xtab);
     float c[4] = {0.f, 0.f, 0.f, 0.f};                                  // c_0 = 0
     const int ucol = 8 * w + 4 * hh;                                    // first of this lane's 4 units
     __syncthreads();
@@ -102,8 +112,14 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
         const size_t tok = (size_t)s * B + (valid ? b : 0);
         float* grow = gates + tok * (8 * HID) + dir * 4 * HID + ucol;
         float4 gin[4];
-        if (XIN) xin_gates(xi, xtab, tok, ucol, gin);
-        else {
+        float xb0 = 0.f, xb1 = 0.f;                // B operands of the two input-projection MFMAs: (x0 | x1), (x2 | 1)
+        if (XIN) {                                 // (invalid lists read list 0's row, never stored)
+            const float* xr = xi.x + tok * xi.I;
+            xb0 = hh == 0 ? xr[0] : (xi.I > 1 ? xr[1] : 0.f);
+            xb1 = hh == 0 ? (xi.I > 2 ? xr[2] : 0.f) : 1.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gin[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g)    // unconditional (invalid lists read list 0's row, never stored); consumed after the MFMAs
                 gin[g] = *reinterpret_cast<const float4*>(grow + g * HID);
@@ -120,6 +136,10 @@ __global__ __launch_bounds__(1024) void bilstm_fwd_kernel(float* __restrict__ ga
             acc = mfma32(wreg[4 * q + 1], hv.y, acc);
             acc = mfma32(wreg[4 * q + 2], hv.z, acc);
             acc = mfma32(wreg[4 * q + 3], hv.w, acc);
+        }
+        if (XIN) {
+            acc = mfma32(wx0, xb0, acc);
+            acc = mfma32(wx1, xb1, acc);
         }
         const float* gi_ = reinterpret_cast<const float*>(&gin[0]);
         float act[16], hnew[4];
