@@ -16,6 +16,7 @@
 // image exists.  One LDS copy of a tile pair (55 KB): two workgroups per CU, their tile phases uncorrelated.
 #include "attention_common.h"
 #include <stdlib.h>
+#include <utility>
 
 #ifndef RLT_A6_DKV_PREFETCH
 #define RLT_A6_DKV_PREFETCH 0   // dK+dV kernel, 1: next tile's global loads issued BEFORE the tile body (32 staging registers live across it); measured 48.9 ms against 47.6 with the loads after the body (the partner workgroup covers their latency)
@@ -733,6 +734,303 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
     store_acc_T<HD>(drow + 2 * E, hh, dv, 1.f);
 }
 
+// ------------------------------------------------------------------------------------------ dK, dV: one wavefront per SIMD
+// Head dim 64.  The two-workgroup kernel above holds 160 stationary registers (K, V fragments, dK, dV) of the 256 a wavefront
+// has at two per SIMD; hipcc spills K fragments into the S chain and its tile body is blocks of MFMAs followed by blocks of vector
+// work that the SIMD partner does not absorb (profiles/r03_notes.md: a bf16 MFMA gap hides 4-5 plain vector instructions of the
+// SAME wavefront; a partner's wait behind an MFMA that waits for the pipe).  Here ONE 256-thread workgroup per CU owns 256 keys,
+// a wavefront 64 (two halves of 32), with 512 registers: K (h, m) / V fragments and the 8 accumulator blocks stay in registers
+// (the l plane of the K fragments in a wavefront-private LDS block), the Q / dO tile images are double-buffered (one barrier per
+// tile), and the tile body is ONE basic block of 64 steps of six MFMAs each; every step carries a fixed unit of the element-wise
+// work whose inputs are ready, spread behind the step's MFMAs by a sched_group_barrier pattern (MFMA, n vector) x 6:
+//   phases (8 steps each), block b = (query sub-tile b >> 1, key half b & 1):  X0 | X1 | Y0 | X2 | Y1 | X3 | Y2 | Y3
+//   X(b): S (4 steps) and dP (4 steps) of block b into ONE score / dP accumulator pair;  Y(b): dV, dK of block b (k-step s x d tile)
+//   vector units:  X0: P = exp2(S - lse) of block 0 behind its dP steps (its dS part is the one unit with no MFMAs beside it);
+//   X(b+1): split of k-step 0 of block b, then staging (Q tile in X1, dO tile in X3: split + LDS store of the next tile, global
+//   load of the one after into the same 16 registers);  Y(b): split of k-step 1 of block b, then P / dS of block b + 1.
+constexpr int QT1 = 256;
+constexpr int PH_KIND[8] = {0, 0, 1, 0, 1, 0, 1, 1};     // 0: X (S, dP), 1: Y (dV, dK)
+constexpr int PH_BLK[8] = {0, 1, 0, 2, 1, 3, 2, 3};
+struct Frag2 { bf16x8 h, m; };
+#ifndef RLT_DKV1_NV
+#define RLT_DKV1_NV 5
+#endif
+template <class F, int... I>
+__device__ __forceinline__ void static_for6(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+__device__ __forceinline__ bf16x8 cat2_6(uint2 a, uint2 b) { return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y)); }
+// element-wise unit of step g: 0 none, 1 exp part only (X0 steps 4..7, block 0), 2 P and dS (Y0 / Y1 / Y2 steps 4..7, block b + 1)
+constexpr int dkv1_e_kind(int g) {
+    const int p = g >> 3, j = g & 7;
+    if (p == 0 && j >= 4) return 1;
+    if ((p == 2 || p == 4 || p == 6) && j >= 4) return 2;
+    return 0;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
+    constexpr int HD = 64, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);              // [2 buffers][Q image | dO image]
+    float* tab0 = reinterpret_cast<float*>(img0 + 4 * IMG6);         // [2 buffers][lse * log2e | delta | row hashes][KT]
+    uint4* klp = reinterpret_cast<uint4*>(tab0 + 2 * 3 * KT);        // [4 wavefronts][2 key halves][4 k-steps][64 lanes]: K fragments, l plane
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT1);
+    int pair, ktile;
+    map_block(blockIdx.x, a.S * H, ntile, pair, ktile);
+    const int s_ = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s_ * B * ld + h * HD;
+    const float* dobase = a.dout + (size_t)s_ * B * E + h * HD;
+    const float* lsebase = a.lse + ((size_t)s_ * H + h) * B;
+    const float* delbase = a.delta + ((size_t)s_ * H + h) * B;
+    const int key0 = ktile * QT1 + wv * 64 + l31;                    // key of half 0; half 1: + 32
+
+    Frag2 kf[2][4];
+    Frag3 vf[2][4];
+    uint4* klw = klp + (size_t)wv * 2 * 4 * 64 + lane;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int kc = min(key0 + 32 * kh, B - 1);
+        Frag3 t3[4];
+        row_frags6<HD>(base + (size_t)kc * ld + E, hh, a.scale * LOG2E, t3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[kh][ks].h = t3[ks].h;
+            kf[kh][ks].m = t3[ks].m;
+            klw[(kh * 4 + ks) * 64] = __builtin_bit_cast(uint4, t3[ks].l);
+        }
+        row_frags6<HD>(base + (size_t)kc * ld + 2 * E, hh, 1.f, vf[kh]);
+    }
+    f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i >> 1][i & 1][r] = 0.f; dv[i >> 1][i & 1][r] = 0.f; }
+
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hk0 = DROP ? rlt_col_hash(ps, (uint32_t)key0) : 0u, hk1 = DROP ? rlt_col_hash(ps, (uint32_t)(key0 + 32)) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int nt = rlt_cdiv_dev(B, KT);
+    Stage6<HD> rs;                                                  // ONE staging set: Q of the next tile, then dO of the next tile, ...
+    float rl, re;
+    const int trow = tid & (KT - 1);
+    auto load_small = [&](int row0) {
+        const int qi = row0 + trow, qc = min(qi, B - 1);
+        const float l = lsebase[qc], e = delbase[qc];
+        rl = qi < B ? l * LOG2E : INFINITY;
+        re = qi < B ? e : 0.f;
+    };
+    auto store_small = [&](float* tb, int row0) {               // (the four wavefronts write the same 64 values)
+        tb[trow] = rl;
+        tb[KT + trow] = re;
+        if (DROP) reinterpret_cast<uint32_t*>(tb)[2 * KT + trow] = rlt_row_hash(ps, (uint32_t)(row0 + trow));
+    };
+    auto stage_unit = [&](uint16_t* img, int i) {
+        const int idx = tid + 256 * i;
+        uint2 h_, m_, l_;
+        split4x3_6(rs.v[i].x, rs.v[i].y, rs.v[i].z, rs.v[i].w, h_, m_, l_);
+        const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
+        *reinterpret_cast<uint2*>(img + off) = h_;
+        *reinterpret_cast<uint2*>(img + PL + off) = m_;
+        *reinterpret_cast<uint2*>(img + 2 * PL + off) = l_;
+    };
+    auto load_unit = [&](const float* src, size_t lds_, int row0, int i) {
+        const int idx = tid + 256 * i;
+        const int row = row0 + idx / (HD / 4), dq_ = idx % (HD / 4);
+        // rows beyond B repeat the last row (finite values): their lse entry is +inf, so P = dS = 0 and nothing reaches dK / dV;
+        // no select here - it would wait for the load where it is issued
+        rs.v[i] = *reinterpret_cast<const float4*>(src + (size_t)min(row, B - 1) * lds_ + 4 * dq_);
+    };
+    // prologue: tile 0 -> buffer 0; Q of tile 1 -> staging registers, lse / delta of tile 1 -> rl / re
+    {
+        Stage6<HD> r0;
+        stage6_load<HD>(base, ld, 0, B, tid, rs);
+        stage6_load<HD>(dobase, (size_t)E, 0, B, tid, r0);
+        load_small(0);
+        stage6_store<HD>(img0, tid, rs, 1.f);
+        stage6_store<HD>(img0 + IMG6, tid, r0, 1.f);
+        store_small(tab0, 0);
+        const int r1 = min(1, nt - 1) * KT;
+        stage6_load<HD>(base, ld, r1, B, tid, rs);
+        load_small(r1);
+    }
+    __syncthreads();
+
+    const uint4* klr_base = klp + (size_t)wv * 2 * 4 * 64 + lane;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const uint16_t* Qc = img0 + cur * 2 * IMG6;
+        const uint16_t* Dc = Qc + IMG6;
+        uint16_t* Qn = img0 + (cur ^ 1) * 2 * IMG6;
+        uint16_t* Dn = Qn + IMG6;
+        const float* Tc = tab0 + cur * 3 * KT;
+        float* Tn = tab0 + (cur ^ 1) * 3 * KT;
+        const int row_n1 = min(t + 1, nt - 1) * KT, row_n2 = min(t + 2, nt - 1) * KT;
+
+        f32x16 sc, dp;                               // S / dP accumulators of the block in its X phase
+        float pv[16], gv[16];                        // P (dropped) and dS of the block whose splits are under way
+        uint2 fr[2][2][2][3];                        // [P | dS][k-step][half][plane]: split operands of the dV / dK products
+        Frag3 afr[2];                                // A fragments of step g (buffer g & 1), read one step ahead
+        uint4 klr[2];
+        float4 lvr[2], evr[2];
+        uint4 hvr[2];
+
+        auto rd_rows = [&](const uint16_t* img, int sub, int ks, Frag3& f) {
+            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * ks;
+            f.h = *reinterpret_cast<const bf16x8*>(img + off);
+            f.m = *reinterpret_cast<const bf16x8*>(img + PL + off);
+            f.l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+        };
+        auto rd_cols = [&](const uint16_t* img, int sub, int s, int dt, Frag3& f) {
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            f.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR));
+            f.m = cat_frag6(tr_read6(img + PL + off), tr_read6(img + PL + off + 8 * LDR));
+            f.l = cat_frag6(tr_read6(img + 2 * PL + off), tr_read6(img + 2 * PL + off + 8 * LDR));
+        };
+        auto e_block = [&](int g) { return (g >> 3) >> 1; };            // phase 0: block 0; Y0 / Y1 / Y2 (phases 2, 4, 6): blocks 1, 2, 3      // block of the element-wise unit of step g
+        auto reads = [&](int g) {                    // everything step g takes from LDS (issued during step g - 1)
+            if (g >= 64) return;
+            const int p = g >> 3, j = g & 7, b = PH_BLK[p], sub = b >> 1, kh = b & 1;
+            if (PH_KIND[p] == 0) {
+                if (j < 4) { rd_rows(Qc, sub, j, afr[g & 1]); klr[g & 1] = klr_base[(kh * 4 + j) * 64]; }
+                else rd_rows(Dc, sub, j - 4, afr[g & 1]);
+            } else {
+                const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
+                rd_cols(which ? Qc : Dc, sub, s, dt, afr[g & 1]);
+            }
+            if (dkv1_e_kind(g)) {
+                const int r0 = (e_block(g) >> 1) * 32 + 8 * (j - 4) + 4 * hh;
+                lvr[g & 1] = *reinterpret_cast<const float4*>(Tc + r0);
+                if (dkv1_e_kind(g) == 2) {
+                    evr[g & 1] = *reinterpret_cast<const float4*>(Tc + KT + r0);
+                    if (DROP) hvr[g & 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + r0);
+                }
+            }
+        };
+        auto operand = [&](int m, int s) {
+            Frag3 f;
+            f.h = cat2_6(fr[m][s][0][0], fr[m][s][1][0]);
+            f.m = cat2_6(fr[m][s][0][1], fr[m][s][1][1]);
+            f.l = cat2_6(fr[m][s][0][2], fr[m][s][1][2]);
+            return f;
+        };
+        auto mfmas = [&](int g) {
+            const int p = g >> 3, j = g & 7, b = PH_BLK[p], kh = b & 1;
+            const Frag3& af = afr[g & 1];
+            if (PH_KIND[p] == 0) {
+                if (j < 4) {
+                    Frag3 bf;
+                    bf.h = kf[kh][j].h; bf.m = kf[kh][j].m; bf.l = __builtin_bit_cast(bf16x8, klr[g & 1]);
+                    if (j == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+                    }
+                    sc = mfma6(af, bf, sc);
+                } else {
+                    if (j == 4) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+                    }
+                    dp = mfma6(af, vf[kh][j - 4], dp);
+                }
+            } else {
+                const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
+                if (which == 0) dv[kh][dt] = mfma6(af, operand(0, s), dv[kh][dt]);
+                else dk[kh][dt] = mfma6(af, operand(1, s), dk[kh][dt]);
+            }
+        };
+        // registers 4c..4c+3 of block b: (part & 1) P = exp2(S - lse); (part & 2) dS = P (dP - delta) and the dropout of P
+        auto unit_e = [&](int part, int b, int c, const float4& l4, const float4& e4, const uint4& h4) {
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+            const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * c + i;
+                if (part & 1) pv[r] = rlt_exp2(sc[r] - lv[i]);
+                if (part & 2) {
+                    float dpr = dp[r];
+                    if (DROP) {
+                        const float m = rlt_keep_rc(hv[i], (b & 1) ? hk1 : hk0, a.drop_thr) ? inv_keep : 0.f;
+                        dpr *= m;
+                        gv[r] = pv[r] * (dpr - ev[i]);
+                        pv[r] *= m;
+                    } else {
+                        gv[r] = pv[r] * (dpr - ev[i]);
+                    }
+                }
+            }
+        };
+        auto unit_split = [&](int m, int s, int half) {
+            const float* w = m ? gv : pv;
+            const int r0 = 8 * s + 4 * half;
+            split4x3_6(w[r0], w[r0 + 1], w[r0 + 2], w[r0 + 3], fr[m][s][half][0], fr[m][s][half][1], fr[m][s][half][2]);
+        };
+        auto units = [&](int g) {
+            const int p = g >> 3, j = g & 7;
+            const uint4 hz = make_uint4(0u, 0u, 0u, 0u);
+            if (dkv1_e_kind(g) == 1) unit_e(1, 0, j - 4, lvr[g & 1], lvr[g & 1], hz);
+            if (dkv1_e_kind(g) == 2) unit_e(3, e_block(g), j - 4, lvr[g & 1], evr[g & 1], DROP ? hvr[g & 1] : hz);
+            if (p == 0) {
+                if (j == 0) store_small(Tn, row_n1);
+                if (j == 1) load_small(row_n2);
+            } else if (p == 1 || p == 3 || p == 5) {
+                if (j < 4) unit_split(j >> 1, 0, j & 1);                                  // k-step 0 of block p >> 1: P, P, dS, dS
+                else if (p == 1) { stage_unit(Qn, j - 4); load_unit(dobase, (size_t)E, row_n1, j - 4); }
+                else if (p == 5) { stage_unit(Dn, j - 4); load_unit(base, ld, row_n2, j - 4); }
+            } else if (p == 2 || p == 4 || p == 6) {
+                if (j < 4) unit_split(j >> 1, 1, j & 1);                                  // k-step 1
+            } else {                                  // Y3: dS k-step 0 | P k-step 1 | dS k-step 1 (P k-step 0 sits before the phase)
+                if (j < 2) unit_split(1, 0, j);
+                else if (j < 4) unit_split(0, 1, j - 2);
+                else if (j < 6) unit_split(1, 1, j - 4);
+            }
+        };
+
+        reads(0);
+        static_for6(std::make_integer_sequence<int, 64>{}, [&](auto G) {
+            constexpr int g = decltype(G)::value;
+            if (g == 8) {                             // dS of block 0: the accumulators are rewritten by X1
+                const int r0 = 4 * hh;
+                const uint4 hz = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 e4 = *reinterpret_cast<const float4*>(Tc + KT + r0 + 8 * c);
+                    const uint4 h4 = DROP ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + r0 + 8 * c) : hz;
+                    unit_e(2, 0, c, e4, e4, h4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 56) {                            // P k-step 0 of block 3
+                unit_split(0, 0, 0);
+                unit_split(0, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            reads(g + 1);
+            mfmas(g);
+            units(g);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int key = key0 + 32 * kh;
+        if (key < B) {
+            float* drow = a.dqkv + ((size_t)s_ * B + key) * ld + h * HD;
+            store_acc_T<HD>(drow + E, hh, dk[kh], a.scale);
+            store_acc_T<HD>(drow + 2 * E, hh, dv[kh], 1.f);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dQ
 template <int HD, bool DROP, bool IMG>
 __global__ __launch_bounds__(256, 2) void attn6_bwd_dq_kernel(AttnArgs a) {
@@ -844,6 +1142,15 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
             const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
             if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP, IMG>, shm_pp))) return rc;
             hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP, IMG>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);
+            return RLT_LAUNCH_RESULT();
+        }
+    }
+    if constexpr (HD == 64) {                 // dK+dV with one wavefront per SIMD: 256 keys per workgroup, double-buffered tiles
+        static const bool dkv1 = [] { const char* e = getenv("RLT_A6_DKV1"); return !e || atoi(e) != 0; }();
+        if (which == 1 && dkv1) {
+            const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * 3 * KT * sizeof(float) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
+            if ((rc = rlt_allow_lds(attn6_bwd_dkv1_kernel<DROP>, shm1))) return rc;
+            hipLaunchKernelGGL((attn6_bwd_dkv1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
             return RLT_LAUNCH_RESULT();
         }
     }
