@@ -51,6 +51,74 @@ __device__ __forceinline__ void split4x3_6(float a, float b, float c, float d, u
     lo.x = pk2_6(ra - __builtin_bit_cast(float, mid.x << 16), rb - __builtin_bit_cast(float, mid.x & 0xffff0000u));
     lo.y = pk2_6(rc - __builtin_bit_cast(float, mid.y << 16), rd - __builtin_bit_cast(float, mid.y & 0xffff0000u));
 }
+// the same split written one instruction per statement in LEVEL order (both conversions, the four unpacks, the four subtractions,
+// ...): volatile asm statements keep their order, so a sched_group_barrier pattern that hands them out four per MFMA gap never puts
+// an instruction next to the one it depends on - in that order the 22 instructions vanish in the shadows of six MFMAs of the same
+// wavefront (tools/micro/mfma_split.hip: 200 cycles per step with and without; 304 as a block behind the MFMAs)
+__device__ __forceinline__ void split4x3_lvl(float a, float b, float c, float d, uint2& hi, uint2& mid, uint2& lo) {
+    uint32_t t0, t1, t2, t3;
+    float r0, r1, r2, r3;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.x) : "v"(a), "v"(b));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.y) : "v"(c), "v"(d));
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(hi.x));
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(hi.x));
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t2) : "v"(hi.y));
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t3) : "v"(hi.y));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a), "v"(t0));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(b), "v"(t1));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(c), "v"(t2));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r3) : "v"(d), "v"(t3));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(mid.x) : "v"(r0), "v"(r1));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(mid.y) : "v"(r2), "v"(r3));
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(mid.x));
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(mid.x));
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t2) : "v"(mid.y));
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t3) : "v"(mid.y));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(r0), "v"(t0));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(r1), "v"(t1));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(r2), "v"(t2));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r3) : "v"(r3), "v"(t3));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo.x) : "v"(r0), "v"(r1));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo.y) : "v"(r2), "v"(r3));
+}
+// the level-ordered split as six parts (4, 4, 4, 4, 4, 2 instructions) with its state, for kernels that hand the parts out one
+// per MFMA gap themselves; `s_nop 0` behind each conversion pair: hipcc puts one between a v_cvt_pk_bf16_f32 and the use of its
+// result two instructions later in its own schedules, and it does not look into asm statements
+#ifndef RLT_SPLIT6_NOP
+#define RLT_SPLIT6_NOP "\n\ts_nop 0"
+#endif
+struct Split6 { uint2 hi, mid, lo; uint32_t t0, t1, t2, t3; float r0, r1, r2, r3; };
+__device__ __forceinline__ void split6_part(Split6& u, float a, float b, float c, float d, int part) {
+    if (part == 0) {
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.hi.x) : "v"(a), "v"(b));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" RLT_SPLIT6_NOP : "=v"(u.hi.y) : "v"(c), "v"(d));
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u.t0) : "v"(u.hi.x));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u.t1) : "v"(u.hi.x));
+    } else if (part == 1) {
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u.t2) : "v"(u.hi.y));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u.t3) : "v"(u.hi.y));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r0) : "v"(a), "v"(u.t0));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r1) : "v"(b), "v"(u.t1));
+    } else if (part == 2) {
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r2) : "v"(c), "v"(u.t2));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r3) : "v"(d), "v"(u.t3));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.mid.x) : "v"(u.r0), "v"(u.r1));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" RLT_SPLIT6_NOP : "=v"(u.mid.y) : "v"(u.r2), "v"(u.r3));
+    } else if (part == 3) {
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u.t0) : "v"(u.mid.x));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u.t1) : "v"(u.mid.x));
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u.t2) : "v"(u.mid.y));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u.t3) : "v"(u.mid.y));
+    } else if (part == 4) {
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r0) : "v"(u.r0), "v"(u.t0));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r1) : "v"(u.r1), "v"(u.t1));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r2) : "v"(u.r2), "v"(u.t2));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u.r3) : "v"(u.r3), "v"(u.t3));
+    } else {
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.lo.x) : "v"(u.r0), "v"(u.r1));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.lo.y) : "v"(u.r2), "v"(u.r3));
+    }
+}
 struct Frag3 { bf16x8 h, m, l; };
 __device__ __forceinline__ Frag3 split8x3(const float (&x)[8]) {
     uint2 h0, m0, l0, h1, m1, l1;
@@ -752,6 +820,20 @@ constexpr int QT1 = 256;
 constexpr int PH_KIND[8] = {0, 0, 1, 0, 1, 0, 1, 1};     // 0: X (S, dP), 1: Y (dV, dK)
 constexpr int PH_BLK[8] = {0, 1, 0, 2, 1, 3, 2, 3};
 struct Frag2 { bf16x8 h, m; };
+#ifndef RLT_DKV1_LVL
+#define RLT_DKV1_LVL 1
+#endif
+#if RLT_DKV1_LVL
+#define RLT_DKV1_SPLIT split4x3_lvl
+#else
+#define RLT_DKV1_SPLIT split4x3_6
+#endif
+#ifndef RLT_DKV1_NB
+#define RLT_DKV1_NB 2      // LDS fragment buffers: operands of step g are read during step g - (NB - 1)
+#endif
+#ifndef RLT_DKV1_PIN
+#define RLT_DKV1_PIN 1
+#endif
 #ifndef RLT_DKV1_NV
 #define RLT_DKV1_NV 5
 #endif
@@ -766,6 +848,14 @@ constexpr int dkv1_e_kind(int g) {
     return 0;
 }
 
+#ifdef RLT_DKV1_STAMPS
+// diagnostic build only: s_memtime at the phase boundaries of one workgroup, tiles 8..15 (tools/bench_kernels.py dkv1_stamps)
+__device__ unsigned long long dkv1_stamps[4 * 8 * 12];
+#define DKV1_STAMP(k) do { if (blockIdx.x == 64 && lane == 0 && t >= 8 && t < 16) \
+    dkv1_stamps[(wv * 8 + (t - 8)) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DKV1_STAMP(k) do { } while (0)
+#endif
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
     constexpr int HD = 64, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
@@ -826,15 +916,6 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         tb[KT + trow] = re;
         if (DROP) reinterpret_cast<uint32_t*>(tb)[2 * KT + trow] = rlt_row_hash(ps, (uint32_t)(row0 + trow));
     };
-    auto stage_unit = [&](uint16_t* img, int i) {
-        const int idx = tid + 256 * i;
-        uint2 h_, m_, l_;
-        split4x3_6(rs.v[i].x, rs.v[i].y, rs.v[i].z, rs.v[i].w, h_, m_, l_);
-        const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
-        *reinterpret_cast<uint2*>(img + off) = h_;
-        *reinterpret_cast<uint2*>(img + PL + off) = m_;
-        *reinterpret_cast<uint2*>(img + 2 * PL + off) = l_;
-    };
     auto load_unit = [&](const float* src, size_t lds_, int row0, int i) {
         const int idx = tid + 256 * i;
         const int row = row0 + idx / (HD / 4), dq_ = idx % (HD / 4);
@@ -868,157 +949,136 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         float* Tn = tab0 + (cur ^ 1) * 3 * KT;
         const int row_n1 = min(t + 1, nt - 1) * KT, row_n2 = min(t + 2, nt - 1) * KT;
 
+#if RLT_DKV1_PIN
+        // (keeps the eight accumulator blocks in AGPRs across the back edge: without it hipcc shares their registers with the
+        // S / dP accumulators and moves 64 of them out and back every tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("" : "+a"(dk[i >> 1][i & 1]));
+            asm volatile("" : "+a"(dv[i >> 1][i & 1]));
+        }
+#endif
         f32x16 sc, dp;                               // S / dP accumulators of the block in its X phase
         float pv[16], gv[16];                        // P (dropped) and dS of the block whose splits are under way
-        uint2 fr[2][2][2][3];                        // [P | dS][k-step][half][plane]: split operands of the dV / dK products
-        Frag3 afr[2];                                // A fragments of step g (buffer g & 1), read one step ahead
-        uint4 klr[2];
+        Split6 st[2][2][2];                          // [P | dS][k-step][half]: the split units (state and result)
+        Split6 sg[4];                                // staging units
+        Frag3 afr[RLT_DKV1_NB];                      // A fragments of an X step (buffer g % NB), read NB - 1 steps ahead
+        v4s trv[RLT_DKV1_NB][3][2];                  // A fragments of a Y step: [g % NB][plane h, m, l][half]
+        uint4 klr[RLT_DKV1_NB];
         float4 lvr[2], evr[2];
         uint4 hvr[2];
-
-        auto rd_rows = [&](const uint16_t* img, int sub, int ks, Frag3& f) {
-            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * ks;
-            f.h = *reinterpret_cast<const bf16x8*>(img + off);
-            f.m = *reinterpret_cast<const bf16x8*>(img + PL + off);
-            f.l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
-        };
-        auto rd_cols = [&](const uint16_t* img, int sub, int s, int dt, Frag3& f) {
-            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
-            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-            f.h = cat_frag6(tr_read6(img + off), tr_read6(img + off + 8 * LDR));
-            f.m = cat_frag6(tr_read6(img + PL + off), tr_read6(img + PL + off + 8 * LDR));
-            f.l = cat_frag6(tr_read6(img + 2 * PL + off), tr_read6(img + 2 * PL + off + 8 * LDR));
-        };
-        auto e_block = [&](int g) { return (g >> 3) >> 1; };            // phase 0: block 0; Y0 / Y1 / Y2 (phases 2, 4, 6): blocks 1, 2, 3      // block of the element-wise unit of step g
-        auto reads = [&](int g) {                    // everything step g takes from LDS (issued during step g - 1)
-            if (g >= 64) return;
-            const int p = g >> 3, j = g & 7, b = PH_BLK[p], sub = b >> 1, kh = b & 1;
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+        // LDS read k of step g1 (issued during step g1 - 1)
+        auto rd = [&](int g1, int k) __attribute__((always_inline)) {
+            const int p = g1 >> 3, j = g1 & 7, b = PH_BLK[p], sub = b >> 1, kh = b & 1;
             if (PH_KIND[p] == 0) {
-                if (j < 4) { rd_rows(Qc, sub, j, afr[g & 1]); klr[g & 1] = klr_base[(kh * 4 + j) * 64]; }
-                else rd_rows(Dc, sub, j - 4, afr[g & 1]);
+                const uint16_t* img = j < 4 ? Qc : Dc;
+                const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
+                if (k == 0) afr[g1 % RLT_DKV1_NB].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
+                else if (k == 1) afr[g1 % RLT_DKV1_NB].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+                else if (k == 2) afr[g1 % RLT_DKV1_NB].h = *reinterpret_cast<const bf16x8*>(img + off);
+                else klr[g1 % RLT_DKV1_NB] = klr_base[(kh * 4 + j) * 64];
             } else {
                 const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
-                rd_cols(which ? Qc : Dc, sub, s, dt, afr[g & 1]);
-            }
-            if (dkv1_e_kind(g)) {
-                const int r0 = (e_block(g) >> 1) * 32 + 8 * (j - 4) + 4 * hh;
-                lvr[g & 1] = *reinterpret_cast<const float4*>(Tc + r0);
-                if (dkv1_e_kind(g) == 2) {
-                    evr[g & 1] = *reinterpret_cast<const float4*>(Tc + KT + r0);
-                    if (DROP) hvr[g & 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + r0);
-                }
+                const uint16_t* img = which ? Qc : Dc;
+                const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+                const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;                   // m, l, h: the order the six products want them
+                trv[g1 % RLT_DKV1_NB][pl][k & 1] = tr_read6(img + pl * PL + off + (k & 1) * 8 * LDR);
             }
         };
-        auto operand = [&](int m, int s) {
-            Frag3 f;
-            f.h = cat2_6(fr[m][s][0][0], fr[m][s][1][0]);
-            f.m = cat2_6(fr[m][s][0][1], fr[m][s][1][1]);
-            f.l = cat2_6(fr[m][s][0][2], fr[m][s][1][2]);
-            return f;
+        auto tl = [&](int b, int c) __attribute__((always_inline)) {
+            lvr[c & 1] = *reinterpret_cast<const float4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
         };
-        auto mfmas = [&](int g) {
+        auto te = [&](int b, int c) __attribute__((always_inline)) {
+            evr[c & 1] = *reinterpret_cast<const float4*>(Tc + KT + (b >> 1) * 32 + 8 * c + 4 * hh);
+            if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + (b >> 1) * 32 + 8 * c + 4 * hh);
+        };
+        // product i of step g: (a.m, b.m), (a.l, b.h), (a.h, b.l), (a.m, b.h), (a.h, b.m), (a.h, b.h)
+        auto mf = [&](int g, int i) __attribute__((always_inline)) {
             const int p = g >> 3, j = g & 7, b = PH_BLK[p], kh = b & 1;
-            const Frag3& af = afr[g & 1];
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;     // plane 0 h, 1 m, 2 l
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
             if (PH_KIND[p] == 0) {
+                const Frag3& af = afr[g % RLT_DKV1_NB];
+                const bf16x8 av = ap == 0 ? af.h : ap == 1 ? af.m : af.l;
                 if (j < 4) {
-                    Frag3 bf;
-                    bf.h = kf[kh][j].h; bf.m = kf[kh][j].m; bf.l = __builtin_bit_cast(bf16x8, klr[g & 1]);
-                    if (j == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-                    }
-                    sc = mfma6(af, bf, sc);
+                    const bf16x8 bv = bp == 0 ? kf[kh][j].h : bp == 1 ? kf[kh][j].m : __builtin_bit_cast(bf16x8, klr[g % RLT_DKV1_NB]);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
                 } else {
-                    if (j == 4) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-                    }
-                    dp = mfma6(af, vf[kh][j - 4], dp);
+                    const Frag3& vv = vf[kh][j - 4];
+                    const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
                 }
             } else {
                 const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
-                if (which == 0) dv[kh][dt] = mfma6(af, operand(0, s), dv[kh][dt]);
-                else dk[kh][dt] = mfma6(af, operand(1, s), dk[kh][dt]);
+                const bf16x8 av = cat_frag6(trv[g % RLT_DKV1_NB][ap][0], trv[g % RLT_DKV1_NB][ap][1]);
+                const Split6& u0 = st[which][s][0];
+                const Split6& u1 = st[which][s][1];
+                const bf16x8 bv = bp == 0 ? cat2_6(u0.hi, u1.hi) : bp == 1 ? cat2_6(u0.mid, u1.mid) : cat2_6(u0.lo, u1.lo);
+                if (which == 0) dv[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dv[kh][dt], 0, 0, 0);
+                else dk[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dk[kh][dt], 0, 0, 0);
             }
         };
-        // registers 4c..4c+3 of block b: (part & 1) P = exp2(S - lse); (part & 2) dS = P (dP - delta) and the dropout of P
-        auto unit_e = [&](int part, int b, int c, const float4& l4, const float4& e4, const uint4& h4) {
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
-            const uint32_t hv[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * c + i;
-                if (part & 1) pv[r] = rlt_exp2(sc[r] - lv[i]);
-                if (part & 2) {
-                    float dpr = dp[r];
-                    if (DROP) {
-                        const float m = rlt_keep_rc(hv[i], (b & 1) ? hk1 : hk0, a.drop_thr) ? inv_keep : 0.f;
-                        dpr *= m;
-                        gv[r] = pv[r] * (dpr - ev[i]);
-                        pv[r] *= m;
-                    } else {
-                        gv[r] = pv[r] * (dpr - ev[i]);
-                    }
-                }
+        // register r of block b: P = exp2(S - lse) / dS = P (dP - delta) and the dropout of P
+        auto ea = [&](int b, int r) __attribute__((always_inline)) {
+            const float4& l4 = lvr[(r >> 2) & 1];
+            const float lv = (r & 3) == 0 ? l4.x : (r & 3) == 1 ? l4.y : (r & 3) == 2 ? l4.z : l4.w;
+            pv[r] = rlt_exp2(sc[r] - lv);
+        };
+        auto eb = [&](int b, int r) __attribute__((always_inline)) {
+            const float4& e4 = evr[(r >> 2) & 1];
+            const float ev = (r & 3) == 0 ? e4.x : (r & 3) == 1 ? e4.y : (r & 3) == 2 ? e4.z : e4.w;
+            float dpr = dp[r];
+            if (DROP) {
+                const uint4& h4 = hvr[(r >> 2) & 1];
+                const uint32_t hv = (r & 3) == 0 ? h4.x : (r & 3) == 1 ? h4.y : (r & 3) == 2 ? h4.z : h4.w;
+                const float m = rlt_keep_rc(hv, (b & 1) ? hk1 : hk0, a.drop_thr) ? inv_keep : 0.f;
+                dpr *= m;
+                gv[r] = pv[r] * (dpr - ev);
+                pv[r] *= m;
+            } else {
+                gv[r] = pv[r] * (dpr - ev);
             }
         };
-        auto unit_split = [&](int m, int s, int half) {
+        auto sp = [&](int m, int s, int half, int part) __attribute__((always_inline)) {
             const float* w = m ? gv : pv;
             const int r0 = 8 * s + 4 * half;
-            split4x3_6(w[r0], w[r0 + 1], w[r0 + 2], w[r0 + 3], fr[m][s][half][0], fr[m][s][half][1], fr[m][s][half][2]);
+            split6_part(st[m][s][half], w[r0], w[r0 + 1], w[r0 + 2], w[r0 + 3], part);
         };
-        auto units = [&](int g) {
-            const int p = g >> 3, j = g & 7;
-            const uint4 hz = make_uint4(0u, 0u, 0u, 0u);
-            if (dkv1_e_kind(g) == 1) unit_e(1, 0, j - 4, lvr[g & 1], lvr[g & 1], hz);
-            if (dkv1_e_kind(g) == 2) unit_e(3, e_block(g), j - 4, lvr[g & 1], evr[g & 1], DROP ? hvr[g & 1] : hz);
-            if (p == 0) {
-                if (j == 0) store_small(Tn, row_n1);
-                if (j == 1) load_small(row_n2);
-            } else if (p == 1 || p == 3 || p == 5) {
-                if (j < 4) unit_split(j >> 1, 0, j & 1);                                  // k-step 0 of block p >> 1: P, P, dS, dS
-                else if (p == 1) { stage_unit(Qn, j - 4); load_unit(dobase, (size_t)E, row_n1, j - 4); }
-                else if (p == 5) { stage_unit(Dn, j - 4); load_unit(base, ld, row_n2, j - 4); }
-            } else if (p == 2 || p == 4 || p == 6) {
-                if (j < 4) unit_split(j >> 1, 1, j & 1);                                  // k-step 1
-            } else {                                  // Y3: dS k-step 0 | P k-step 1 | dS k-step 1 (P k-step 0 sits before the phase)
-                if (j < 2) unit_split(1, 0, j);
-                else if (j < 4) unit_split(0, 1, j - 2);
-                else if (j < 6) unit_split(1, 1, j - 4);
+        // staging unit i (rows idx / 16 of the tile): which = 0: Q of tile t + 1 -> image, then load dO of tile t + 1 into the same
+        // registers; which = 1: dO of tile t + 1 -> image, then load Q of tile t + 2
+        auto stg = [&](int which, int i, int part) __attribute__((always_inline)) {
+            split6_part(sg[i], rs.v[i].x, rs.v[i].y, rs.v[i].z, rs.v[i].w, part);
+            if (part == 5) {
+                uint16_t* img = which ? Dn : Qn;
+                const int idx = tid + 256 * i;
+                const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
+                *reinterpret_cast<uint2*>(img + off) = sg[i].hi;
+                *reinterpret_cast<uint2*>(img + PL + off) = sg[i].mid;
+                *reinterpret_cast<uint2*>(img + 2 * PL + off) = sg[i].lo;
+                if (which == 0) load_unit(dobase, (size_t)E, row_n1, i);
+                else load_unit(base, ld, row_n2, i);
             }
         };
-
-        reads(0);
-        static_for6(std::make_integer_sequence<int, 64>{}, [&](auto G) {
-            constexpr int g = decltype(G)::value;
-            if (g == 8) {                             // dS of block 0: the accumulators are rewritten by X1
-                const int r0 = 4 * hh;
-                const uint4 hz = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 e4 = *reinterpret_cast<const float4*>(Tc + KT + r0 + 8 * c);
-                    const uint4 h4 = DROP ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + r0 + 8 * c) : hz;
-                    unit_e(2, 0, c, e4, e4, h4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (g == 56) {                            // P k-step 0 of block 3
-                unit_split(0, 0, 0);
-                unit_split(0, 0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            reads(g + 1);
-            mfmas(g);
-            units(g);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, RLT_DKV1_NV, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        store_small(Tn, row_n1);                     // lse / delta of tile t + 1 (loaded during tile t - 1)
+        load_small(row_n2);
+        rd(0, 0); rd(0, 1); rd(0, 2); rd(0, 3);
+#if RLT_DKV1_NB == 3
+        rd(1, 0); rd(1, 1); rd(1, 2); rd(1, 3);
+#endif
+        GAP_END;
+#if RLT_DKV1_NB == 3
+#include "attention6_dkv1_body3.inc"
+#else
+#include "attention6_dkv1_body.inc"
+#endif
+#undef GAP_END
+        DKV1_STAMP(8);
         __syncthreads();
+        DKV1_STAMP(9);
     }
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -1189,6 +1249,11 @@ size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat) {
     return (size_t)nmat * S * H * rlt_cdiv(B, KT) * per;
 }
 
+#ifdef RLT_DKV1_STAMPS
+extern "C" int rlt_debug_dkv1_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dkv1_stamps), sizeof(unsigned long long) * 4 * 8 * 12);
+}
+#endif
 #ifdef RLT_PP_STAMPS
 extern "C" int rlt_debug_pp_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamps), sizeof(unsigned long long) * 128);

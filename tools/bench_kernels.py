@@ -266,6 +266,34 @@ def g6c_stamps(T=4096 * 300):
         del A, Bm, C
 
 
+def dkv1_stamps(B=4096, S=60, H=4, HD=64):
+    """Phase timeline of the one-wavefront-per-SIMD dK+dV kernel: needs a -DRLT_DKV1_STAMPS library (RLT_HIP_LIB)."""
+    import ctypes
+    E = H * HD
+    T = S * B
+    qkv = torch.randn(T, 3 * E, device=dev); out = torch.randn(T, E, device=dev); lse = torch.randn(S, H, B, device=dev).abs() + 20
+    dout = torch.randn(T, E, device=dev); dqkv = torch.empty_like(qkv)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    ws = torch.empty(wb // 4 + 4, device=dev)
+    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream())
+    f = lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    ms = timeit(f)
+    fn = N.load().rlt_debug_dkv1_stamps
+    fn.restype = ctypes.c_int
+    buf = (ctypes.c_ulonglong * (4 * 8 * 12))()
+    assert fn(buf) == 0
+    v = list(buf)
+    print(f"dkv1 {ms:.3f} ms; per tile: phases X0 X1 Y0 X2 Y1 X3 Y2 Y3 | barrier wait | tile period   (48 MFMAs per phase = 1,536 matrix cycles)")
+    for w in range(4):
+        for tl in range(7):
+            st = v[(w * 8 + tl) * 12:(w * 8 + tl) * 12 + 12]
+            nx = v[(w * 8 + tl + 1) * 12]
+            ph = [st[k + 1] - st[k] for k in range(8)]
+            print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:5d}" for x in ph) + f" | {st[9] - st[8]:5d} | {nx - st[0]:6d}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attention", "gemms", "lstm"]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("RLT_")}, flush=True)
