@@ -51,39 +51,12 @@ __device__ __forceinline__ void split4x3_6(float a, float b, float c, float d, u
     lo.x = pk2_6(ra - __builtin_bit_cast(float, mid.x << 16), rb - __builtin_bit_cast(float, mid.x & 0xffff0000u));
     lo.y = pk2_6(rc - __builtin_bit_cast(float, mid.y << 16), rd - __builtin_bit_cast(float, mid.y & 0xffff0000u));
 }
-// the same split written one instruction per statement in LEVEL order (both conversions, the four unpacks, the four subtractions,
-// ...): volatile asm statements keep their order, so a sched_group_barrier pattern that hands them out four per MFMA gap never puts
-// an instruction next to the one it depends on - in that order the 22 instructions vanish in the shadows of six MFMAs of the same
-// wavefront (tools/micro/mfma_split.hip: 200 cycles per step with and without; 304 as a block behind the MFMAs)
-__device__ __forceinline__ void split4x3_lvl(float a, float b, float c, float d, uint2& hi, uint2& mid, uint2& lo) {
-    uint32_t t0, t1, t2, t3;
-    float r0, r1, r2, r3;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.x) : "v"(a), "v"(b));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi.y) : "v"(c), "v"(d));
-    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(hi.x));
-    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(hi.x));
-    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t2) : "v"(hi.y));
-    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t3) : "v"(hi.y));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a), "v"(t0));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(b), "v"(t1));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(c), "v"(t2));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r3) : "v"(d), "v"(t3));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(mid.x) : "v"(r0), "v"(r1));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(mid.y) : "v"(r2), "v"(r3));
-    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(mid.x));
-    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(mid.x));
-    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(t2) : "v"(mid.y));
-    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(t3) : "v"(mid.y));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(r0), "v"(t0));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(r1), "v"(t1));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(r2), "v"(t2));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r3) : "v"(r3), "v"(t3));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo.x) : "v"(r0), "v"(r1));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo.y) : "v"(r2), "v"(r3));
-}
-// the level-ordered split as six parts (4, 4, 4, 4, 4, 2 instructions) with its state, for kernels that hand the parts out one
-// per MFMA gap themselves; `s_nop 0` behind each conversion pair: hipcc puts one between a v_cvt_pk_bf16_f32 and the use of its
-// result two instructions later in its own schedules, and it does not look into asm statements
+// The split written one instruction per asm statement in LEVEL order (both conversions, the four unpacks, the four subtractions,
+// ...), as six parts (4, 4, 4, 4, 4, 2 instructions) with its state, for kernels that hand the parts out one per MFMA gap: in
+// that order no instruction sits next to the one it depends on, and the 22 instructions vanish in the shadows of six MFMAs of the
+// same wavefront (tools/micro/mfma_split.hip: 200 cycles per step with and without; 304 as a block behind the MFMAs).  `s_nop 0`
+// behind each conversion pair: hipcc puts one between a v_cvt_pk_bf16_f32 and the use of its result two instructions later in its
+// own schedules, and it does not look into asm statements.
 #ifndef RLT_SPLIT6_NOP
 #define RLT_SPLIT6_NOP "\n\ts_nop 0"
 #endif
@@ -804,50 +777,24 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ dK, dV: one wavefront per SIMD
 // Head dim 64.  The two-workgroup kernel above holds 160 stationary registers (K, V fragments, dK, dV) of the 256 a wavefront
-// has at two per SIMD; hipcc spills K fragments into the S chain and its tile body is blocks of MFMAs followed by blocks of vector
-// work that the SIMD partner does not absorb (profiles/r03_notes.md: a bf16 MFMA gap hides 4-5 plain vector instructions of the
-// SAME wavefront; a partner's wait behind an MFMA that waits for the pipe).  Here ONE 256-thread workgroup per CU owns 256 keys,
-// a wavefront 64 (two halves of 32), with 512 registers: K (h, m) / V fragments and the 8 accumulator blocks stay in registers
-// (the l plane of the K fragments in a wavefront-private LDS block), the Q / dO tile images are double-buffered (one barrier per
-// tile), and the tile body is ONE basic block of 64 steps of six MFMAs each; every step carries a fixed unit of the element-wise
-// work whose inputs are ready, spread behind the step's MFMAs by a sched_group_barrier pattern (MFMA, n vector) x 6:
-//   phases (8 steps each), block b = (query sub-tile b >> 1, key half b & 1):  X0 | X1 | Y0 | X2 | Y1 | X3 | Y2 | Y3
-//   X(b): S (4 steps) and dP (4 steps) of block b into ONE score / dP accumulator pair;  Y(b): dV, dK of block b (k-step s x d tile)
-//   vector units:  X0: P = exp2(S - lse) of block 0 behind its dP steps (its dS part is the one unit with no MFMAs beside it);
-//   X(b+1): split of k-step 0 of block b, then staging (Q tile in X1, dO tile in X3: split + LDS store of the next tile, global
-//   load of the one after into the same 16 registers);  Y(b): split of k-step 1 of block b, then P / dS of block b + 1.
+// has at two per SIMD; hipcc spills K fragments into the S chain (scratch reloads and `s_waitcnt vmcnt(0)` between the MFMAs) and
+// its tile body is blocks of MFMAs followed by blocks of vector work that the SIMD partner does not absorb.  A bf16 MFMA hides four
+// plain vector instructions of the SAME wavefront when they sit right behind it (tools/micro/mfma_split.hip).  So here ONE
+// 256-thread workgroup per CU owns 256 keys, a wavefront 64 (two halves of 32), with 512 registers: K (h, m) / V fragments and the
+// 8 accumulator blocks stay in registers (the l plane of the K fragments in a wavefront-private LDS block), the Q / dO tile images
+// are double-buffered (one barrier per tile), and the tile body is ONE basic block of 64 steps of six MFMAs, each MFMA followed by
+// a gap with at most one chunk (~4 vector instructions) of the element-wise work and one LDS read of the next step.  The chunks -
+// P = exp2(S - lse) and dS = P (dP - delta) per register, the three-way splits of P and dS in six parts, split + LDS store of the
+// next tile (Q, then dO through the same 16 staging registers) - are placed by tools/gen_attn6_body.py (earliest deadline first,
+// dependences checked there); `GAP_END` fences keep hipcc from reordering them:
+//   phases, block b = (query sub-tile b >> 1, key half b & 1):  X0 | X1 | Y0 | X2 | Y1 | X3 | Y2 | Y3
+//   X(b): S (4 steps) and dP (4 steps) of block b into ONE score / dP accumulator pair;  Y(b): dV, dK of block b (8 steps)
 constexpr int QT1 = 256;
-constexpr int PH_KIND[8] = {0, 0, 1, 0, 1, 0, 1, 1};     // 0: X (S, dP), 1: Y (dV, dK)
-constexpr int PH_BLK[8] = {0, 1, 0, 2, 1, 3, 2, 3};
 struct Frag2 { bf16x8 h, m; };
-#ifndef RLT_DKV1_LVL
-#define RLT_DKV1_LVL 1
-#endif
-#if RLT_DKV1_LVL
-#define RLT_DKV1_SPLIT split4x3_lvl
-#else
-#define RLT_DKV1_SPLIT split4x3_6
-#endif
-#ifndef RLT_DKV1_NB
-#define RLT_DKV1_NB 2      // LDS fragment buffers: operands of step g are read during step g - (NB - 1)
-#endif
 #ifndef RLT_DKV1_PIN
 #define RLT_DKV1_PIN 1
 #endif
-#ifndef RLT_DKV1_NV
-#define RLT_DKV1_NV 5
-#endif
-template <class F, int... I>
-__device__ __forceinline__ void static_for6(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 __device__ __forceinline__ bf16x8 cat2_6(uint2 a, uint2 b) { return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y)); }
-// element-wise unit of step g: 0 none, 1 exp part only (X0 steps 4..7, block 0), 2 P and dS (Y0 / Y1 / Y2 steps 4..7, block b + 1)
-constexpr int dkv1_e_kind(int g) {
-    const int p = g >> 3, j = g & 7;
-    if (p == 0 && j >= 4) return 1;
-    if ((p == 2 || p == 4 || p == 6) && j >= 4) return 2;
-    return 0;
-}
-
 #ifdef RLT_DKV1_STAMPS
 // diagnostic build only: s_memtime at the phase boundaries of one workgroup, tiles 8..15 (tools/bench_kernels.py dkv1_stamps)
 __device__ unsigned long long dkv1_stamps[4 * 8 * 12];
@@ -962,30 +909,30 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         float pv[16], gv[16];                        // P (dropped) and dS of the block whose splits are under way
         Split6 st[2][2][2];                          // [P | dS][k-step][half]: the split units (state and result)
         Split6 sg[4];                                // staging units
-        Frag3 afr[RLT_DKV1_NB];                      // A fragments of an X step (buffer g % NB), read NB - 1 steps ahead
-        v4s trv[RLT_DKV1_NB][3][2];                  // A fragments of a Y step: [g % NB][plane h, m, l][half]
-        uint4 klr[RLT_DKV1_NB];
+        Frag3 afr[2];                                // A fragments of an X step, read one step ahead
+        v4s trv[2][3][2];                            // A fragments of a Y step: [buffer][plane h, m, l][half]
+        uint4 klr[2];
         float4 lvr[2], evr[2];
         uint4 hvr[2];
 #define GAP_END __builtin_amdgcn_sched_barrier(0)
-        // LDS read k of step g1 (issued during step g1 - 1)
-        auto rd = [&](int g1, int k) __attribute__((always_inline)) {
-            const int p = g1 >> 3, j = g1 & 7, b = PH_BLK[p], sub = b >> 1, kh = b & 1;
-            if (PH_KIND[p] == 0) {
-                const uint16_t* img = j < 4 ? Qc : Dc;
-                const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
-                if (k == 0) afr[g1 % RLT_DKV1_NB].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
-                else if (k == 1) afr[g1 % RLT_DKV1_NB].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
-                else if (k == 2) afr[g1 % RLT_DKV1_NB].h = *reinterpret_cast<const bf16x8*>(img + off);
-                else klr[g1 % RLT_DKV1_NB] = klr_base[(kh * 4 + j) * 64];
-            } else {
-                const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
-                const uint16_t* img = which ? Qc : Dc;
-                const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
-                const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-                const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;                   // m, l, h: the order the six products want them
-                trv[g1 % RLT_DKV1_NB][pl][k & 1] = tr_read6(img + pl * PL + off + (k & 1) * 8 * LDR);
-            }
+#define ATTN6_STAMP DKV1_STAMP
+        // LDS read k of step j of X(b) / Y(b) into buffer u (issued one step ahead)
+        auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
+            const int sub = b >> 1, kh = b & 1;
+            const uint16_t* img = j < 4 ? Qc : Dc;
+            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
+            if (k == 0) afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
+            else if (k == 1) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+            else if (k == 2) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
+            else klr[u] = klr_base[(kh * 4 + j) * 64];
+        };
+        auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
+            const int sub = b >> 1, s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
+            const uint16_t* img = which ? Qc : Dc;
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;                       // m, l, h: the order the six products want them
+            trv[u][pl][k & 1] = tr_read6(img + pl * PL + off + (k & 1) * 8 * LDR);
         };
         auto tl = [&](int b, int c) __attribute__((always_inline)) {
             lvr[c & 1] = *reinterpret_cast<const float4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
@@ -994,33 +941,32 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             evr[c & 1] = *reinterpret_cast<const float4*>(Tc + KT + (b >> 1) * 32 + 8 * c + 4 * hh);
             if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + (b >> 1) * 32 + 8 * c + 4 * hh);
         };
-        // product i of step g: (a.m, b.m), (a.l, b.h), (a.h, b.l), (a.m, b.h), (a.h, b.m), (a.h, b.h)
-        auto mf = [&](int g, int i) __attribute__((always_inline)) {
-            const int p = g >> 3, j = g & 7, b = PH_BLK[p], kh = b & 1;
-            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;     // plane 0 h, 1 m, 2 l
+        // product i of a step: (a.m, b.m), (a.l, b.h), (a.h, b.l), (a.m, b.h), (a.h, b.m), (a.h, b.h); planes 0 h, 1 m, 2 l
+        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int kh = b & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            if (PH_KIND[p] == 0) {
-                const Frag3& af = afr[g % RLT_DKV1_NB];
-                const bf16x8 av = ap == 0 ? af.h : ap == 1 ? af.m : af.l;
-                if (j < 4) {
-                    const bf16x8 bv = bp == 0 ? kf[kh][j].h : bp == 1 ? kf[kh][j].m : __builtin_bit_cast(bf16x8, klr[g % RLT_DKV1_NB]);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
-                } else {
-                    const Frag3& vv = vf[kh][j - 4];
-                    const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
-                }
+            const bf16x8 av = ap == 0 ? afr[u].h : ap == 1 ? afr[u].m : afr[u].l;
+            if (j < 4) {
+                const bf16x8 bv = bp == 0 ? kf[kh][j].h : bp == 1 ? kf[kh][j].m : __builtin_bit_cast(bf16x8, klr[u]);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
             } else {
-                const int s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
-                const bf16x8 av = cat_frag6(trv[g % RLT_DKV1_NB][ap][0], trv[g % RLT_DKV1_NB][ap][1]);
-                const Split6& u0 = st[which][s][0];
-                const Split6& u1 = st[which][s][1];
-                const bf16x8 bv = bp == 0 ? cat2_6(u0.hi, u1.hi) : bp == 1 ? cat2_6(u0.mid, u1.mid) : cat2_6(u0.lo, u1.lo);
-                if (which == 0) dv[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dv[kh][dt], 0, 0, 0);
-                else dk[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dk[kh][dt], 0, 0, 0);
+                const Frag3& vv = vf[kh][j - 4];
+                const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
             }
+        };
+        auto my = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int kh = b & 1, s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
+            const bf16x8 av = cat_frag6(trv[u][ap][0], trv[u][ap][1]);
+            const Split6& u0 = st[which][s][0];
+            const Split6& u1 = st[which][s][1];
+            const bf16x8 bv = bp == 0 ? cat2_6(u0.hi, u1.hi) : bp == 1 ? cat2_6(u0.mid, u1.mid) : cat2_6(u0.lo, u1.lo);
+            if (which == 0) dv[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dv[kh][dt], 0, 0, 0);
+            else dk[kh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dk[kh][dt], 0, 0, 0);
         };
         // register r of block b: P = exp2(S - lse) / dS = P (dP - delta) and the dropout of P
         auto ea = [&](int b, int r) __attribute__((always_inline)) {
@@ -1065,17 +1011,15 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         };
         store_small(Tn, row_n1);                     // lse / delta of tile t + 1 (loaded during tile t - 1)
         load_small(row_n2);
-        rd(0, 0); rd(0, 1); rd(0, 2); rd(0, 3);
-#if RLT_DKV1_NB == 3
-        rd(1, 0); rd(1, 1); rd(1, 2); rd(1, 3);
-#endif
+        rx(0, 0, 0, 0); rx(0, 1, 0, 0); rx(0, 2, 0, 0); rx(0, 3, 0, 0);
         GAP_END;
-#if RLT_DKV1_NB == 3
-#include "attention6_dkv1_body3.inc"
-#else
+        if constexpr (DROP) {
+#include "attention6_dkv1_body_drop.inc"
+        } else {
 #include "attention6_dkv1_body.inc"
-#endif
+        }
 #undef GAP_END
+#undef ATTN6_STAMP
         DKV1_STAMP(8);
         __syncthreads();
         DKV1_STAMP(9);
@@ -1088,6 +1032,198 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             store_acc_T<HD>(drow + E, hh, dk[kh], a.scale);
             store_acc_T<HD>(drow + 2 * E, hh, dv[kh], 1.f);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dQ: one wavefront per SIMD
+// The same construction for dQ (head dim 64): a workgroup owns 256 queries, a wavefront 64 (two halves of 32) with the Q (h, m) /
+// dO fragments, lse, delta and the four dQ accumulator blocks in registers (l plane of the Q fragments in LDS); K / V tile images
+// double-buffered; block b = (key sub-tile b >> 1, query half b & 1): X(b) = S^T and dP^T (8 steps), Y(b) = dQ^T += K^T dS^T
+// (4 steps: k-step s x d tile); tile body generated by tools/gen_attn6_body.py dq.  Keys beyond B: their K rows are staged as
+// zeros, so whatever dS they get multiplies a zero column of K^T - no mask on the scores.
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
+    constexpr int HD = 64, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);              // [2 buffers][K image | V image]
+    uint32_t* tab0 = reinterpret_cast<uint32_t*>(img0 + 4 * IMG6);   // [2 buffers][KT] column hashes of the tile's keys (DROP)
+    uint4* qlp = reinterpret_cast<uint4*>(tab0 + 2 * KT);            // [4 wavefronts][2 query halves][4 k-steps][64 lanes]: Q fragments, l plane
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int B = a.B, H = a.H, E = H * HD;
+    const size_t ld = (size_t)3 * E;
+    const int ntile = rlt_cdiv_dev(B, QT1);
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, ntile, pair, qt);
+    const int s_ = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s_ * B * ld + h * HD;
+    const int q0 = qt * QT1 + wv * 64 + l31;                        // query of half 0; half 1: + 32
+
+    Frag2 qf[2][4];
+    Frag3 dof[2][4];
+    float lse2[2], del[2];
+    uint4* qlw = qlp + (size_t)wv * 2 * 4 * 64 + lane;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        const int qc = min(q0 + 32 * qh, B - 1);
+        Frag3 t3[4];
+        row_frags6<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, t3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[qh][ks].h = t3[ks].h;
+            qf[qh][ks].m = t3[ks].m;
+            qlw[(qh * 4 + ks) * 64] = __builtin_bit_cast(uint4, t3[ks].l);
+        }
+        row_frags6<HD>(a.dout + ((size_t)s_ * B + qc) * E + h * HD, hh, 1.f, dof[qh]);
+        lse2[qh] = a.lse[((size_t)s_ * H + h) * B + qc] * LOG2E;
+        del[qh] = a.delta[((size_t)s_ * H + h) * B + qc];
+    }
+    f32x16 dq[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i >> 1][i & 1][r] = 0.f;
+
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const uint32_t hq0 = DROP ? rlt_row_hash(ps, (uint32_t)q0) : 0u, hq1 = DROP ? rlt_row_hash(ps, (uint32_t)(q0 + 32)) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int nt = rlt_cdiv_dev(B, KT);
+    Stage6<HD> rs;                                                  // ONE staging set: K of the next tile, then V of the next tile, ...
+    const int trow = tid & (KT - 1);
+    auto load_unit = [&](const float* src, int row0, int i) {
+        const int idx = tid + 256 * i;
+        const int row = row0 + idx / (HD / 4), dq_ = idx % (HD / 4);
+        rs.v[i] = *reinterpret_cast<const float4*>(src + (size_t)min(row, B - 1) * ld + 4 * dq_);
+    };
+    {   // prologue: tile 0 -> buffer 0; K of tile 1 -> staging registers
+        Stage6<HD> r0;
+        stage6_load<HD>(base + E, ld, 0, B, tid, rs);               // (zero rows beyond B)
+        stage6_load<HD>(base + 2 * E, ld, 0, B, tid, r0);
+        stage6_store<HD>(img0, tid, rs, 1.f);
+        stage6_store<HD>(img0 + IMG6, tid, r0, 1.f);
+        if (DROP) tab0[trow] = rlt_col_hash(ps, (uint32_t)trow);
+        const int r1 = min(1, nt - 1) * KT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_unit(base + E, r1, i);
+    }
+    __syncthreads();
+
+    const uint4* qlr_base = qlp + (size_t)wv * 2 * 4 * 64 + lane;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const uint16_t* Kc = img0 + cur * 2 * IMG6;
+        const uint16_t* Vc = Kc + IMG6;
+        uint16_t* Kn = img0 + (cur ^ 1) * 2 * IMG6;
+        uint16_t* Vn = Kn + IMG6;
+        const uint32_t* Tc = tab0 + cur * KT;
+        uint32_t* Tn = tab0 + (cur ^ 1) * KT;
+        const int row_n1 = min(t + 1, nt - 1) * KT, row_n2 = min(t + 2, nt - 1) * KT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(dq[i >> 1][i & 1]));     // (see attn6_bwd_dkv1_kernel)
+        f32x16 sc, dp;                               // S^T / dP^T accumulators of the block in its X phase
+        float pv[16], gv[16];                        // P and dS^T of the block whose element-wise work / splits are under way
+        Split6 st[2][2][2];                          // [1][k-step][half]: the split units of dS^T (state and result)
+        Split6 sg[4];                                // staging units
+        Frag3 afr[2];
+        v4s trv[2][3][2];
+        uint4 qlr[2];
+        uint4 hvr[2];
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+#define ATTN6_STAMP DKV1_STAMP
+        auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
+            const int sub = b >> 1, qh = b & 1;
+            const uint16_t* img = j < 4 ? Kc : Vc;
+            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
+            if (k == 0) afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
+            else if (k == 1) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+            else if (k == 2) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
+            else qlr[u] = qlr_base[(qh * 4 + j) * 64];
+        };
+        auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
+            const int sub = b >> 1, s = j >> 1, dt = j & 1;
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
+            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;
+            trv[u][pl][k & 1] = tr_read6(Kc + pl * PL + off + (k & 1) * 8 * LDR);
+        };
+        auto te = [&](int b, int c) __attribute__((always_inline)) {
+            if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
+        };
+        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int qh = b & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            const bf16x8 av = ap == 0 ? afr[u].h : ap == 1 ? afr[u].m : afr[u].l;
+            if (j < 4) {
+                const bf16x8 bv = bp == 0 ? qf[qh][j].h : bp == 1 ? qf[qh][j].m : __builtin_bit_cast(bf16x8, qlr[u]);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
+            } else {
+                const Frag3& vv = dof[qh][j - 4];
+                const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
+            }
+        };
+        auto my = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int qh = b & 1, s = j >> 1, dt = j & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
+            const bf16x8 av = cat_frag6(trv[u][ap][0], trv[u][ap][1]);
+            const Split6& u0 = st[1][s][0];
+            const Split6& u1 = st[1][s][1];
+            const bf16x8 bv = bp == 0 ? cat2_6(u0.hi, u1.hi) : bp == 1 ? cat2_6(u0.mid, u1.mid) : cat2_6(u0.lo, u1.lo);
+            dq[qh][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, dq[qh][dt], 0, 0, 0);
+        };
+        auto ea = [&](int b, int r) __attribute__((always_inline)) { pv[r] = rlt_exp2(sc[r] - lse2[b & 1]); };
+        auto eb = [&](int b, int r) __attribute__((always_inline)) {
+            float dpr = dp[r];
+            if (DROP) {
+                const uint4& h4 = hvr[(r >> 2) & 1];
+                const uint32_t hv = (r & 3) == 0 ? h4.x : (r & 3) == 1 ? h4.y : (r & 3) == 2 ? h4.z : h4.w;
+                dpr = rlt_keep_rc((b & 1) ? hq1 : hq0, hv, a.drop_thr) ? dpr * inv_keep : 0.f;
+            }
+            gv[r] = pv[r] * (dpr - del[b & 1]);
+        };
+        auto sp = [&](int m, int s, int half, int part) __attribute__((always_inline)) {
+            const int r0 = 8 * s + 4 * half;
+            split6_part(st[1][s][half], gv[r0], gv[r0 + 1], gv[r0 + 2], gv[r0 + 3], part);
+        };
+        // staging unit i: which = 0: K of tile t + 1 (rows beyond B as zeros) -> image, then load V of tile t + 1 into the same
+        // registers; which = 1: V of tile t + 1 -> image, then load K of tile t + 2
+        auto stg = [&](int which, int i, int part) __attribute__((always_inline)) {
+            const int idx = tid + 256 * i;
+            if (which == 0 && part == 0) {
+                const bool ok = row_n1 + idx / (HD / 4) < B;
+                rs.v[i] = make_float4(ok ? rs.v[i].x : 0.f, ok ? rs.v[i].y : 0.f, ok ? rs.v[i].z : 0.f, ok ? rs.v[i].w : 0.f);
+            }
+            split6_part(sg[i], rs.v[i].x, rs.v[i].y, rs.v[i].z, rs.v[i].w, part);
+            if (part == 5) {
+                uint16_t* img = which ? Vn : Kn;
+                const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
+                *reinterpret_cast<uint2*>(img + off) = sg[i].hi;
+                *reinterpret_cast<uint2*>(img + PL + off) = sg[i].mid;
+                *reinterpret_cast<uint2*>(img + 2 * PL + off) = sg[i].lo;
+                if (which == 0) load_unit(base + 2 * E, row_n1, i);
+                else load_unit(base + E, row_n2, i);
+            }
+        };
+        if (DROP) Tn[trow] = rlt_col_hash(ps, (uint32_t)(row_n1 + trow));
+        rx(0, 0, 0, 0); rx(0, 1, 0, 0); rx(0, 2, 0, 0); rx(0, 3, 0, 0);
+        GAP_END;
+        if constexpr (DROP) {
+#include "attention6_dq1_body_drop.inc"
+        } else {
+#include "attention6_dq1_body.inc"
+        }
+#undef GAP_END
+#undef ATTN6_STAMP
+        DKV1_STAMP(8);
+        __syncthreads();
+        DKV1_STAMP(9);
+    }
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        const int q = q0 + 32 * qh;
+        if (q < B) store_acc_T<HD>(a.dqkv + ((size_t)s_ * B + q) * ld + h * HD, hh, dq[qh], a.scale);
     }
 }
 
@@ -1207,6 +1343,13 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     }
     if constexpr (HD == 64) {                 // dK+dV with one wavefront per SIMD: 256 keys per workgroup, double-buffered tiles
         static const bool dkv1 = [] { const char* e = getenv("RLT_A6_DKV1"); return !e || atoi(e) != 0; }();
+        static const bool dq1 = [] { const char* e = getenv("RLT_A6_DQ1"); return !e || atoi(e) != 0; }();
+        if (which == 2 && dq1) {
+            const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
+            if ((rc = rlt_allow_lds(attn6_bwd_dq1_kernel<DROP>, shm1))) return rc;
+            hipLaunchKernelGGL((attn6_bwd_dq1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
+            return RLT_LAUNCH_RESULT();
+        }
         if (which == 1 && dkv1) {
             const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * 3 * KT * sizeof(float) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
             if ((rc = rlt_allow_lds(attn6_bwd_dkv1_kernel<DROP>, shm1))) return rc;
