@@ -62,6 +62,10 @@ __device__ __forceinline__ void split4x3_6(float a, float b, float c, float d, u
 #endif
 struct Split6 { uint2 hi, mid, lo; uint32_t t0, t1, t2, t3; float r0, r1, r2, r3; };
 __device__ __forceinline__ void split6_part(Split6& u, float a, float b, float c, float d, int part) {
+#ifdef RLT_SPLIT6_EMPTY        // diagnostic: the results exist for the compiler, no instruction is issued (wrong results)
+    if (part == 5) asm volatile("" : "=v"(u.hi.x), "=v"(u.hi.y), "=v"(u.mid.x), "=v"(u.mid.y), "=v"(u.lo.x), "=v"(u.lo.y) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return;
+#endif
     if (part == 0) {
         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.hi.x) : "v"(a), "v"(b));
         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" RLT_SPLIT6_NOP : "=v"(u.hi.y) : "v"(c), "v"(d));
@@ -796,10 +800,11 @@ struct Frag2 { bf16x8 h, m; };
 #endif
 __device__ __forceinline__ bf16x8 cat2_6(uint2 a, uint2 b) { return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y)); }
 #ifdef RLT_DKV1_STAMPS
-// diagnostic build only: s_memtime at the phase boundaries of one workgroup, tiles 8..15 (tools/bench_kernels.py dkv1_stamps)
-__device__ unsigned long long dkv1_stamps[4 * 8 * 12];
-#define DKV1_STAMP(k) do { if (blockIdx.x == 64 && lane == 0 && t >= 8 && t < 16) \
-    dkv1_stamps[(wv * 8 + (t - 8)) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// diagnostic build only: s_memtime at every step of tiles 8..11 of one workgroup (tools/bench_kernels.py dkv1_stamps); entries 64 /
+// 65: before / behind the barrier
+__device__ unsigned long long dkv1_stamps[4 * 4 * 66];
+#define DKV1_STAMP(k) do { if (blockIdx.x == 64 && lane == 0 && t >= 8 && t < 12) \
+    dkv1_stamps[(wv * 4 + (t - 8)) * 66 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DKV1_STAMP(k) do { } while (0)
 #endif
@@ -1020,9 +1025,9 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         }
 #undef GAP_END
 #undef ATTN6_STAMP
-        DKV1_STAMP(8);
+        DKV1_STAMP(64);
         __syncthreads();
-        DKV1_STAMP(9);
+        DKV1_STAMP(65);
     }
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -1216,9 +1221,9 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         }
 #undef GAP_END
 #undef ATTN6_STAMP
-        DKV1_STAMP(8);
+        DKV1_STAMP(64);
         __syncthreads();
-        DKV1_STAMP(9);
+        DKV1_STAMP(65);
     }
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
@@ -1394,7 +1399,7 @@ size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat) {
 
 #ifdef RLT_DKV1_STAMPS
 extern "C" int rlt_debug_dkv1_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dkv1_stamps), sizeof(unsigned long long) * 4 * 8 * 12);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dkv1_stamps), sizeof(unsigned long long) * 4 * 4 * 66);
 }
 #endif
 #ifdef RLT_PP_STAMPS

@@ -266,7 +266,7 @@ def g6c_stamps(T=4096 * 300):
         del A, Bm, C
 
 
-def dkv1_stamps(B=4096, S=60, H=4, HD=64):
+def dkv1_stamps(B=4096, S=60, H=4, HD=64, which="dkv"):
     """Phase timeline of the one-wavefront-per-SIMD dK+dV kernel: needs a -DRLT_DKV1_STAMPS library (RLT_HIP_LIB)."""
     import ctypes
     E = H * HD
@@ -278,20 +278,25 @@ def dkv1_stamps(B=4096, S=60, H=4, HD=64):
     wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
     ws = torch.empty(wb // 4 + 4, device=dev)
     call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream())
-    f = lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
     ms = timeit(f)
     fn = N.load().rlt_debug_dkv1_stamps
     fn.restype = ctypes.c_int
-    buf = (ctypes.c_ulonglong * (4 * 8 * 12))()
+    buf = (ctypes.c_ulonglong * (4 * 4 * 66))()
     assert fn(buf) == 0
     v = list(buf)
-    print(f"dkv1 {ms:.3f} ms; per tile: phases X0 X1 Y0 X2 Y1 X3 Y2 Y3 | barrier wait | tile period   (48 MFMAs per phase = 1,536 matrix cycles)")
-    for w in range(4):
-        for tl in range(7):
-            st = v[(w * 8 + tl) * 12:(w * 8 + tl) * 12 + 12]
-            nx = v[(w * 8 + tl + 1) * 12]
-            ph = [st[k + 1] - st[k] for k in range(8)]
-            print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:5d}" for x in ph) + f" | {st[9] - st[8]:5d} | {nx - st[0]:6d}")
+    nstep = 64 if which == "dkv" else 48
+    print(f"{which}1 {ms:.3f} ms; cycles per step (six MFMAs = 192 matrix cycles) of tiles 9, 10 of wavefronts 0 and 3, then barrier wait and tile period")
+    for w in (0, 3):
+        for tl in (1, 2):
+            st = v[(w * 4 + tl) * 66:(w * 4 + tl) * 66 + 66]
+            nx = v[(w * 4 + tl + 1) * 66]
+            d = [st[k + 1] - st[k] for k in range(nstep - 1)] + [st[64] - st[nstep - 1]]
+            print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:4d}" for x in d) + f" | {st[65] - st[64]:5d} | {nx - st[0]:6d}")
+
+
+def dq1_stamps():
+    dkv1_stamps(which="dq")
 
 
 if __name__ == "__main__":

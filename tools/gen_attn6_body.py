@@ -24,6 +24,8 @@ ea / eb (block, register), sp (matrix, k-step, half, part), stg (matrix, unit, p
 import sys
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "dkv"
+import os
+OMIT = set(os.environ.get("GEN_OMIT", "").split(","))     # diagnostic: leave out the calls of these kinds (results are wrong)
 DROP = len(sys.argv) > 2 and sys.argv[2] == "drop"
 AHEAD = 1                                # LDS operands of step g are read during step g - AHEAD
 NB = AHEAD + 1
@@ -214,9 +216,7 @@ last_kind_b = None
 phase = 0
 for g, (kind, b, j) in enumerate(steps):
     out.append(f"// step {g}: {kind}{b}.{j}")
-    if j == 0:
-        out.append(f"ATTN6_STAMP({phase});")
-        phase += 1
+    out.append(f"ATTN6_STAMP({g});")
     gn = g + AHEAD
     for i in range(6):
         q = 6 * g + i
@@ -224,7 +224,8 @@ for g, (kind, b, j) in enumerate(steps):
         if i < nreads(gn):
             k2, b2, j2 = steps[gn]
             line += f" r{k2.lower()}({gn % NB}, {i}, {b2}, {j2});"
-        line += " " + " ".join(pref[q] + sched[q])
+        work = [c for c in pref[q] + sched[q] if c.split("(")[0] not in OMIT]
+        line += " " + " ".join(work)
         if not sched[q]:
             idle += 1
         out.append(line.rstrip() + " GAP_END;")

@@ -62,6 +62,37 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ in, float* __
             SUB(r0, r0, t0_); SUB(r1, r1, t1_); SUB(r2, r2, t2_); SUB(r3, r3, t3_);
             CVT(l01, r0, r1); CVT(l23, r2, r3);
         }
+        if (MODE == 6 || MODE == 7 || MODE == 8) {
+            // the X step of the attention kernels: the split in level order, 4 per gap, one ds_read_b128 in each of the first four
+            // gaps (mode 7: the MFMAs of the NEXT step take what was read: a wait before each; mode 8: reads only, no split)
+#define RD(d, o) asm volatile("ds_read_b128 %0, %1 offset:" #o : "=v"(d) : "v"(lp))
+#define MFA(x) { bf16x8 xa = __builtin_bit_cast(bf16x8, x); asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(xa), "v"(b)); }
+            if (MODE == 7) { asm volatile("s_waitcnt lgkmcnt(3)"); MFA(d0); } else MF;
+            RD(d0, 0); if (MODE != 8) { CVT(h01, x0, x1); CVT(h23, x2, x3); SHL(t0_, h01); AND(t1_, h01); }
+            if (MODE == 7) { asm volatile("s_waitcnt lgkmcnt(3)"); MFA(d1); } else MF;
+            RD(d1, 4096); if (MODE != 8) { SHL(t2_, h23); AND(t3_, h23); SUB(r0, x0, t0_); SUB(r1, x1, t1_); }
+            if (MODE == 7) { asm volatile("s_waitcnt lgkmcnt(3)"); MFA(d2); } else MF;
+            RD(d2, 8192); if (MODE != 8) { SUB(r2, x2, t2_); SUB(r3, x3, t3_); CVT(m01, r0, r1); CVT(m23, r2, r3); }
+            if (MODE == 7) { asm volatile("s_waitcnt lgkmcnt(3)"); MFA(d3); } else MF;
+            RD(d3, 12288); if (MODE != 8) { SHL(t0_, m01); AND(t1_, m01); SHL(t2_, m23); AND(t3_, m23); }
+            MF; if (MODE != 8) { SUB(r0, r0, t0_); SUB(r1, r1, t1_); SUB(r2, r2, t2_); SUB(r3, r3, t3_); }
+            MF; if (MODE != 8) { CVT(l01, r0, r1); CVT(l23, r2, r3); }
+        }
+        if (MODE == 9 || MODE == 10) {
+            // the split with its subtractions as v_pk_add_f32 (two values per instruction): 18 instead of 22 instructions
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#define PKSUB(d, x, y) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y))
+            f2 xa = {x0, x1}, xb = {x2, x3}, ta, tb, ra, rb;
+            uint32_t ua0, ua1, ub0, ub1;
+            MF; CVT(h01, xa.x, xa.y); CVT(h23, xb.x, xb.y); SHL(ua0, h01); AND(ua1, h01);
+            MF; SHL(ub0, h23); AND(ub1, h23); ta = f2{__builtin_bit_cast(float, ua0), __builtin_bit_cast(float, ua1)}; PKSUB(ra, xa, ta); tb = f2{__builtin_bit_cast(float, ub0), __builtin_bit_cast(float, ub1)}; PKSUB(rb, xb, tb);
+            MF; CVT(m01, ra.x, ra.y); CVT(m23, rb.x, rb.y); SHL(ua0, m01); AND(ua1, m01);
+            MF; SHL(ub0, m23); AND(ub1, m23); ta = f2{__builtin_bit_cast(float, ua0), __builtin_bit_cast(float, ua1)}; PKSUB(ra, ra, ta); tb = f2{__builtin_bit_cast(float, ub0), __builtin_bit_cast(float, ub1)}; PKSUB(rb, rb, tb);
+            MF; CVT(l01, ra.x, ra.y); CVT(l23, rb.x, rb.y);
+            if (MODE == 10) { SHL(ua0, l01); AND(ua1, l01); SHL(ub0, l23); AND(ub1, l23); }
+            MF;
+            if (MODE == 10) { CVT(L01, x0, x2); CVT(L23, x1, x3); SHL(T0, L01); AND(T1, L01); }
+        }
         if (MODE == 3) {
             MF; CVT(h01, x0, x1); CVT(h23, x2, x3); SHL(t0_, h01); AND(t1_, h01); CVT(H01, y0, y1); CVT(H23, y2, y3); SHL(T0, H01); AND(T1, H01);
             MF; SHL(t2_, h23); AND(t3_, h23); SUB(r0, x0, t0_); SUB(r1, x1, t1_); SHL(T2, H23); AND(T3, H23); SUB(R0, y0, T0); SUB(R1, y1, T1);
@@ -75,7 +106,7 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ in, float* __
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += c[r];
     s += __builtin_bit_cast(float, l01 ^ l23 ^ L01 ^ L23);
-    if (MODE == 4) s += __builtin_bit_cast(float, d0.x ^ d1.y ^ d2.z ^ d3.w);
+    if (MODE == 4 || MODE >= 6) { asm volatile("s_waitcnt lgkmcnt(0)"); s += __builtin_bit_cast(float, d0.x ^ d1.y ^ d2.z ^ d3.w); }
     if (s == 123.456f) out[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -103,5 +134,10 @@ int main() {
     run<3>(in, out, cyc, "+ two splits (44), level order, 8 per gap");
     run<4>(in, out, cyc, "+ one split, 4 per gap, + 4 ds_read_b128 and a wait per step");
     run<5>(in, out, cyc, "+ one split, 4 per gap, next step's B operand from the split");
+    run<8>(in, out, cyc, "six MFMAs + one ds_read_b128 behind each of the first four");
+    run<6>(in, out, cyc, "+ one split, 4 per gap, one ds_read_b128 in each of the first four gaps");
+    run<7>(in, out, cyc, "  same, the next step's MFMAs take the data (wait before each)");
+    run<9>(in, out, cyc, "+ one split with v_pk_add_f32 subtractions (18 instructions), <= 4 per gap");
+    run<10>(in, out, cyc, "  same + 8 more plain instructions in the two light gaps");
     return 0;
 }
