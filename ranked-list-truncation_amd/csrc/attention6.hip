@@ -921,6 +921,9 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         uint4 hvr[2];
 #define GAP_END __builtin_amdgcn_sched_barrier(0)
 #define ATTN6_STAMP DKV1_STAMP
+// (asking for the finished S / dP accumulators in VGPRs here - asm("" : "+v"(sc)) - makes hipcc copy all 16 registers in one
+// burst behind the last MFMA; left to itself it reads each register where its chunk needs it, one v_accvgpr_read per element)
+#define ACC_DONE(w) do { } while (0)
         // LDS read k of step j of X(b) / Y(b) into buffer u (issued one step ahead)
         auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, kh = b & 1;
@@ -1025,6 +1028,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         }
 #undef GAP_END
 #undef ATTN6_STAMP
+#undef ACC_DONE
         DKV1_STAMP(64);
         __syncthreads();
         DKV1_STAMP(65);
@@ -1134,6 +1138,9 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         uint4 hvr[2];
 #define GAP_END __builtin_amdgcn_sched_barrier(0)
 #define ATTN6_STAMP DKV1_STAMP
+// (asking for the finished S / dP accumulators in VGPRs here - asm("" : "+v"(sc)) - makes hipcc copy all 16 registers in one
+// burst behind the last MFMA; left to itself it reads each register where its chunk needs it, one v_accvgpr_read per element)
+#define ACC_DONE(w) do { } while (0)
         auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, qh = b & 1;
             const uint16_t* img = j < 4 ? Kc : Vc;
@@ -1221,6 +1228,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         }
 #undef GAP_END
 #undef ATTN6_STAMP
+#undef ACC_DONE
         DKV1_STAMP(64);
         __syncthreads();
         DKV1_STAMP(65);

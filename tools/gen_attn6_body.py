@@ -221,6 +221,8 @@ for g, (kind, b, j) in enumerate(steps):
     for i in range(6):
         q = 6 * g + i
         line = f"m{kind.lower()}({g % NB}, {i}, {b}, {j}); GAP_END;"
+        if kind == "X" and i == 5 and j in (3, 7):
+            line += f" ACC_DONE({j >> 2});"              # the score (0) / dP (1) accumulator is complete
         if i < nreads(gn):
             k2, b2, j2 = steps[gn]
             line += f" r{k2.lower()}({gn % NB}, {i}, {b2}, {j2});"
