@@ -10,8 +10,10 @@
 // prefetch of the next K tile overlaps the MFMAs of the current one.  blockIdx is remapped so that
 // the tiles an XCD runs are contiguous (they share the A panel in that XCD's L2).
 #include "common.h"
+#include "split6.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -1576,6 +1578,247 @@ int launch_gemm6c(GemmArgs g, int ns, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
+// ======================================================================================================
+// gemm6e: the 256 x 256 six-product tile by ONE wavefront per SIMD (256 threads, 128 x 128 per wavefront: all 256 AGPRs are
+// accumulators).  In gemm6c two wavefronts share a SIMD and the ~250 vector instructions a wavefront spends on the split of the
+// next K tile are not absorbed by its partner's MFMAs (slot timeline in profiles/r04_notes.md: 3,800 cycles for a slot that only
+// multiplies, 5,200 for one that also splits, 3,072 of MFMAs in both).  A bf16 MFMA hides ~4 plain vector instructions of the
+// SAME wavefront when they sit right behind it (tools/micro/mfma_split.hip), so here a slot is one k-step of 16 = 16 groups of
+// six MFMAs per wavefront, each MFMA followed by a gap that carries one part of the split of the k-step two slots ahead (its
+// eight staged pieces: 4 of A, 4 of B per thread), a store + reload, or fragment reads - placed by tools/gen_gemm6e_slot.py,
+// fenced so that hipcc keeps the order.  Three k-step buffers rotate as in gemm6c (same LDS layout, phys6 rows, swizzled
+// 16-byte chunks); slot s multiplies buffer s % 3, writes k-step s + 2 into buffer (s + 2) % 3 (free since the barrier that
+// opened the slot) and reloads the staging registers of its parity with k-step s + 4.  Loads are per k-step (64 bytes of a
+// K-contiguous row per 4 lanes: half lines - the price of a uniform slot).
+template <bool KC>
+__device__ __forceinline__ size_t off6e(int tid, int ld) {           // this thread's element offset inside a k-step of an operand
+    if (KC) return (size_t)phys6(tid >> 2) * ld + 4 * (tid & 3);     // row phys6(t + 64 i) = phys6(t) + 64 i, float4 kq
+    return (size_t)(4 * (tid & 3)) * ld + 4 * (tid >> 2);            // k rows 4 kb + i, columns 4 mb ..
+}
+template <bool KC>
+__device__ __forceinline__ void load6e(const float* __restrict__ P, int ld, int i, float4& v) {   // P: operand + uniform part + off6e
+    v = *reinterpret_cast<const float4*>(P + (size_t)(KC ? 64 * i : i) * ld);
+}
+template <bool KC>
+__device__ __forceinline__ int dst6e(int tid, int p) {               // bf16 element offset of piece p inside the operand's h plane
+    const int x = tid & 3;
+    const int pr = KC ? (tid >> 2) + 64 * p : ((((tid >> 2) * 4) & ~15) | (p << 2) | ((tid >> 2) & 3));
+    return pr * 16 + 8 * ((x >> 1) ^ ((pr >> 3) & 1)) + 4 * (x & 1);
+}
+template <bool KC>
+__device__ __forceinline__ void vals6e(const float4 (&v)[4], int p, float& a, float& b, float& c, float& d) {
+    if (KC) { a = v[p].x; b = v[p].y; c = v[p].z; d = v[p].w; }
+    else {
+        const float* f0 = reinterpret_cast<const float*>(&v[0]);
+        const float* f1 = reinterpret_cast<const float*>(&v[1]);
+        const float* f2 = reinterpret_cast<const float*>(&v[2]);
+        const float* f3 = reinterpret_cast<const float*>(&v[3]);
+        a = f0[p]; b = f1[p]; c = f2[p]; d = f3[p];
+    }
+}
+
+template <bool TA, bool TB, bool PERSIST>
+__global__ __launch_bounds__(256, 1) void gemm6e_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    uint16_t* lds = reinterpret_cast<uint16_t*>(gsm);          // [3][A_h | A_m | A_l | B_h | B_m | B_l]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    int bid, zslab;
+    decode_block(g, bid, zslab);
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    int m0 = tm * BM2, n0 = tn * BN2;
+    const int kbeg = zslab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nks = (kend - kbeg) / 16;              // k-steps per output tile: even, >= 4 (host-checked)
+
+    f32x16 acc[2][2][4];                             // [row half of 64][A block in the half][B block]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][j][r] = 0.f;
+
+    constexpr bool AKC = !TA, BKC = TB;
+    const bool want_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pl = phys6(l31);
+    const int csw = 8 * (hh ^ ((pl >> 3) & 1));
+    const int arow = (wm * 128 + pl) * 16 + csw, brow = 3 * HB6 + (wn * 128 + pl) * 16 + csw;
+    const size_t offA = off6e<AKC>(tid, g.lda), offB = off6e<BKC>(tid, g.ldb);
+    int dA[4], dB[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { dA[p] = dst6e<AKC>(tid, p); dB[p] = 3 * HB6 + dst6e<BKC>(tid, p); }
+
+    int vid = blockIdx.x, nm0 = m0, nn0 = n0;
+    bool has_next = false;
+    auto decode_next = [&]() {
+        const int nwg = g.tiles_m * g.tiles_n;
+        vid += gridDim.x;
+        has_next = PERSIST && vid < nwg;
+        if (has_next) {
+            const int q = nwg >> 3, r = nwg & 7, xcd = vid & 7, jj = vid >> 3;
+            const int nb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jj;
+            const int ntm = nb / g.tiles_n;
+            nm0 = ntm * BM2; nn0 = (nb - ntm * g.tiles_n) * BN2;
+        }
+    };
+    // operand pointers of k-step `ks` of the stream: ks < nks -> this output tile; nks.. -> the next one's (or, at the end of the
+    // stream, a harmless re-read of the last k-step: loads and stores of the slot body are unconditional)
+    auto srcA = [&](int ks) {
+        const bool wrap = PERSIST && has_next && ks >= nks;
+        const int k0 = kbeg + 16 * (wrap ? ks - nks : min(ks, nks - 1)), mm = wrap ? nm0 : m0;
+        return g.A + (AKC ? (size_t)mm * g.lda + k0 : (size_t)k0 * g.lda + mm) + offA;
+    };
+    auto srcB = [&](int ks) {
+        const bool wrap = PERSIST && has_next && ks >= nks;
+        const int k0 = kbeg + 16 * (wrap ? ks - nks : min(ks, nks - 1)), nn = wrap ? nn0 : n0;
+        return g.B + (BKC ? (size_t)nn * g.ldb + k0 : (size_t)k0 * g.ldb + nn) + offB;
+    };
+    float4 ra[2][4], rb[2][4];                       // staged k-steps, by parity
+    auto add_cs = [&](const float4 (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { csum.x += v[i].x; csum.y += v[i].y; csum.z += v[i].z; csum.w += v[i].w; }
+    };
+    auto stash_all = [&](uint16_t* wb, const float4 (&va)[4], const float4 (&vb)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float a, b, c, d;
+            uint2 hi, mid, lo;
+            vals6e<AKC>(va, p, a, b, c, d);
+            split4x3(a, b, c, d, hi, mid, lo);
+            *reinterpret_cast<uint2*>(wb + dA[p]) = hi;
+            *reinterpret_cast<uint2*>(wb + dA[p] + HB6) = mid;
+            *reinterpret_cast<uint2*>(wb + dA[p] + 2 * HB6) = lo;
+            vals6e<BKC>(vb, p, a, b, c, d);
+            split4x3(a, b, c, d, hi, mid, lo);
+            *reinterpret_cast<uint2*>(wb + dB[p]) = hi;
+            *reinterpret_cast<uint2*>(wb + dB[p] + HB6) = mid;
+            *reinterpret_cast<uint2*>(wb + dB[p] + 2 * HB6) = lo;
+        }
+    };
+    bf16x8 a[4][3], b[2][3];
+    auto frag_a = [&](const uint16_t* base, int i, int q) { a[i][q] = *reinterpret_cast<const bf16x8*>(base + arow + q * HB6 + i * 32 * 16); };
+    auto frag_b = [&](const uint16_t* base, int j, int q) { b[j & 1][q] = *reinterpret_cast<const bf16x8*>(base + brow + q * HB6 + j * 32 * 16); };
+
+    // prologue: k-steps 0, 1 -> buffers 0, 1; k-steps 2, 3 in flight; fragments of A blocks 0, 1 and B block 0 of buffer 0
+    {
+        const float* pa = srcA(0); const float* pb = srcB(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load6e<AKC>(pa, g.lda, i, ra[0][i]); load6e<BKC>(pb, g.ldb, i, rb[0][i]); }
+        pa = srcA(1); pb = srcB(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load6e<AKC>(pa, g.lda, i, ra[1][i]); load6e<BKC>(pb, g.ldb, i, rb[1][i]); }
+        if (want_cs) { add_cs(ra[0]); add_cs(ra[1]); }
+        stash_all(lds, ra[0], rb[0]);
+        stash_all(lds + KB6, ra[1], rb[1]);
+        if (PERSIST) decode_next();
+        pa = srcA(2); pb = srcB(2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load6e<AKC>(pa, g.lda, i, ra[0][i]); load6e<BKC>(pb, g.ldb, i, rb[0][i]); }
+        pa = srcA(3); pb = srcB(3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load6e<AKC>(pa, g.lda, i, ra[1][i]); load6e<BKC>(pb, g.ldb, i, rb[1][i]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { frag_a(lds, 0, q); frag_a(lds, 1, q); frag_b(lds, 0, q); }
+
+    // one slot (parity PAR of its k-step index s): multiplies buffer `buf`, writes k-step s + 2 (staged set PAR) into `wbuf`,
+    // reloads the set from (pa, pb) = k-step s + 4, reads the first fragments of the next slot out of `nbuf`
+    auto slot = [&](auto par_tag, int buf, int wbuf, int nbuf, const float* pa, const float* pb) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const uint16_t* base = lds + buf * KB6;
+        const uint16_t* nbase = lds + nbuf * KB6;
+        uint16_t* wb = lds + wbuf * KB6;
+        Split6 su;
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+#define MM(i_, j_, k_) acc[(i_) >> 1][(i_) & 1][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
+            a[i_][(k_) == 0 || (k_) == 3 ? 1 : (k_) == 1 ? 2 : 0], b[(j_) & 1][(k_) == 0 || (k_) == 4 ? 1 : (k_) == 2 ? 2 : 0], acc[(i_) >> 1][(i_) & 1][j_], 0, 0, 0)
+#define SP(p_, k_) do { float x0_, x1_, x2_, x3_; \
+            if ((p_) < 4) vals6e<AKC>(ra[PAR], (p_) & 3, x0_, x1_, x2_, x3_); else vals6e<BKC>(rb[PAR], (p_) & 3, x0_, x1_, x2_, x3_); \
+            split6_part(su, x0_, x1_, x2_, x3_, k_); } while (0)
+#define ST(p_) do { const int d_ = (p_) < 4 ? dA[(p_) & 3] : dB[(p_) & 3]; \
+            *reinterpret_cast<uint2*>(wb + d_) = su.hi; *reinterpret_cast<uint2*>(wb + d_ + HB6) = su.mid; \
+            *reinterpret_cast<uint2*>(wb + d_ + 2 * HB6) = su.lo; \
+            if ((p_) < 4) { if (AKC) load6e<AKC>(pa, g.lda, (p_) & 3, ra[PAR][(p_) & 3]); \
+                            else if ((p_) == 3) { for (int i_ = 0; i_ < 4; ++i_) load6e<AKC>(pa, g.lda, i_, ra[PAR][i_]); } } \
+            else { if (BKC) load6e<BKC>(pb, g.ldb, (p_) & 3, rb[PAR][(p_) & 3]); \
+                   else if ((p_) == 7) { for (int i_ = 0; i_ < 4; ++i_) load6e<BKC>(pb, g.ldb, i_, rb[PAR][i_]); } } } while (0)
+#define RA(i_, q_, n_) frag_a((n_) ? nbase : base, i_, q_)
+#define RB(j_, q_, n_) frag_b((n_) ? nbase : base, j_, q_)
+#include "gemm6e_slot.inc"
+#undef GAP_END
+#undef MM
+#undef SP
+#undef ST
+#undef RA
+#undef RB
+    };
+
+    int u = 0;                                       // buffer of the slot's k-step
+    while (true) {
+        for (int s = 0; s < nks; s += 2) {
+            const int u1 = u == 2 ? 0 : u + 1, u2 = u1 == 2 ? 0 : u1 + 1;
+            if (want_cs && s + 2 < nks) add_cs(ra[0]);
+            slot(std::integral_constant<int, 0>{}, u, u2, u1, srcA(s + 4), srcB(s + 4));
+            __syncthreads();
+            if (want_cs && s + 3 < nks) add_cs(ra[1]);
+            slot(std::integral_constant<int, 1>{}, u1, u, u2, srcA(s + 5), srcB(s + 5));
+            __syncthreads();
+            u = u2;
+        }
+        write_output_t<4>(g, acc[0], m0 + wm * 128, n0 + wn * 128, true, l31, hh, zslab);
+        write_output_t<4>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 128, true, l31, hh, zslab);
+        if (!PERSIST || !has_next) break;
+        m0 = nm0; n0 = nn0;
+        decode_next();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][j][r] = 0.f;
+    }
+    if (want_cs) {          // threads 4 mb + kb (kb < 4) hold partial sums of columns 4 mb .. 4 mb + 3
+        float4* red = reinterpret_cast<float4*>(gsm);
+        __syncthreads();
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[4 * tid];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const float4 o = red[4 * tid + j];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            float* dst = (g.cs_slab ? g.cs_slab + (size_t)zslab * g.M : g.colsum) + m0 + 4 * tid;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+template <bool TA, bool TB>
+int launch_gemm6e(GemmArgs g, int ns, hipStream_t st) {
+    const size_t shm = (size_t)3 * KB6 * sizeof(uint16_t);
+    g.tiles_m = g.M / BM2; g.tiles_n = g.N / BN2;
+    if constexpr (!TA) {
+        static const int persist_wgs = [] { const char* e = getenv("RLT_GEMM6_PERSIST"); return e ? atoi(e) : 256; }();   // 0: off
+        const long long tiles = (long long)g.tiles_m * g.tiles_n;
+        if (persist_wgs > 0 && ns == 1 && tiles > persist_wgs && persist_wgs % 8 == 0) {
+            int rc = rlt_allow_lds(gemm6e_kernel<TA, TB, true>, shm);
+            if (rc) return rc;
+            hipLaunchKernelGGL((gemm6e_kernel<TA, TB, true>), dim3(persist_wgs), dim3(256), shm, st, g);
+            return RLT_LAUNCH_RESULT();
+        }
+    }
+    int rc = rlt_allow_lds(gemm6e_kernel<TA, TB, false>, shm);
+    if (rc) return rc;
+    dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
+    hipLaunchKernelGGL((gemm6e_kernel<TA, TB, false>), grid, dim3(256), shm, st, g);
+    return RLT_LAUNCH_RESULT();
+}
+
 // the bf16x6 tile needs M % 256 == 0, N % 128 == 0, whole 32-wide K tiles per slab and the branch-free loader
 // preconditions; other shapes of that mode run on the exact f32 MFMA kernel (more exact still)
 bool gemm6_ok(const GemmArgs& g) {
@@ -1870,7 +2113,14 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only && !x6_no_c && g.kchunk / BK3 >= 2 &&
         (min(g.K, g.kchunk) / BK3) >= 2 && (g.K % g.kchunk == 0 || (g.K % g.kchunk) / BK3 >= 2)) {
         // (every K slab holds at least two K tiles of 32: the k-step pipeline stages one register tile ahead)
-        if (!ta && tb) rc = launch_gemm6c<false, true>(g, ns, st);
+        static const bool x6_e = [] { const char* e = getenv("RLT_GEMM6E"); return !e || atoi(e) != 0; }();     // RLT_GEMM6E=0 -> gemm6c
+        // gemm6e (one wavefront per SIMD) for the weight-gradient products only (A stored [K][M], K = the 1.2 M rows): its K loop is
+        // ~11 % faster (5.66 against 6.38 ms for 2048 x 256 x 1,228,800), but its epilogue - 256 accumulator registers per lane
+        // through hipcc's register allocation - costs twice gemm6c's, which decides the K = 256 products (4.9 against 2.7 ms)
+        if (x6_e && ta) {
+            if (!tb) rc = launch_gemm6e<true, false>(g, ns, st);
+            else rc = launch_gemm6e<true, true>(g, ns, st);
+        } else if (!ta && tb) rc = launch_gemm6c<false, true>(g, ns, st);
         else if (!ta && !tb) rc = launch_gemm6c<false, false>(g, ns, st);
         else if (ta && !tb) rc = launch_gemm6c<true, false>(g, ns, st);
         else rc = launch_gemm6c<true, true>(g, ns, st);
