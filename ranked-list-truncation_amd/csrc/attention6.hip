@@ -751,6 +751,9 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 //   X(b): S (4 steps) and dP (4 steps) of block b into ONE score / dP accumulator pair;  Y(b): dV, dK of block b (8 steps)
 constexpr int QT1 = 256;
 struct Frag2 { bf16x8 h, m; };
+#ifndef RLT_A6_MLAST
+#define RLT_A6_MLAST 0     // 1: the plane of the first product is read LAST so that one wait covers a step - measured 1 % slower
+#endif
 #ifndef RLT_DKV1_PIN
 #define RLT_DKV1_PIN 1
 #endif
@@ -885,17 +888,20 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             const int sub = b >> 1, kh = b & 1;
             const uint16_t* img = j < 4 ? Qc : Dc;
             const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
-            if (k == 0) afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
-            else if (k == 1) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
-            else if (k == 2) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
-            else klr[u] = klr_base[(kh * 4 + j) * 64];
+            // issue order: the plane the FIRST product takes (m) LAST - LDS reads complete in order, so the one wait in front of
+            // that product covers the whole step (issued m, l, h: a wait before each of the first three products)
+            const int kk = RLT_A6_MLAST ? (j < 4 ? k : k + 1) : (k < 3 ? 3 - k : 0);
+            if (kk == 0) klr[u] = klr_base[(kh * 4 + j) * 64];
+            else if (kk == 1) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
+            else if (kk == 2) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+            else afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
         };
         auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
             const uint16_t* img = which ? Qc : Dc;
             const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
             const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-            const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;                       // m, l, h: the order the six products want them
+            const int pl = RLT_A6_MLAST ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 1 : k < 4 ? 2 : 0);     // h, l, m: the plane of the first product last
             trv[u][pl][k & 1] = tr_read6(img + pl * PL + off + (k & 1) * 8 * LDR);
         };
         auto tl = [&](int b, int c) __attribute__((always_inline)) {
@@ -1101,16 +1107,17 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
             const int sub = b >> 1, qh = b & 1;
             const uint16_t* img = j < 4 ? Kc : Vc;
             const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
-            if (k == 0) afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
-            else if (k == 1) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
-            else if (k == 2) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
-            else qlr[u] = qlr_base[(qh * 4 + j) * 64];
+            const int kk = RLT_A6_MLAST ? (j < 4 ? k : k + 1) : (k < 3 ? 3 - k : 0);     // (m last: see attn6_bwd_dkv1_kernel)
+            if (kk == 0) qlr[u] = qlr_base[(qh * 4 + j) * 64];
+            else if (kk == 1) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
+            else if (kk == 2) afr[u].l = *reinterpret_cast<const bf16x8*>(img + 2 * PL + off);
+            else afr[u].m = *reinterpret_cast<const bf16x8*>(img + PL + off);
         };
         auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, s = j >> 1, dt = j & 1;
             const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
             const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-            const int pl = k < 2 ? 1 : k < 4 ? 2 : 0;
+            const int pl = RLT_A6_MLAST ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 1 : k < 4 ? 2 : 0);
             trv[u][pl][k & 1] = tr_read6(Kc + pl * PL + off + (k & 1) * 8 * LDR);
         };
         auto te = [&](int b, int c) __attribute__((always_inline)) {
