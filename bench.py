@@ -411,6 +411,8 @@ def main():
         if x6_attn:                               # six bf16 MFMA products per fp32 product: peak 2500 / 6
             img_tag = "true" if os.environ.get("RLT_ATTN6_IMG", "0") not in ("", "0") else "false"     # staged from tile images?
             kern, mult, peak = f"attn6_bwd_dkv_kernel<{hd},{drop_tag},{img_tag}>", 6, PEAK_BF16_MFMA_TFLOPS
+            if hd == 64 and os.environ.get("RLT_A6_DKV1", "1") != "0":       # head dim 64: the one-wavefront-per-SIMD form
+                kern = f"attn6_bwd_dkv1_kernel<{drop_tag}>"
         elif mode in ("fp32", "bf16x6"):          # (bf16x6 with RLT_ATTN6=0: the exact-fp32 kernels)
             kern, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 1, PEAK_F32_MFMA_TFLOPS
         else:

@@ -7,11 +7,11 @@
 // The split written one instruction per asm statement in LEVEL order (both conversions, the four unpacks, the four subtractions,
 // ...), as six parts (4, 4, 4, 4, 4, 2 instructions) with its state, for kernels that hand the parts out one per MFMA gap: in
 // that order no instruction sits next to the one it depends on, and the 22 instructions vanish in the shadows of six MFMAs of the
-// same wavefront (tools/micro/mfma_split.hip: 200 cycles per step with and without; 304 as a block behind the MFMAs).  `s_nop 0`
-// behind each conversion pair: hipcc puts one between a v_cvt_pk_bf16_f32 and the use of its result two instructions later in its
-// own schedules, and it does not look into asm statements.
+// same wavefront (tools/micro/mfma_split.hip: 200 cycles per step with and without; 304 as a block behind the MFMAs).  The wait
+// state a v_cvt_pk_bf16_f32 needs before its result is used two instructions later is inserted by hipcc for these asm statements
+// exactly as for its own code (`cvt; cvt; s_nop 0; use` in the ISA): no `s_nop` in the asm text.
 #ifndef RLT_SPLIT6_NOP
-#define RLT_SPLIT6_NOP "\n\ts_nop 0"
+#define RLT_SPLIT6_NOP ""
 #endif
 struct Split6 { uint2 hi, mid, lo; uint32_t t0, t1, t2, t3; float r0, r1, r2, r3; };
 __device__ __forceinline__ void split6_part(Split6& u, float a, float b, float c, float d, int part) {

@@ -36,7 +36,7 @@ def main():
         fetch = one(f"{tag}_pmc_fetch_{mode}/**/p_counter_collection.csv")
         write = one(f"{tag}_pmc_write_{mode}/**/p_counter_collection.csv")
         if fetch and write:
-            dom = {"fp32": "attn_bwd_dkv_kernel", "bf16x3": "attn3_bwd_dkv_kernel", "bf16x6": "attn6_bwd_dkv_kernel"}[mode]
+            dom = {"fp32": "attn_bwd_dkv_kernel", "bf16x3": "attn3_bwd_dkv_kernel", "bf16x6": "attn6_bwd_dkv"}[mode]
             with open(os.path.join(P, f"{tag}_pmc_traffic_{mode}.json"), "w") as f:
                 # steps in the profiled command: 1 warm-up + 2 timed + 3 kernel-timing steps
                 subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), fetch, write, dom,
