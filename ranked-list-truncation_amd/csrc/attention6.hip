@@ -831,8 +831,10 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         const int idx = tid + 256 * i;
         const int row = row0 + idx / (HD / 4), dq_ = idx % (HD / 4);
         // rows beyond B repeat the last row (finite values): their lse entry is +inf, so P = dS = 0 and nothing reaches dK / dV;
-        // no select here - it would wait for the load where it is issued
-        rs.v[i] = *reinterpret_cast<const float4*>(src + (size_t)min(row, B - 1) * lds_ + 4 * dq_);
+        // no select here - it would wait for the load where it is issued.  32-bit element offset from the (uniform) matrix
+        // base: B * ld < 2^24 (host-checked for this kernel), one v_mad_u32_u24 instead of a 64-bit multiply per load
+        const uint32_t off = __umul24((uint32_t)min(row, B - 1), (uint32_t)lds_) + 4u * (uint32_t)dq_;
+        rs.v[i] = *reinterpret_cast<const float4*>(src + off);
     };
     // prologue: tile 0 -> buffer 0; Q of tile 1 -> staging registers, lse / delta of tile 1 -> rl / re
     {
@@ -1063,7 +1065,8 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
     auto load_unit = [&](const float* src, int row0, int i) {
         const int idx = tid + 256 * i;
         const int row = row0 + idx / (HD / 4), dq_ = idx % (HD / 4);
-        rs.v[i] = *reinterpret_cast<const float4*>(src + (size_t)min(row, B - 1) * ld + 4 * dq_);
+        const uint32_t off = __umul24((uint32_t)min(row, B - 1), (uint32_t)ld) + 4u * (uint32_t)dq_;     // (see attn6_bwd_dkv1_kernel)
+        rs.v[i] = *reinterpret_cast<const float4*>(src + off);
     };
     {   // prologue: tile 0 -> buffer 0; K of tile 1 -> staging registers
         Stage6<HD> r0;
@@ -1320,13 +1323,14 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     if constexpr (HD == 64) {                 // dK+dV with one wavefront per SIMD: 256 keys per workgroup, double-buffered tiles
         static const bool dkv1 = [] { const char* e = getenv("RLT_A6_DKV1"); return !e || atoi(e) != 0; }();
         static const bool dq1 = [] { const char* e = getenv("RLT_A6_DQ1"); return !e || atoi(e) != 0; }();
-        if (which == 2 && dq1) {
+        const bool small24 = (long long)a.B * 3 * a.H * HD < (1ll << 24);     // their loaders form B * ld in 24-bit multiplies
+        if (which == 2 && dq1 && small24) {
             const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
             if ((rc = rlt_allow_lds(attn6_bwd_dq1_kernel<DROP>, shm1))) return rc;
             hipLaunchKernelGGL((attn6_bwd_dq1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
             return RLT_LAUNCH_RESULT();
         }
-        if (which == 1 && dkv1) {
+        if (which == 1 && dkv1 && small24) {
             const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * 3 * KT * sizeof(float) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
             if ((rc = rlt_allow_lds(attn6_bwd_dkv1_kernel<DROP>, shm1))) return rc;
             hipLaunchKernelGGL((attn6_bwd_dkv1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
