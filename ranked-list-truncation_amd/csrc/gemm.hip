@@ -1617,6 +1617,42 @@ __device__ __forceinline__ void vals6e(const float4 (&v)[4], int p, float& a, fl
     }
 }
 
+// epilogue of gemm6e for the plain / bias / bias + ReLU / accumulate / split-K-slab outputs (the host sends every other epilogue
+// - 1-bit masks, float masks, dropout - to gemm6c): one loop nest, the accumulator registers read where they are stored
+template <int NJ>
+__device__ __forceinline__ void write_output_simple(const GemmArgs& g, const f32x16 (&acc)[2][NJ], int rbase, int cbase, int l31, int hh, int z) {
+    const bool to_slab = g.slab != nullptr;
+    float* out = to_slab ? g.slab + (size_t)z * g.M * g.N : g.C;
+    const int ldo = to_slab ? g.N : g.ldc;
+    const int rb = __builtin_amdgcn_readfirstlane(rbase), cb = __builtin_amdgcn_readfirstlane(cbase);
+    const int loff = 4 * hh * ldo + l31;
+    const bool relu = !to_slab && (g.flags & RLT_GEMM_RELU), accum = !to_slab && (g.flags & RLT_GEMM_ACCUMULATE);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = cb + j * 32 + l31;
+        float bv = 0.f;
+        if (!to_slab) {
+            if (g.bias) bv += g.bias[col];
+            if (g.bias2) bv += g.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float* base = out + (size_t)(rb + i * 32 + dr) * ldo + (cb + j * 32);       // scalar
+                float v = acc[i][j][r] + bv;
+                if (accum) v += base[loff];
+                if (relu) v = fmaxf(v, 0.f);
+                base[loff] = v;
+            }
+        }
+    }
+}
+inline bool gemm6e_epilogue_ok(const GemmArgs& g) {
+    return !g.mask && !g.bits_in && !g.bits_out && g.drop_p <= 0.f;
+}
+
 template <bool TA, bool TB, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void gemm6e_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -1769,8 +1805,8 @@ __global__ __launch_bounds__(256, 1) void gemm6e_kernel(GemmArgs g) {
             __syncthreads();
             u = u2;
         }
-        write_output_t<4>(g, acc[0], m0 + wm * 128, n0 + wn * 128, true, l31, hh, zslab);
-        write_output_t<4>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 128, true, l31, hh, zslab);
+        write_output_simple<4>(g, acc[0], m0 + wm * 128, n0 + wn * 128, l31, hh, zslab);
+        write_output_simple<4>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 128, l31, hh, zslab);
         if (!PERSIST || !has_next) break;
         m0 = nm0; n0 = nn0;
         decode_next();
@@ -2114,11 +2150,15 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
         (min(g.K, g.kchunk) / BK3) >= 2 && (g.K % g.kchunk == 0 || (g.K % g.kchunk) / BK3 >= 2)) {
         // (every K slab holds at least two K tiles of 32: the k-step pipeline stages one register tile ahead)
         static const bool x6_e = [] { const char* e = getenv("RLT_GEMM6E"); return !e || atoi(e) != 0; }();     // RLT_GEMM6E=0 -> gemm6c
-        // gemm6e (one wavefront per SIMD) for the weight-gradient products only (A stored [K][M], K = the 1.2 M rows): its K loop is
-        // ~11 % faster (5.66 against 6.38 ms for 2048 x 256 x 1,228,800), but its epilogue - 256 accumulator registers per lane
-        // through hipcc's register allocation - costs twice gemm6c's, which decides the K = 256 products (4.9 against 2.7 ms)
-        if (x6_e && ta) {
-            if (!tb) rc = launch_gemm6e<true, false>(g, ns, st);
+        // gemm6e (one wavefront per SIMD) where the K loop decides - the weight-gradient products (A stored [K][M], K = the 1.2 M
+        // rows: 5.66 against 6.38 ms for 2048 x 256 x 1,228,800) and K >= 1024 (ffn1 dX 5.92 against 6.34 ms, ffn2 forward 5.90 against
+        // 6.04) - and the epilogue is one of its plain forms; the K = 256 products (prologue / epilogue bound: 7.02 against 6.70 ms
+        // for 1,228,800 x 2048 x 256) and the mask / dropout epilogues stay on gemm6c.  RLT_GEMM6E_ALL=1: every shape (A/B switch)
+        static const bool x6_e_all = [] { const char* e = getenv("RLT_GEMM6E_ALL"); return e && atoi(e) != 0; }();
+        if (x6_e && gemm6e_epilogue_ok(g) && (ta || g.K >= 1024 || x6_e_all)) {
+            if (!ta && tb) rc = launch_gemm6e<false, true>(g, ns, st);
+            else if (!ta && !tb) rc = launch_gemm6e<false, false>(g, ns, st);
+            else if (!tb) rc = launch_gemm6e<true, false>(g, ns, st);
             else rc = launch_gemm6e<true, true>(g, ns, st);
         } else if (!ta && tb) rc = launch_gemm6c<false, true>(g, ns, st);
         else if (!ta && !tb) rc = launch_gemm6c<false, false>(g, ns, st);
