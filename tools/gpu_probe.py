@@ -340,7 +340,9 @@ def _attn_ref(qkv, H):          # qkv (B,S,3E) double; attention over axis 0
 @section
 def attention():
     for (B, S, H, HD) in [(5, 7, 4, 64), (63, 5, 4, 64), (130, 3, 2, 64), (200, 2, 4, 64), (5, 9, 8, 16), (70, 4, 8, 16),
-                          (33, 3, 2, 32), (300, 2, 4, 64), (6, 3, 2, 128), (70, 2, 2, 128), (130, 2, 1, 128)]:
+                          (33, 3, 2, 32), (300, 2, 4, 64), (6, 3, 2, 128), (70, 2, 2, 128), (130, 2, 1, 128),
+                          # whole 64-key tiles: the one-wavefront forward kernel of head dim 64 (1, 2, 5 tiles; 320 = a partial workgroup)
+                          (64, 3, 4, 64), (128, 2, 2, 64), (320, 2, 4, 64)]:
         E = H * HD
         qkv = torch.randn(B, S, 3 * E)
         dout = torch.randn(B, S, E)
@@ -380,10 +382,10 @@ def attention():
     # the first tile's reference in place while the later weights underflow; a ramp of 6 stays inside the lazy window.  At span 280
     # one fp32 ulp of a score is 3e-5 and the weights of the top keys carry that as a RELATIVE error whatever the kernel does
     # (measured 2.5e-5 .. 6e-5 on the f32 MFMA): that case has the looser bound.
-    for HD in (16, 64):
+    for HD, B in ((16, 300), (64, 300), (64, 320)):      # (320: whole tiles - the one-wavefront forward kernel)
         for tag, span, ftol in (("rising", 40.0, 2e-5), ("steeply rising", 280.0, 2e-4), ("falling", -280.0, 2e-5),
                                 ("inside the window", 6.0, 2e-5)):
-            B, S, H = 300, 2, 2
+            S, H = 2, 2
             E = H * HD
             ramp = torch.linspace(0.0, 1.0, B).view(B, 1, 1)
             q = torch.full((B, S, E), 1.0) + 0.01 * torch.randn(B, S, E)
@@ -397,8 +399,8 @@ def attention():
             qd = _pm(qkv).to(dev).requires_grad_(True)
             od = ops.list_attention(qd, S, B, H)
             od.backward(_pm(dout).to(dev))
-            report(f"attn lazy rescale hd{HD} scores {tag}: fwd", rel(_unpm(od, B, S), orf), mfma_tol(ftol))
-            report(f"attn lazy rescale hd{HD} scores {tag}: dqkv", rel(_unpm(qd.grad, B, S), qr.grad), mfma_tol(5 * ftol))
+            report(f"attn lazy rescale hd{HD} B{B} scores {tag}: fwd", rel(_unpm(od, B, S), orf), mfma_tol(ftol))
+            report(f"attn lazy rescale hd{HD} B{B} scores {tag}: dqkv", rel(_unpm(qd.grad, B, S), qr.grad), mfma_tol(5 * ftol))
 
 
 @section
@@ -627,7 +629,7 @@ def dropout():
     for nm, a, bref in zip(("dx", "dw1", "db1", "dw2", "db2"), devs, refs):
         report(f"drop ffn {nm}", rel(a.grad, bref.grad), mfma_tol(3e-5))
     # attention-probability dropout
-    for (B, S, H, HD) in [(70, 3, 2, 64), (40, 2, 4, 16)]:
+    for (B, S, H, HD) in [(70, 3, 2, 64), (40, 2, 4, 16), (192, 2, 2, 64)]:      # (192: whole tiles - the one-wavefront forward)
         E = H * HD
         qkv = torch.randn(B, S, 3 * E)
         dout = torch.randn(B, S, E)
