@@ -754,6 +754,9 @@ struct Frag2 { bf16x8 h, m; };
 #ifndef RLT_A6_MLAST
 #define RLT_A6_MLAST 0     // 1: the plane of the first product is read LAST so that one wait covers a step - measured 1 % slower
 #endif
+#ifndef RLT_A6_ACCV
+#define RLT_A6_ACCV 1      // S / dP products of the one-wavefront kernels as asm MFMAs with VGPR accumulators (0: builtins, A/B switch)
+#endif
 #ifndef RLT_DKV1_PIN
 #define RLT_DKV1_PIN 1
 #endif
@@ -870,6 +873,14 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             asm volatile("" : "+a"(dk[i >> 1][i & 1]));
             asm volatile("" : "+a"(dv[i >> 1][i & 1]));
         }
+#if RLT_A6_ACCV
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            asm volatile("" : "+a"(kf[i >> 2][i & 3].h));
+            asm volatile("" : "+a"(kf[i >> 2][i & 3].m));
+            asm volatile("" : "+a"(vf[i >> 2][i & 3].h));
+        }
+#endif
 #endif
         f32x16 sc, dp;                               // S / dP accumulators of the block in its X phase
         float pv[16], gv[16];                        // P (dropped) and dS of the block whose splits are under way
@@ -914,20 +925,39 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(Tc) + 2 * KT + (b >> 1) * 32 + 8 * c + 4 * hh);
         };
         // product i of a step: (a.m, b.m), (a.l, b.h), (a.h, b.l), (a.m, b.h), (a.h, b.m), (a.h, b.h); planes 0 h, 1 m, 2 l
-        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
-            const int kh = b & 1;
-            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
+        // The S / dP products as asm statements: accumulator in VGPRs (the element-wise chunks read it there - as a builtin hipcc
+        // puts it into AGPRs and every element costs a v_accvgpr_read), the K fragments and the h plane of V in AGPRs ("a": their
+        // only uses, pinned at the loop top; with dK / dV that is 224 of the 256).  hipcc does not see an MFMA in the asm and
+        // inserts no wait states for it: the accumulator is first read ACC_LAG = 3 gaps (3 MFMAs + their chunks: > 11 wait
+        // states) behind the last product (tools/gen_attn6_body.py); a product never follows a vector write of its operands
+        // (fragments come from LDS / the setup).
+        auto mfma_v = [&](f32x16& c, bf16x8 av, bf16x8 bv, bool zero, bool b_agpr) __attribute__((always_inline)) {
+#if !RLT_A6_ACCV
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero ? z : c, 0, 0, 0);
+            return;
+#endif
+            if (zero) {
+                if (b_agpr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(av), "a"(bv));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(av), "v"(bv));
+            } else {
+                if (b_agpr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "a"(bv));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+            }
+        };
+        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int kh = b & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
             const bf16x8 av = ap == 0 ? afr[u].h : ap == 1 ? afr[u].m : afr[u].l;
             if (j < 4) {
-                const bf16x8 bv = bp == 0 ? kf[kh][j].h : bp == 1 ? kf[kh][j].m : __builtin_bit_cast(bf16x8, klr[u]);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
+                if (bp == 2) mfma_v(sc, av, __builtin_bit_cast(bf16x8, klr[u]), false, false);
+                else mfma_v(sc, av, bp == 0 ? kf[kh][j].h : kf[kh][j].m, j == 0 && i == 0, true);
             } else {
                 const Frag3& vv = vf[kh][j - 4];
-                const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
+                if (bp == 0) mfma_v(dp, av, vv.h, false, true);
+                else mfma_v(dp, av, bp == 1 ? vv.m : vv.l, j == 4 && i == 0, false);
             }
         };
         auto my = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
@@ -1093,6 +1123,16 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         const int row_n1 = min(t + 1, nt - 1) * KT, row_n2 = min(t + 2, nt - 1) * KT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(dq[i >> 1][i & 1]));     // (see attn6_bwd_dkv1_kernel)
+#if RLT_A6_ACCV
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {               // the stationary fragments live in AGPRs (their only uses are "a" operands)
+            asm volatile("" : "+a"(qf[i >> 2][i & 3].h));
+            asm volatile("" : "+a"(qf[i >> 2][i & 3].m));
+            asm volatile("" : "+a"(dof[i >> 2][i & 3].h));
+            asm volatile("" : "+a"(dof[i >> 2][i & 3].m));
+            asm volatile("" : "+a"(dof[i >> 2][i & 3].l));
+        }
+#endif
         f32x16 sc, dp;                               // S^T / dP^T accumulators of the block in its X phase
         float pv[16], gv[16];                        // P and dS^T of the block whose element-wise work / splits are under way
         Split6 st[2][2][2];                          // [1][k-step][half]: the split units of dS^T (state and result)
@@ -1126,20 +1166,37 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         auto te = [&](int b, int c) __attribute__((always_inline)) {
             if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
         };
-        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
-            const int qh = b & 1;
-            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
+        // The S^T / dP^T products as asm statements: accumulator in VGPRs (the element-wise chunks read it there - as a builtin
+        // hipcc puts it into AGPRs and every element costs a v_accvgpr_read), stationary fragments in AGPRs ("a": the only uses of
+        // qf / dof, so they live there).  hipcc does not see an MFMA in the asm and inserts no wait states for it: the
+        // accumulator is first read RLT_A6_ACC_LAG gaps (>= 3 MFMAs + their chunks: > 11 wait states) behind the last product
+        // (tools/gen_attn6_body.py), a product never follows a vector write of its operands (fragments come from LDS / setup).
+        auto mfma_v = [&](f32x16& c, bf16x8 av, bf16x8 bv, bool zero, bool b_agpr) __attribute__((always_inline)) {
+#if !RLT_A6_ACCV
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero ? z : c, 0, 0, 0);
+            return;
+#endif
+            if (zero) {
+                if (b_agpr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(av), "a"(bv));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(av), "v"(bv));
+            } else {
+                if (b_agpr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "a"(bv));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+            }
+        };
+        auto mx = [&](int u, int i, int b, int j) __attribute__((always_inline)) {
+            const int qh = b & 1;
+            const int ap = i == 0 || i == 3 ? 1 : i == 1 ? 2 : 0, bp = i == 0 || i == 4 ? 1 : i == 2 ? 2 : 0;
             const bf16x8 av = ap == 0 ? afr[u].h : ap == 1 ? afr[u].m : afr[u].l;
             if (j < 4) {
-                const bf16x8 bv = bp == 0 ? qf[qh][j].h : bp == 1 ? qf[qh][j].m : __builtin_bit_cast(bf16x8, qlr[u]);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 0 && i == 0) ? z : sc, 0, 0, 0);
+                if (bp == 2) mfma_v(sc, av, __builtin_bit_cast(bf16x8, qlr[u]), false, false);
+                else mfma_v(sc, av, bp == 0 ? qf[qh][j].h : qf[qh][j].m, j == 0 && i == 0, true);
             } else {
                 const Frag3& vv = dof[qh][j - 4];
-                const bf16x8 bv = bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l;
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, (j == 4 && i == 0) ? z : dp, 0, 0, 0);
+                mfma_v(dp, av, bp == 0 ? vv.h : bp == 1 ? vv.m : vv.l, j == 4 && i == 0, true);
             }
         };
         auto my = [&](int u, int i, int b, int j) __attribute__((always_inline)) {

@@ -72,7 +72,7 @@ class Task:
 
 
 tasks = []
-ACC_LAG = 2                              # gaps between the last MFMA of a product and the first read of its accumulator
+ACC_LAG = 3                              # gaps between the last MFMA of a product and the first read of its accumulator (>= 11 wait states: the asm MFMAs of the dQ kernel)
 ea, eb, spl = {}, {}, {}
 for b in range(4):
     x0 = xstart[b]
