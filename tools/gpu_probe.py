@@ -1988,9 +1988,11 @@ def trainer_dp_mt(which=None):
 @section
 def x6_image_staging():
     """The bf16x6 attention kernels staged from pre-split tile images (RLT_ATTN6_IMG=1: a prepare pass per call, LDS-DMA in the
-    kernels; off by default, the switch is read once per process): the op-level attention sections in a child process."""
+    kernels; off by default, the switch is read once per process): the op-level attention sections in a child process - with the
+    two-workgroup backward kernels at head dim 64 (RLT_A6_DKV1=0, RLT_A6_DQ1=0: the forms the one-wavefront kernels replaced by
+    default, still the path for inputs whose B * ld exceeds their 24-bit row offsets)."""
     import subprocess
-    env = dict(os.environ, RLT_ATTN6_IMG="1", RLT_PRECISION="bf16x6")
+    env = dict(os.environ, RLT_ATTN6_IMG="1", RLT_PRECISION="bf16x6", RLT_A6_DKV1="0", RLT_A6_DQ1="0")
     res = subprocess.run([sys.executable, os.path.abspath(__file__), "attention", "scale_ops"], env=env, capture_output=True, text=True,
                          timeout=900)
     report("x6_image_staging: child exit status", float(res.returncode), 0)
