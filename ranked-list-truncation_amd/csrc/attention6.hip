@@ -1446,5 +1446,9 @@ int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st) {
     const bool drop = a.drop_p > 0.f;
     if (HD == 64) return drop ? attn6_dispatch<64, true>(which, a, st) : attn6_dispatch<64, false>(which, a, st);
     if (HD == 32) return drop ? attn6_dispatch<32, true>(which, a, st) : attn6_dispatch<32, false>(which, a, st);
+    // head dim 16: the 16x16x32 kernels of attention6n.hip (RLT_A6N=0: the 32x32x16 kernels of this file, A/B runs; the
+    // pre-split-image staging exists in this file only)
+    static const bool a6n = [] { const char* e = getenv("RLT_A6N"); return !e || atoi(e) != 0; }();
+    if (a6n && which < 3 && !(a.img != nullptr && (which != 1 || a.dimg != nullptr))) return rlt_attn6n_run(which, a, st);
     return drop ? attn6_dispatch<16, true>(which, a, st) : attn6_dispatch<16, false>(which, a, st);
 }

@@ -1,0 +1,583 @@
+// List-axis attention at head dim 16 (Choopy / MtChoopy: d_model 128, 8 heads - reference models/Choopy.py:7,11-12,19-21;
+// BASELINE configs[2]: 8192 lists x 300), fp32-FAITHFUL six-product arithmetic ("bf16x6", see attention6.hip) on the NARROW bf16
+// MFMA, v_mfma_f32_16x16x32_bf16.  Same interface, same algorithm (flash-style, scores produced with the wavefront's own rows on
+// the lanes, deterministic, no atomics) and the same fp32 softmax arithmetic as attention6.hip; what changes is how the products
+// map onto the matrix pipe, because at head dim 16 the 32x32x16 kernels pay for padding and for the vector ALU:
+//
+//  1. No padded axis.  A d-indexed OUTPUT (P.V, dV, dK, dQ) on the 32-row MFMA is half padding at d = 16; the 16-row MFMA has
+//     none (6 instead of 12 MFMA-equivalents per 32 x 32 block and product).
+//  2. Plane PAIRS in the contraction.  A d-CONTRACTED product (S = Q K^T, dP = dO V^T) has K = 16, the 16x16x32 MFMA K = 32: two
+//     of the six plane products share one MFMA - A = [a_m | a_l], B = [b_m ; b_h] gives a_m b_m + a_l b_h, [a_h | a_m] x [b_l ; b_h]
+//     gives a_h b_l + a_m b_h, [a_h | a_h] x [b_m ; b_h] gives a_h b_m + a_h b_h: three full MFMAs per 16 x 16 tile, smallest terms
+//     first as before.  The pairing costs nothing at staging time: lane group g = lane >> 4 simply reads plane (g < 2 ? X : Y).
+//  3. The three-way split of the FRESH operand (P, dS: one per score) on the matrix pipe.  x = h + m + l needs, per value, a
+//     conversion, an unpack and a subtraction per level in vector code (5.5 instructions: what bounds the 32x32x16 kernels at
+//     this head dim).  But the packed h of two 16 x 16 score tiles IS already the B operand of the next product, so the
+//     residual comes from an MFMA: R1 = X - SEL h, with SEL a constant selection matrix of -1.0 entries (C = X, A = SEL, B = h).
+//     fp32 accumulation of one exact bf16 product into X is exact (the difference is representable), so h, m, l are BIT-IDENTICAL
+//     to the vector split (tools/micro/mfma_resid.hip: 0 mismatches over every exponent, exp2 weights, denormals, worst-split).
+//     1.5 vector instructions per value (three v_cvt_pk_bf16_f32 per pair) + four 16-cycle MFMAs per 512 values.
+//
+// Tile images: [plane h | m | l][64 rows][16 d] bf16, 32-byte rows, unpadded (row reads as ds_read_b128 and transposed reads as
+// ds_read_b64_tr_b16 are both conflict-free on it), split once per workgroup at staging time, double-buffered (one barrier per
+// tile).  A wavefront owns NB blocks of 16 of its own rows (queries in forward / dQ, keys in dK+dV): fragments of a tile are read
+// once per wavefront and used NB times.  Two 16 x 16 score tiles (keys 16 kb + 4 g + r of lane group g, register r) form one B
+// operand of the next product: k slot (g, j) <-> tile row 16 (j >> 2) + 4 g + (j & 3), and the transposed reads deliver the A
+// operand in exactly that order (block rows 4 g .. 4 g + 3 and + 16).
+#include "attention_common.h"
+#include <stdlib.h>
+
+#ifndef RLT_A6N_NB
+#define RLT_A6N_NB 4        // 16-row blocks owned by a wavefront (forward / dQ)
+#endif
+#ifndef RLT_A6N_NBK
+#define RLT_A6N_NBK 2       // ... in dK+dV (twice the stationary state per block)
+#endif
+#ifndef RLT_A6N_OCC
+#define RLT_A6N_OCC 2       // wavefronts per SIMD the register budget is declared for
+#endif
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+constexpr int PLN = KT * 16;          // bf16 elements per plane of a tile image
+constexpr int IMGN = 3 * PLN;         // ... per image (h | m | l): 6 KiB
+
+__device__ __forceinline__ uint32_t pk2n(float a, float b) {
+    // the cast form: hipcc emits v_cvt_pk_bf16_f32 and inserts the wait states an MFMA needs behind a vector write of its operand
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ float lo16(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi16(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ f32x4 mm(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d)); }
+
+// exact three-way split in vector code (staging and the stationary fragments only): four values -> three packed pairs
+__device__ __forceinline__ void split4v(float a, float b, float c, float d, uint2& h, uint2& m, uint2& l) {
+    h.x = pk2n(a, b); h.y = pk2n(c, d);
+    const float ra = a - lo16(h.x), rb = b - hi16(h.x), rc = c - lo16(h.y), rd = d - hi16(h.y);
+    m.x = pk2n(ra, rb); m.y = pk2n(rc, rd);
+    l.x = pk2n(ra - lo16(m.x), rb - hi16(m.x)); l.y = pk2n(rc - lo16(m.y), rd - hi16(m.y));
+}
+
+struct Planes { bf16x8 h, m, l; };
+// ... of two 16 x 16 accumulator tiles on the matrix pipe (see the header): sel0 / sel1 select the tile
+__device__ __forceinline__ bf16x8 pack8(const f32x4& t0, const f32x4& t1) {
+    return frag4(pk2n(t0[0], t0[1]), pk2n(t0[2], t0[3]), pk2n(t1[0], t1[1]), pk2n(t1[2], t1[3]));
+}
+__device__ __forceinline__ Planes split_mx(f32x4 t0, f32x4 t1, bf16x8 sel0, bf16x8 sel1) {
+    Planes p;
+    p.h = pack8(t0, t1);
+    t0 = mm(sel0, p.h, t0); t1 = mm(sel1, p.h, t1);
+    p.m = pack8(t0, t1);
+    t0 = mm(sel0, p.m, t0); t1 = mm(sel1, p.m, t1);
+    p.l = pack8(t0, t1);
+    return p;
+}
+// acc += A^T-image planes x fresh planes: the six products, smallest first
+__device__ __forceinline__ f32x4 mm6(const Planes& a, const Planes& b, f32x4 c) {
+    c = mm(a.m, b.m, c);
+    c = mm(a.l, b.h, c);
+    c = mm(a.h, b.l, c);
+    c = mm(a.m, b.h, c);
+    c = mm(a.h, b.m, c);
+    return mm(a.h, b.h, c);
+}
+
+// per-lane constants
+struct LaneN {
+    int l15, g;
+    int offA, offB, offC;     // element offsets of the three row-fragment reads of a 16-row block: [m|l], [h|m], [h|h]
+    int offT;                 // ... of the transposed reads of a 32-row block (plane 0, first half)
+    bf16x8 sel0, sel1;        // selection operands of the matrix-pipe split
+};
+__device__ __forceinline__ LaneN lane_consts(int lane) {
+    LaneN c;
+    c.l15 = lane & 15; c.g = lane >> 4;
+    const int ro = c.l15 * 16 + 8 * (c.g & 1);
+    c.offA = (c.g < 2 ? 1 : 2) * PLN + ro;
+    c.offB = (c.g < 2 ? 0 : 1) * PLN + ro;
+    c.offC = ro;
+    c.offT = (4 * c.g + (c.l15 >> 2)) * 16 + 4 * (c.l15 & 3);
+    uint32_t s0[4] = {0u, 0u, 0u, 0u};
+    if ((c.l15 >> 2) == c.g) s0[(c.l15 & 3) >> 1] = (c.l15 & 1) ? 0xBF800000u : 0x0000BF80u;     // -1.0 at element l15 & 3
+    c.sel0 = frag4(s0[0], s0[1], 0u, 0u);
+    c.sel1 = frag4(0u, 0u, s0[0], s0[1]);
+    return c;
+}
+
+// the wavefront's own row as the stationary B fragments of the row products: bmh = [x_m ; x_h], blh = [x_l ; x_h]
+__device__ __forceinline__ void own_frags(const float* __restrict__ rowp, const LaneN& c, float mul, bf16x8& bmh, bf16x8& blh) {
+    const float4 v0 = *reinterpret_cast<const float4*>(rowp + 8 * (c.g & 1));
+    const float4 v1 = *reinterpret_cast<const float4*>(rowp + 8 * (c.g & 1) + 4);
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4v(v0.x * mul, v0.y * mul, v0.z * mul, v0.w * mul, h0, m0, l0);
+    split4v(v1.x * mul, v1.y * mul, v1.z * mul, v1.w * mul, h1, m1, l1);
+    const bool lo = c.g < 2;
+    bmh = frag4(lo ? m0.x : h0.x, lo ? m0.y : h0.y, lo ? m1.x : h1.x, lo ? m1.y : h1.y);
+    blh = frag4(lo ? l0.x : h0.x, lo ? l0.y : h0.y, lo ? l1.x : h1.x, lo ? l1.y : h1.y);
+}
+
+// row fragments of the 16-row block `blk` of an image
+struct RowFr { bf16x8 a, b, c; };
+__device__ __forceinline__ RowFr row_fr(const uint16_t* __restrict__ img, int blk, const LaneN& c) {
+    RowFr f;
+    f.a = *reinterpret_cast<const bf16x8*>(img + c.offA + blk * 256);
+    f.b = *reinterpret_cast<const bf16x8*>(img + c.offB + blk * 256);
+    f.c = *reinterpret_cast<const bf16x8*>(img + c.offC + blk * 256);
+    return f;
+}
+// tile[row = block row][col = lane] = sum_d image[row][d] * own[col][d]
+__device__ __forceinline__ f32x4 row_prod(const RowFr& f, bf16x8 bmh, bf16x8 blh, f32x4 c) {
+    c = mm(f.a, bmh, c);
+    c = mm(f.b, blh, c);
+    return mm(f.c, bmh, c);
+}
+// transposed fragments of the 32-row block `b32` of an image (A[d][k slot])
+__device__ __forceinline__ bf16x8 tr_pair(const uint16_t* p) {
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+    const v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 256));
+    const v8s v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ Planes tr_fr(const uint16_t* __restrict__ img, int b32, const LaneN& c) {
+    Planes f;
+    f.h = tr_pair(img + c.offT + b32 * 512);
+    f.m = tr_pair(img + PLN + c.offT + b32 * 512);
+    f.l = tr_pair(img + 2 * PLN + c.offT + b32 * 512);
+    return f;
+}
+
+// staging: one float4 of a [64][16] fp32 tile per thread (row tid >> 2, d 4 (tid & 3)); rows beyond nrows read as zero
+__device__ __forceinline__ float4 stage_ld(const float* __restrict__ base, size_t ld, int row0, int nrows, int tid) {
+    const int row = row0 + (tid >> 2);
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * ld + 4 * (tid & 3));
+    const bool ok = row < nrows;
+    return make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+}
+__device__ __forceinline__ void stage_st(uint16_t* __restrict__ img, int tid, const float4& v) {
+    uint2 h, m, l;
+    split4v(v.x, v.y, v.z, v.w, h, m, l);
+    const int off = (tid >> 2) * 16 + 4 * (tid & 3);
+    *reinterpret_cast<uint2*>(img + off) = h;
+    *reinterpret_cast<uint2*>(img + PLN + off) = m;
+    *reinterpret_cast<uint2*>(img + 2 * PLN + off) = l;
+}
+// max / sum over the four lanes (l & 15) + 16 {0, 1, 2, 3} that share a column
+__device__ __forceinline__ float col_max4(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float col_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NB, bool DROP>
+__global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
+    uint32_t* htab = reinterpret_cast<uint32_t*>(img0 + 4 * IMGN);   // [2][KT] column hashes of the tile's keys (DROP)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const LaneN c = lane_consts(lane);
+    const int B = a.B, H = a.H, E = H * 16;
+    const size_t ld = (size_t)3 * E;
+    constexpr int WROWS = 16 * NB, GROWS = 4 * WROWS;
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, rlt_cdiv_dev(B, GROWS), pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * 16;
+    const int row0 = qt * GROWS + wv * WROWS;
+    const bool wave_live = row0 < B;
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+
+    bf16x8 qmh[NB], qlh[NB];
+    uint32_t hq[NB];
+    f32x4 o[NB];
+    float m_run[NB], l_run[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = row0 + 16 * n + c.l15;
+        own_frags(base + (size_t)min(q, B - 1) * ld, c, a.scale * LOG2E, qmh[n], qlh[n]);
+        hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+        o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[n] = 0.f; l_run[n] = 0.f;          // m_run: the reference of the weights, set by the first block
+    }
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    const int nt = rlt_cdiv_dev(B, KT);
+    float4 rk = stage_ld(base + E, ld, 0, B, tid), rv = stage_ld(base + 2 * E, ld, 0, B, tid);
+    stage_st(img0, tid, rk);
+    stage_st(img0 + IMGN, tid, rv);
+    if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const uint16_t* Ki = img0 + buf * 2 * IMGN;
+        const uint16_t* Vi = Ki + IMGN;
+        if (t + 1 < nt) {
+            rk = stage_ld(base + E, ld, (t + 1) * KT, B, tid);
+            rv = stage_ld(base + 2 * E, ld, (t + 1) * KT, B, tid);
+        }
+        if (wave_live) {
+            const bool tail = (t + 1) * KT > B;
+#pragma unroll
+            for (int b32 = 0; b32 < KT / 32; ++b32) {
+                const RowFr k0 = row_fr(Ki, 2 * b32, c), k1 = row_fr(Ki, 2 * b32 + 1, c);
+                const Planes vt = tr_fr(Vi, b32, c);
+                f32x4 sc[NB][2];                                   // S^T[key][q], log2 domain
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    sc[n][0] = row_prod(k0, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    sc[n][1] = row_prod(k1, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                if (tail) {                                        // last tile only: keys beyond B
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (t * KT + b32 * 32 + kb * 16 + 4 * c.g + r >= B) {
+#pragma unroll
+                                for (int n = 0; n < NB; ++n) sc[n][kb][r] = -INFINITY;
+                            }
+                }
+                // lazy rescaling as in attention16.hip: the weights are exp2(score - m_run) with the reference m_run moving only
+                // when a weight would leave the comfortable fp32 range - the common block has no max search and no cross-lane step
+                f32x4 pe[NB][2];
+                float psum[NB];
+                const bool first = t == 0 && b32 == 0;
+                bool redo = first;
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    psum[n] = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pe[n][kb][r] = rlt_exp2(sc[n][kb][r] - m_run[n]);
+                            psum[n] += pe[n][kb][r];
+                        }
+                    redo |= !(psum[n] <= 4096.f);
+                }
+                if (__any(redo)) {                                 // wave-uniform; rare after the first block
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        float tmax = -INFINITY;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[n][kb][r]);
+                        tmax = col_max4(tmax);
+                        const float m_new = first ? tmax : fmaxf(tmax, m_run[n]);
+                        const float alpha = first ? 0.f : rlt_exp2(m_run[n] - m_new);
+                        psum[n] = 0.f;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                pe[n][kb][r] = rlt_exp2(sc[n][kb][r] - m_new);
+                                psum[n] += pe[n][kb][r];
+                            }
+                        l_run[n] *= alpha;
+                        m_run[n] = m_new;
+                        o[n] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    l_run[n] += psum[n];
+                    if (DROP) {                                    // on the normalised probabilities: the normaliser keeps every key
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            const uint4 hc = *reinterpret_cast<const uint4*>(htab + buf * KT + b32 * 32 + kb * 16 + 4 * c.g);
+                            pe[n][kb][0] = rlt_keep_rc(hq[n], hc.x, a.drop_thr) ? pe[n][kb][0] * inv_keep : 0.f;
+                            pe[n][kb][1] = rlt_keep_rc(hq[n], hc.y, a.drop_thr) ? pe[n][kb][1] * inv_keep : 0.f;
+                            pe[n][kb][2] = rlt_keep_rc(hq[n], hc.z, a.drop_thr) ? pe[n][kb][2] * inv_keep : 0.f;
+                            pe[n][kb][3] = rlt_keep_rc(hq[n], hc.w, a.drop_thr) ? pe[n][kb][3] * inv_keep : 0.f;
+                        }
+                    }
+                    const Planes pp = split_mx(pe[n][0], pe[n][1], c.sel0, c.sel1);
+                    o[n] = mm6(vt, pp, o[n]);                       // O^T[d][q] += V^T P^T
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            stage_st(img0 + (buf ^ 1) * 2 * IMGN, tid, rk);
+            stage_st(img0 + (buf ^ 1) * 2 * IMGN + IMGN, tid, rv);
+            if (DROP && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
+        }
+        __syncthreads();
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const float l_tot = col_sum4(l_run[n]);
+        const int q = row0 + 16 * n + c.l15;
+        if (q < B) {
+            const float inv = 1.f / l_tot;
+            *reinterpret_cast<float4*>(a.o + ((size_t)s * B + q) * E + h * 16 + 4 * c.g) =
+                make_float4(o[n][0] * inv, o[n][1] * inv, o[n][2] * inv, o[n][3] * inv);
+            if (c.g == 0) a.lse_o[((size_t)s * H + h) * B + q] = (m_run[n] + log2f(l_tot)) * LN2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+// Keys beyond B: their K and V rows are staged as zeros, so whatever dS they get multiplies a zero column of K^T.
+template <int NB, bool DROP>
+__global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
+    uint32_t* htab = reinterpret_cast<uint32_t*>(img0 + 4 * IMGN);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const LaneN c = lane_consts(lane);
+    const int B = a.B, H = a.H, E = H * 16;
+    const size_t ld = (size_t)3 * E;
+    constexpr int WROWS = 16 * NB, GROWS = 4 * WROWS;
+    int pair, qt;
+    map_block(blockIdx.x, a.S * H, rlt_cdiv_dev(B, GROWS), pair, qt);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * 16;
+    const int row0 = qt * GROWS + wv * WROWS;
+    const bool wave_live = row0 < B;
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+
+    bf16x8 qmh[NB], qlh[NB], dmh[NB], dlh[NB];
+    float lse2[NB], del[NB];
+    uint32_t hq[NB];
+    f32x4 dq[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = row0 + 16 * n + c.l15, qc = min(q, B - 1);
+        own_frags(base + (size_t)qc * ld, c, a.scale * LOG2E, qmh[n], qlh[n]);
+        own_frags(a.dout + ((size_t)s * B + qc) * E + h * 16, c, 1.f, dmh[n], dlh[n]);
+        lse2[n] = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
+        del[n] = a.delta[((size_t)s * H + h) * B + qc];
+        hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
+        dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    const int nt = rlt_cdiv_dev(B, KT);
+    float4 rk = stage_ld(base + E, ld, 0, B, tid), rv = stage_ld(base + 2 * E, ld, 0, B, tid);
+    stage_st(img0, tid, rk);
+    stage_st(img0 + IMGN, tid, rv);
+    if (DROP && tid < KT) htab[tid] = rlt_col_hash(ps, (uint32_t)tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const uint16_t* Ki = img0 + buf * 2 * IMGN;
+        const uint16_t* Vi = Ki + IMGN;
+        if (t + 1 < nt) {
+            rk = stage_ld(base + E, ld, (t + 1) * KT, B, tid);
+            rv = stage_ld(base + 2 * E, ld, (t + 1) * KT, B, tid);
+        }
+        if (wave_live) {
+#pragma unroll
+            for (int b32 = 0; b32 < KT / 32; ++b32) {
+                const RowFr k0 = row_fr(Ki, 2 * b32, c), k1 = row_fr(Ki, 2 * b32 + 1, c);
+                const RowFr v0 = row_fr(Vi, 2 * b32, c), v1 = row_fr(Vi, 2 * b32 + 1, c);
+                const Planes kt = tr_fr(Ki, b32, c);
+                uint4 hc[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+                if (DROP) {
+                    hc[0] = *reinterpret_cast<const uint4*>(htab + buf * KT + b32 * 32 + 4 * c.g);
+                    hc[1] = *reinterpret_cast<const uint4*>(htab + buf * KT + b32 * 32 + 16 + 4 * c.g);
+                }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    f32x4 sc[2], dp[2];
+                    sc[0] = row_prod(k0, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // S^T[key][q]
+                    sc[1] = row_prod(k1, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    dp[0] = row_prod(v0, dmh[n], dlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // dP^T[key][q]
+                    dp[1] = row_prod(v1, dmh[n], dlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const uint32_t hcs[4] = {hc[kb].x, hc[kb].y, hc[kb].z, hc[kb].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = rlt_exp2(sc[kb][r] - lse2[n]);
+                            float dpr = dp[kb][r];
+                            if (DROP) dpr = rlt_keep_rc(hq[n], hcs[r], a.drop_thr) ? dpr * inv_keep : 0.f;
+                            dp[kb][r] = p * (dpr - del[n]);                          // dS^T
+                        }
+                    }
+                    const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
+                    dq[n] = mm6(kt, ds, dq[n]);                                      // dQ^T[d][q] += K^T dS^T
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            stage_st(img0 + (buf ^ 1) * 2 * IMGN, tid, rk);
+            stage_st(img0 + (buf ^ 1) * 2 * IMGN + IMGN, tid, rv);
+            if (DROP && tid < KT) htab[(buf ^ 1) * KT + tid] = rlt_col_hash(ps, (uint32_t)((t + 1) * KT + tid));
+        }
+        __syncthreads();
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = row0 + 16 * n + c.l15;
+        if (q < B)
+            *reinterpret_cast<float4*>(a.dqkv + ((size_t)s * B + q) * ld + h * 16 + 4 * c.g) =
+                make_float4(dq[n][0] * a.scale, dq[n][1] * a.scale, dq[n][2] * a.scale, dq[n][3] * a.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+// Queries beyond B: their Q / dO rows are staged as zeros and their lse entry is +inf, so P = dS = 0.
+template <int NB, bool DROP>
+__global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][Q image | dO image]
+    float* tab0 = reinterpret_cast<float*>(img0 + 4 * IMGN);      // [2 buffers][lse * log2e | delta | row hashes][KT]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const LaneN c = lane_consts(lane);
+    const int B = a.B, H = a.H, E = H * 16;
+    const size_t ld = (size_t)3 * E;
+    constexpr int WROWS = 16 * NB, GROWS = 4 * WROWS;
+    int pair, ktile;
+    map_block(blockIdx.x, a.S * H, rlt_cdiv_dev(B, GROWS), pair, ktile);
+    const int s = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s * B * ld + h * 16;
+    const float* dobase = a.dout + (size_t)s * B * E + h * 16;
+    const float* lsebase = a.lse + ((size_t)s * H + h) * B;
+    const float* delbase = a.delta + ((size_t)s * H + h) * B;
+    const int row0 = ktile * GROWS + wv * WROWS;
+    const bool wave_live = row0 < B;
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+
+    bf16x8 kmh[NB], klh[NB], vmh[NB], vlh[NB];
+    uint32_t hk[NB];
+    f32x4 dk[NB], dv[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int key = row0 + 16 * n + c.l15, kc = min(key, B - 1);
+        own_frags(base + (size_t)kc * ld + E, c, a.scale * LOG2E, kmh[n], klh[n]);
+        own_frags(base + (size_t)kc * ld + 2 * E, c, 1.f, vmh[n], vlh[n]);
+        hk[n] = DROP ? rlt_col_hash(ps, (uint32_t)key) : 0u;
+        dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    const int nt = rlt_cdiv_dev(B, KT);
+    float4 rq, rd;
+    float rl = 0.f, re = 0.f;
+    auto load_tile = [&](int r0) {
+        rq = stage_ld(base, ld, r0, B, tid);
+        rd = stage_ld(dobase, (size_t)E, r0, B, tid);
+        if (tid < KT) {
+            const int qi = r0 + tid, qc = min(qi, B - 1);
+            const float l = lsebase[qc], e = delbase[qc];
+            rl = qi < B ? l * LOG2E : INFINITY;
+            re = qi < B ? e : 0.f;
+        }
+    };
+    auto store_tile = [&](int b, int r0) {
+        stage_st(img0 + b * 2 * IMGN, tid, rq);
+        stage_st(img0 + b * 2 * IMGN + IMGN, tid, rd);
+        if (tid < KT) {
+            float* tb = tab0 + b * 3 * KT;
+            tb[tid] = rl; tb[KT + tid] = re;
+            if (DROP) reinterpret_cast<uint32_t*>(tb)[2 * KT + tid] = rlt_row_hash(ps, (uint32_t)(r0 + tid));
+        }
+    };
+    load_tile(0);
+    store_tile(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const uint16_t* Qi = img0 + buf * 2 * IMGN;
+        const uint16_t* Di = Qi + IMGN;
+        const float* tb = tab0 + buf * 3 * KT;
+        if (t + 1 < nt) load_tile((t + 1) * KT);
+        if (wave_live) {
+#pragma unroll
+            for (int b32 = 0; b32 < KT / 32; ++b32) {
+                const RowFr q0 = row_fr(Qi, 2 * b32, c), q1 = row_fr(Qi, 2 * b32 + 1, c);
+                const RowFr d0 = row_fr(Di, 2 * b32, c), d1 = row_fr(Di, 2 * b32 + 1, c);
+                const Planes qt_ = tr_fr(Qi, b32, c), dt_ = tr_fr(Di, b32, c);
+                float4 l4[2], e4[2];
+                uint4 hr[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    l4[kb] = *reinterpret_cast<const float4*>(tb + b32 * 32 + kb * 16 + 4 * c.g);
+                    e4[kb] = *reinterpret_cast<const float4*>(tb + KT + b32 * 32 + kb * 16 + 4 * c.g);
+                    if (DROP) hr[kb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(tb) + 2 * KT + b32 * 32 + kb * 16 + 4 * c.g);
+                }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    f32x4 sc[2], dp[2];
+                    sc[0] = row_prod(q0, kmh[n], klh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // S[q][key]
+                    sc[1] = row_prod(q1, kmh[n], klh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    dp[0] = row_prod(d0, vmh[n], vlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[q][key]
+                    dp[1] = row_prod(d1, vmh[n], vlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const float ls[4] = {l4[kb].x, l4[kb].y, l4[kb].z, l4[kb].w};
+                        const float es[4] = {e4[kb].x, e4[kb].y, e4[kb].z, e4[kb].w};
+                        const uint32_t hrs[4] = {hr[kb].x, hr[kb].y, hr[kb].z, hr[kb].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = rlt_exp2(sc[kb][r] - ls[r]);
+                            if (DROP) {
+                                const float m = rlt_keep_rc(hrs[r], hk[n], a.drop_thr) ? inv_keep : 0.f;
+                                sc[kb][r] = p * m;                                   // dropped P (feeds dV)
+                                dp[kb][r] = p * (dp[kb][r] * m - es[r]);             // dS
+                            } else {
+                                sc[kb][r] = p;
+                                dp[kb][r] = p * (dp[kb][r] - es[r]);
+                            }
+                        }
+                    }
+                    const Planes pp = split_mx(sc[0], sc[1], c.sel0, c.sel1);
+                    dv[n] = mm6(dt_, pp, dv[n]);                                     // dV^T[d][key] += dO^T P
+                    const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
+                    dk[n] = mm6(qt_, ds, dk[n]);                                     // dK^T[d][key] += Q^T dS
+                }
+            }
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1, (t + 1) * KT);
+        __syncthreads();
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int key = row0 + 16 * n + c.l15;
+        if (key < B) {
+            float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * 16 + 4 * c.g;
+            *reinterpret_cast<float4*>(drow + E) =
+                make_float4(dk[n][0] * a.scale, dk[n][1] * a.scale, dk[n][2] * a.scale, dk[n][3] * a.scale);
+            *reinterpret_cast<float4*>(drow + 2 * E) = make_float4(dv[n][0], dv[n][1], dv[n][2], dv[n][3]);
+        }
+    }
+}
+
+template <bool DROP>
+int launch6n(int which, const AttnArgs& a, hipStream_t st) {
+    constexpr int NB = RLT_A6N_NB, NBK = RLT_A6N_NBK;
+    const size_t shm = (size_t)4 * IMGN * sizeof(uint16_t) + (which == 1 ? 2 * 3 * KT * sizeof(float) : 2 * KT * sizeof(uint32_t));
+    if (which == 0)
+        hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), dim3(256), shm, st, a);
+    else if (which == 1)
+        hipLaunchKernelGGL((attn6n_bwd_dkv_kernel<NBK, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NBK)), dim3(256), shm, st, a);
+    else
+        hipLaunchKernelGGL((attn6n_bwd_dq_kernel<NB, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), dim3(256), shm, st, a);
+    return RLT_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+// which = 0 forward, 1 dK/dV, 2 dQ (head dim 16, bf16x6 arithmetic)
+int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st) {
+    return a.drop_p > 0.f ? launch6n<true>(which, a, st) : launch6n<false>(which, a, st);
+}

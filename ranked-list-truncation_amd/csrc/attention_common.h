@@ -74,6 +74,9 @@ int rlt_attn6_run(int which, const AttnArgs& a, int HD, hipStream_t st);
 // ... with pre-split tile images (which = 3: write the Q / K / V images from a.qkv into a.img; 4: the dO images from a.dout into
 // a.dimg); nmat matrices of S*H pairs x ceil(B / 64) tiles
 size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat);
+// ... at head dim 16 on the 16x16x32 MFMA (no padded head-dim axis, plane pairs in the d contraction, the split of P / dS on the
+// matrix pipe), defined in attention6n.hip: which = 0 forward, 1 dK/dV, 2 dQ
+int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st);
 // exact fp32 at head dim 16 on the 16x16x4 MFMA (no padded head-dim axis), defined in attention16.hip: same `which`
 int rlt_attn16_run(int which, const AttnArgs& a, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip

@@ -13,7 +13,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # per-file extras.  attention6.hip: no SLP packing - v_pk_add_f32 / v_pk_mul_f32 do not run beside a partner wavefront's bf16 MFMAs
 # (tools/micro/mfma_valu_overlap.hip), the unpacked forms do; the exact-fp32 files keep the packing (there every vector instruction
 # adds to the MFMA time, and a packed one does two lanes' work)
-FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"], "attention6n.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
