@@ -37,6 +37,27 @@
 #define RLT_A6N_OCC 2       // wavefronts per SIMD the register budget is declared for
 #endif
 
+#ifndef RLT_A6N_SEED
+#define RLT_A6N_SEED 1      // the row / lane constants (-m_run, -lse, -delta) as the INITIAL accumulators of the score / dP products (as attention16.hip): no subtraction per score
+#endif
+#ifndef RLT_A6N_ABL
+#define RLT_A6N_ABL 0       // timing-only ablations of the dQ kernel (wrong results): 1 no element-wise work, 2 no split MFMAs, 4 no score / dP products, 8 no dQ product
+#endif
+#ifndef RLT_A6N_SGB
+#define RLT_A6N_SGB 0       // 1: sched_group_barrier pattern (1 MFMA, 2 vector) over the block body of dQ / dK+dV
+#endif
+// interleave hint for the scheduling region that ends here: NM x (one MFMA, NV vector instructions)
+template <int NM, int NV>
+__device__ __forceinline__ void interleave_hint() {
+#if RLT_A6N_SGB
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+#endif
+}
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,6 +93,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& t0, const f32x4& t1) {
 __device__ __forceinline__ Planes split_mx(f32x4 t0, f32x4 t1, bf16x8 sel0, bf16x8 sel1) {
     Planes p;
     p.h = pack8(t0, t1);
+    if (RLT_A6N_ABL & 2) { p.m = pack8(t1, t0); p.l = pack8(t0, t0); return p; }
     t0 = mm(sel0, p.h, t0); t1 = mm(sel1, p.h, t1);
     p.m = pack8(t0, t1);
     t0 = mm(sel0, p.m, t0); t1 = mm(sel1, p.m, t1);
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
 
     bf16x8 qmh[NB], qlh[NB];
     uint32_t hq[NB];
-    f32x4 o[NB];
+    f32x4 o[NB], seed[NB];                      // seed: -m_run in all four registers, the initial value of the score accumulators
     float m_run[NB], l_run[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -207,6 +229,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
         own_frags(base + (size_t)min(q, B - 1) * ld, c, a.scale * LOG2E, qmh[n], qlh[n]);
         hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
         o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        seed[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         m_run[n] = 0.f; l_run[n] = 0.f;          // m_run: the reference of the weights, set by the first block
     }
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
@@ -235,8 +258,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                 f32x4 sc[NB][2];                                   // S^T[key][q], log2 domain
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    sc[n][0] = row_prod(k0, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
-                    sc[n][1] = row_prod(k1, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    sc[n][0] = row_prod(k0, qmh[n], qlh[n], seed[n]);          // (seeded: scores relative to the reference)
+                    sc[n][1] = row_prod(k1, qmh[n], qlh[n], seed[n]);
                 }
                 if (tail) {                                        // last tile only: keys beyond B
 #pragma unroll
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pe[n][kb][r] = rlt_exp2(sc[n][kb][r] - m_run[n]);
+                            pe[n][kb][r] = rlt_exp2(RLT_A6N_SEED ? sc[n][kb][r] : sc[n][kb][r] - m_run[n]);
                             psum[n] += pe[n][kb][r];
                         }
                     redo |= !(psum[n] <= 4096.f);
@@ -275,8 +298,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
 #pragma unroll
                             for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[n][kb][r]);
                         tmax = col_max4(tmax);
-                        const float m_new = first ? tmax : fmaxf(tmax, m_run[n]);
-                        const float alpha = first ? 0.f : rlt_exp2(m_run[n] - m_new);
+                        // (seeded: scores are relative to the old reference, d = the move of the reference)
+                        const float mo = RLT_A6N_SEED ? 0.f : m_run[n];
+                        const float m_new = first ? tmax : fmaxf(tmax, mo);
+                        const float alpha = first ? 0.f : rlt_exp2(mo - m_new);
                         psum[n] = 0.f;
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb)
@@ -286,7 +311,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                                 psum[n] += pe[n][kb][r];
                             }
                         l_run[n] *= alpha;
-                        m_run[n] = m_new;
+                        m_run[n] = RLT_A6N_SEED ? m_run[n] + m_new : m_new;
+                        if (RLT_A6N_SEED) seed[n] = f32x4{-m_run[n], -m_run[n], -m_run[n], -m_run[n]};
                         o[n] *= alpha;
                     }
                 }
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
     bf16x8 qmh[NB], qlh[NB], dmh[NB], dlh[NB];
     float lse2[NB], del[NB];
     uint32_t hq[NB];
-    f32x4 dq[NB];
+    f32x4 dq[NB], seed_s[NB], seed_d[NB];       // seeds: -lse / -delta of the lane's query in all four registers
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int q = row0 + 16 * n + c.l15, qc = min(q, B - 1);
@@ -360,6 +386,9 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
         own_frags(a.dout + ((size_t)s * B + qc) * E + h * 16, c, 1.f, dmh[n], dlh[n]);
         lse2[n] = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
         del[n] = a.delta[((size_t)s * H + h) * B + qc];
+        const float s0 = RLT_A6N_SEED ? -lse2[n] : 0.f, d0 = RLT_A6N_SEED && !DROP ? -del[n] : 0.f;
+        seed_s[n] = f32x4{s0, s0, s0, s0};
+        seed_d[n] = f32x4{d0, d0, d0, d0};
         hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
         dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -394,24 +423,32 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     f32x4 sc[2], dp[2];
-                    sc[0] = row_prod(k0, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // S^T[key][q]
-                    sc[1] = row_prod(k1, qmh[n], qlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
-                    dp[0] = row_prod(v0, dmh[n], dlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // dP^T[key][q]
-                    dp[1] = row_prod(v1, dmh[n], dlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    if (RLT_A6N_ABL & 4) {
+                        sc[0] = f32x4{lse2[n], del[n], lse2[n], del[n]}; sc[1] = sc[0] * 0.5f; dp[0] = sc[0] + 1.f; dp[1] = sc[1] - 1.f;
+                        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(dp[0]), "+v"(dp[1]));
+                    } else {
+                    sc[0] = row_prod(k0, qmh[n], qlh[n], seed_s[n]);                     // S^T[key][q] (- lse[q])
+                    sc[1] = row_prod(k1, qmh[n], qlh[n], seed_s[n]);
+                    dp[0] = row_prod(v0, dmh[n], dlh[n], seed_d[n]);                     // dP^T[key][q] (- delta[q])
+                    dp[1] = row_prod(v1, dmh[n], dlh[n], seed_d[n]);
+                    }
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
                         const uint32_t hcs[4] = {hc[kb].x, hc[kb].y, hc[kb].z, hc[kb].w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float p = rlt_exp2(sc[kb][r] - lse2[n]);
+                            if (RLT_A6N_ABL & 1) continue;
+                            const float p = rlt_exp2(RLT_A6N_SEED ? sc[kb][r] : sc[kb][r] - lse2[n]);
                             float dpr = dp[kb][r];
                             if (DROP) dpr = rlt_keep_rc(hq[n], hcs[r], a.drop_thr) ? dpr * inv_keep : 0.f;
-                            dp[kb][r] = p * (dpr - del[n]);                          // dS^T
+                            dp[kb][r] = RLT_A6N_SEED && !DROP ? p * dpr : p * (dpr - del[n]);     // dS^T
                         }
                     }
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
+                    if (RLT_A6N_ABL & 8) { asm volatile("" :: "v"(ds.h), "v"(ds.m), "v"(ds.l)); continue; }
                     dq[n] = mm6(kt, ds, dq[n]);                                      // dQ^T[d][q] += K^T dS^T
                 }
+                interleave_hint<22 * NB, 2>();
             }
         }
         if (t + 1 < nt) {
@@ -479,6 +516,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
             const float l = lsebase[qc], e = delbase[qc];
             rl = qi < B ? l * LOG2E : INFINITY;
             re = qi < B ? e : 0.f;
+            if (RLT_A6N_SEED) { rl = -rl; re = -re; }       // negated: initial values of the score / dP accumulators
         }
     };
     auto store_tile = [&](int b, int r0) {
@@ -517,10 +555,11 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     f32x4 sc[2], dp[2];
-                    sc[0] = row_prod(q0, kmh[n], klh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // S[q][key]
-                    sc[1] = row_prod(q1, kmh[n], klh[n], f32x4{0.f, 0.f, 0.f, 0.f});
-                    dp[0] = row_prod(d0, vmh[n], vlh[n], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[q][key]
-                    dp[1] = row_prod(d1, vmh[n], vlh[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sc[0] = row_prod(q0, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[0].x, l4[0].y, l4[0].z, l4[0].w} : z4);     // S[q][key] (- lse[q])
+                    sc[1] = row_prod(q1, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[1].x, l4[1].y, l4[1].z, l4[1].w} : z4);
+                    dp[0] = row_prod(d0, vmh[n], vlh[n], RLT_A6N_SEED && !DROP ? f32x4{e4[0].x, e4[0].y, e4[0].z, e4[0].w} : z4);     // dP[q][key] (- delta[q])
+                    dp[1] = row_prod(d1, vmh[n], vlh[n], RLT_A6N_SEED && !DROP ? f32x4{e4[1].x, e4[1].y, e4[1].z, e4[1].w} : z4);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
                         const float ls[4] = {l4[kb].x, l4[kb].y, l4[kb].z, l4[kb].w};
@@ -528,14 +567,14 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                         const uint32_t hrs[4] = {hr[kb].x, hr[kb].y, hr[kb].z, hr[kb].w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float p = rlt_exp2(sc[kb][r] - ls[r]);
+                            const float p = rlt_exp2(RLT_A6N_SEED ? sc[kb][r] : sc[kb][r] - ls[r]);
                             if (DROP) {
                                 const float m = rlt_keep_rc(hrs[r], hk[n], a.drop_thr) ? inv_keep : 0.f;
                                 sc[kb][r] = p * m;                                   // dropped P (feeds dV)
-                                dp[kb][r] = p * (dp[kb][r] * m - es[r]);             // dS
+                                dp[kb][r] = RLT_A6N_SEED ? p * (dp[kb][r] * m + es[r]) : p * (dp[kb][r] * m - es[r]);   // dS
                             } else {
                                 sc[kb][r] = p;
-                                dp[kb][r] = p * (dp[kb][r] - es[r]);
+                                dp[kb][r] = RLT_A6N_SEED ? p * dp[kb][r] : p * (dp[kb][r] - es[r]);
                             }
                         }
                     }
@@ -544,6 +583,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
                     dk[n] = mm6(qt_, ds, dk[n]);                                     // dK^T[d][key] += Q^T dS
                 }
+                interleave_hint<32 * NB, 2>();
             }
         }
         if (t + 1 < nt) store_tile(buf ^ 1, (t + 1) * KT);
