@@ -158,10 +158,12 @@ def hbm_kernel_roofline(S, dev, lists=262144, reps=10):
     sums = torch.empty(2, dtype=torch.float64, device=dev)
     wsb = N.query("rlt_loss_metrics_workspace", lists)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
+    from rlt_hip import ops as _ops
+    tab = _ops.dcg_table(dev)
 
     def run():
         N.call("rlt_loss_metrics", N.ptr(p), N.ptr(y), None, lists, S, N.METRIC_F1, -1.0, N.LOSS_JS, 0.85, -1.0, N.ptr(per_list),
-               N.ptr(loss_out), N.ptr(dp), N.ptr(k), N.ptr(f1), N.ptr(dcg), N.ptr(sums), N.ptr(ws), wsb, N.stream())
+               N.ptr(loss_out), N.ptr(dp), N.ptr(k), N.ptr(f1), N.ptr(dcg), N.ptr(sums), N.ptr(tab), N.ptr(ws), wsb, N.stream())
     for _ in range(3):
         run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -35,7 +35,7 @@ extern "C" {
 #define RLT_E_WORKSPACE (-3)  /* workspace too small                               */
 #define RLT_E_ALIGN    (-4)   /* pointer / leading dimension not 16-byte aligned   */
 
-#define RLT_ABI_VERSION 3
+#define RLT_ABI_VERSION 4
 int rlt_abi_version(void);
 /* Precision of the MFMA contractions (the rlt_gemm* family, rlt_list_attention_*, the BiLSTM recurrences); inputs, outputs,
  * softmax, LayerNorm, gate nonlinearities, losses and every accumulator are fp32 in all modes.
@@ -44,9 +44,15 @@ int rlt_abi_version(void);
  *                        (8 + 8 + 8 significand bits: all 24 operand bits enter), six of the nine partial products kept,
  *                        each exact in the matrix pipe, fp32 accumulation; what is dropped is < 2^-23 of the product
  *                        in the worst case (under one fp32 ulp; 2^-29 typical).  Held to the FP32 mode's tolerances in
- *                        the tests; measured against fp64 it is as accurate as the f32 MFMA kernels or better.  Head dim
- *                        128 and shapes off the tile grid run the exact-fp32 kernels in this mode.  THE DEFAULT: the
- *                        reference computes in fp32 end to end (models/AttnCut.py:8-14).
+ *                        the tests.  Measured against fp64 (tools/gpu_probe.py x6_adversarial, profiles/r05_notes.md): at
+ *                        or below the f32 MFMA kernels' error on random operands and on the adversarial classes `ones`
+ *                        (low significand bits all ones, one sign) and `cancel` (sums cancelling by 1e4); on operands
+ *                        that all share the SAME worst-case low bits (`worst-split`: 0x7F40, one sign) the dropped terms
+ *                        add coherently - up to 8x the f32 MFMA kernels' error in attention backward (dQ / dK at 2048
+ *                        lists), 17x in a K ~ 10^6 contraction - always inside the a-priori bound K 2^-24 of an fp32
+ *                        chain and two orders inside BASELINE.json's 1e-4.  Head dim 128 and shapes off the tile grid
+ *                        run the exact-fp32 kernels in this mode.  THE DEFAULT: the reference computes in fp32 end to
+ *                        end (models/AttnCut.py:8-14).
  *   RLT_PRECISION_BF16X3 opt-in fast mode: every operand split into bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi
  *                        (16 operand bits, ~2^-16 relative error per product, ~2x faster end to end; inside
  *                        BASELINE.json's 1e-4 bound but narrower than the reference's arithmetic)
@@ -104,16 +110,22 @@ int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int 
  * loss_out = (sum of the per-list terms)/B from a float64 sum.  All outputs required except dp.  Two launches: the pass
  * (two ranked lists per wavefront - one per 32-lane half - when S % 4 == 0 and S <= 384, one per wavefront otherwise; a grid
  * sized to the chip striding over the lists; every wavefront leaves its float64 partial sums in ws) and a one-workgroup
- * fixed-order reduction of those partials (deterministic).  The float64 DCG coefficients 1/log2(j+2) and their prefix sums
- * come from a per-device table the library builds on first use (a 16 KB allocation and one synchronous copy).
+ * fixed-order reduction of those partials (deterministic).  The float64 DCG coefficients 1/log2(j+2) (utils/metrics.py:7) and
+ * their prefix sums are read from `dcg_table`, CALLER memory of rlt_dcg_table_bytes() bytes (8-byte aligned) that
+ * rlt_dcg_table_init has filled once (one small launch on `stream`; the table does not depend on B, S or the metric and may be
+ * shared by every later call on that device): like every entry point of this library the call allocates nothing, never
+ * synchronises with the host and may be captured into a graph.  (ABI 3 built the table itself on first use: a hidden
+ * hipMalloc + synchronous copy.)
  * ws: rlt_loss_metrics_workspace(B) bytes.
  * Algorithmic bytes per list: read p, labels 8S, write dp 4S + 24 B of results (3.6 KB at S = 300). */
+size_t rlt_dcg_table_bytes(void);
+int rlt_dcg_table_init(void* table, size_t table_bytes, void* stream);
 size_t rlt_loss_metrics_workspace(int B);
 int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
                      int metric, float penalty, int kind, float tau, double metric_penalty,
                      float* loss_per_list, float* loss_out, float* dp,
                      int32_t* k_out, double* f1_out, double* dcg_out, double* sums,
-                     void* ws, size_t ws_bytes, void* stream);
+                     const void* dcg_table, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ multi-task terms (L7-L8)
  * utils/losses.py:99-141 (RerankLoss) and nn.BCELoss of :177,:187 (MtCutLoss).

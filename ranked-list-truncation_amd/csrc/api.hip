@@ -1,6 +1,7 @@
 // ABI bookkeeping for librlt_hip.so.
 #include "common.h"
 
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -11,16 +12,19 @@
 //              models/AttnCut.py:8-14, so the default of a drop-in is a reference-faithful mode; bf16x3 is opt-in); written
 //              only by rlt_set_precision
 //   tl_scope   the mode of the entry-point call running on this thread (common.h: RltPrecScope), -1 outside any call
-static int g_default = -1;
+static std::atomic<int> g_default{-1};      // (atomic: the first call of any thread may initialise it while another thread sets it)
 static thread_local int tl_scope = -1;
 static int default_precision() {
-    if (g_default < 0) {
+    int d = g_default.load(std::memory_order_relaxed);
+    if (d < 0) {
         const char* e = getenv("RLT_PRECISION");
-        if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) g_default = RLT_PRECISION_FP32;
-        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_default = RLT_PRECISION_BF16X3;
-        else g_default = RLT_PRECISION_BF16X6;
+        int from_env = RLT_PRECISION_BF16X6;
+        if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) from_env = RLT_PRECISION_FP32;
+        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) from_env = RLT_PRECISION_BF16X3;
+        // a concurrent rlt_set_precision wins over the environment
+        if (g_default.compare_exchange_strong(d, from_env, std::memory_order_relaxed)) d = from_env;
     }
-    return g_default;
+    return d;
 }
 int rlt_precision() { return tl_scope >= 0 ? tl_scope : default_precision(); }
 RltPrecScope::RltPrecScope(int p) : saved(tl_scope), set(p >= 0) { if (set) tl_scope = p; }
@@ -30,7 +34,7 @@ extern "C" {
 
 int rlt_set_precision(int mode) {
     if (mode != RLT_PRECISION_FP32 && mode != RLT_PRECISION_BF16X3 && mode != RLT_PRECISION_BF16X6) return RLT_E_ARG;
-    g_default = mode;
+    g_default.store(mode, std::memory_order_relaxed);
     return 0;
 }
 int rlt_get_precision(void) { return default_precision(); }

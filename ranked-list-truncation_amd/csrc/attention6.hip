@@ -4,7 +4,10 @@
 //   x = h + m + l  (h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits),
 //   a*b ~ m*m' + l*h' + h*l' + m*h' + h*m' + h*h'   (six v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest first);
 // what is dropped is < 2^-23 |a b| in the worst case, 2^-29 typically (tests/test_split6.py): under one fp32 ulp of the
-// product.  Six bf16 products cost 6/16 of one f32 MFMA
+// product.  (On operands that all share the worst-case low bits the ROUNDINGS of the small plane products into the large running
+// sums add coherently: up to 8x the f32 MFMA kernels' error in dQ / dK at head dim 64, inside the fp32-chain bound; the head-dim-16
+// kernels keep the small products in an accumulator of their own and are below the f32 kernels on every class - attention6n.hip,
+// tools/gpu_probe.py x6_adversarial, profiles/r05_notes.md.)  Six bf16 products cost 6/16 of one f32 MFMA
 // product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
 //
 // Head dims 64 (the AttnCut / MMOECut family), 32 and 16 (Choopy / MtChoopy), with and without train-mode dropout; head dim

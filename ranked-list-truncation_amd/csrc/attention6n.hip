@@ -40,6 +40,9 @@
 #ifndef RLT_A6N_SEED
 #define RLT_A6N_SEED 1      // the row / lane constants (-m_run, -lse, -delta) as the INITIAL accumulators of the score / dP products (as attention16.hip): no subtraction per score
 #endif
+#ifndef RLT_A6N_2ACC
+#define RLT_A6N_2ACC 1      // 1: the five small plane products of the list-contracted outputs (O, dQ, dK, dV) accumulate in their OWN accumulator, added to the h h' accumulator once at the end
+#endif
 #ifndef RLT_A6N_ABL
 #define RLT_A6N_ABL 0       // timing-only ablations of the dQ kernel (wrong results): 1 no element-wise work, 2 no split MFMAs, 4 no score / dP products, 8 no dQ product
 #endif
@@ -74,7 +77,14 @@ __device__ __forceinline__ uint32_t pk2n(float a, float b) {
 }
 __device__ __forceinline__ float lo16(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float hi16(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-__device__ __forceinline__ f32x4 mm(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#ifndef RLT_A6N_PAD
+#define RLT_A6N_PAD -1      // >= 0: `s_nop PAD` behind every MFMA (the issuing wavefront steps back from the SIMD's issue port: attention6.hip, RLT_A6_PP_PAD)
+#endif
+__device__ __forceinline__ f32x4 mm(bf16x8 a, bf16x8 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    if (RLT_A6N_PAD >= 0) asm volatile("s_nop %1" : "+v"(c) : "n"(RLT_A6N_PAD >= 0 ? RLT_A6N_PAD : 0));
+    return c;
+}
 __device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d)); }
 
 // exact three-way split in vector code (staging and the stationary fragments only): four values -> three packed pairs
@@ -101,6 +111,15 @@ __device__ __forceinline__ Planes split_mx(f32x4 t0, f32x4 t1, bf16x8 sel0, bf16
     return p;
 }
 // acc += A^T-image planes x fresh planes: the six products, smallest first
+// ... with the small products in their own accumulator (RLT_A6N_2ACC)
+__device__ __forceinline__ void mm6_2(const Planes& a, const Planes& b, f32x4& big, f32x4& small) {
+    small = mm(a.m, b.m, small);
+    small = mm(a.l, b.h, small);
+    small = mm(a.h, b.l, small);
+    small = mm(a.m, b.h, small);
+    small = mm(a.h, b.m, small);
+    big = mm(a.h, b.h, big);
+}
 __device__ __forceinline__ f32x4 mm6(const Planes& a, const Planes& b, f32x4 c) {
     c = mm(a.m, b.m, c);
     c = mm(a.l, b.h, c);
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
 
     bf16x8 qmh[NB], qlh[NB];
     uint32_t hq[NB];
-    f32x4 o[NB], seed[NB];                      // seed: -m_run in all four registers, the initial value of the score accumulators
+    f32x4 o[NB], o2[NB], seed[NB];                      // seed: -m_run in all four registers, the initial value of the score accumulators
     float m_run[NB], l_run[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
         own_frags(base + (size_t)min(q, B - 1) * ld, c, a.scale * LOG2E, qmh[n], qlh[n]);
         hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
         o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         seed[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         m_run[n] = 0.f; l_run[n] = 0.f;          // m_run: the reference of the weights, set by the first block
     }
@@ -314,6 +334,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                         m_run[n] = RLT_A6N_SEED ? m_run[n] + m_new : m_new;
                         if (RLT_A6N_SEED) seed[n] = f32x4{-m_run[n], -m_run[n], -m_run[n], -m_run[n]};
                         o[n] *= alpha;
+                        if (RLT_A6N_2ACC) o2[n] *= alpha;
                     }
                 }
 #pragma unroll
@@ -330,7 +351,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                         }
                     }
                     const Planes pp = split_mx(pe[n][0], pe[n][1], c.sel0, c.sel1);
-                    o[n] = mm6(vt, pp, o[n]);                       // O^T[d][q] += V^T P^T
+                    if (RLT_A6N_2ACC) mm6_2(vt, pp, o[n], o2[n]);
+                    else o[n] = mm6(vt, pp, o[n]);                  // O^T[d][q] += V^T P^T
                 }
             }
         }
@@ -346,6 +368,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
     for (int n = 0; n < NB; ++n) {
         const float l_tot = col_sum4(l_run[n]);
         const int q = row0 + 16 * n + c.l15;
+        if (RLT_A6N_2ACC) o[n] += o2[n];
         if (q < B) {
             const float inv = 1.f / l_tot;
             *reinterpret_cast<float4*>(a.o + ((size_t)s * B + q) * E + h * 16 + 4 * c.g) =
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
     bf16x8 qmh[NB], qlh[NB], dmh[NB], dlh[NB];
     float lse2[NB], del[NB];
     uint32_t hq[NB];
-    f32x4 dq[NB], seed_s[NB], seed_d[NB];       // seeds: -lse / -delta of the lane's query in all four registers
+    f32x4 dq[NB], dq2[NB], seed_s[NB], seed_d[NB];       // seeds: -lse / -delta of the lane's query in all four registers
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int q = row0 + 16 * n + c.l15, qc = min(q, B - 1);
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
         seed_d[n] = f32x4{d0, d0, d0, d0};
         hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
         dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dq2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 
@@ -446,7 +470,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
                     }
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
                     if (RLT_A6N_ABL & 8) { asm volatile("" :: "v"(ds.h), "v"(ds.m), "v"(ds.l)); continue; }
-                    dq[n] = mm6(kt, ds, dq[n]);                                      // dQ^T[d][q] += K^T dS^T
+                    if (RLT_A6N_2ACC) mm6_2(kt, ds, dq[n], dq2[n]);
+                    else dq[n] = mm6(kt, ds, dq[n]);                                 // dQ^T[d][q] += K^T dS^T
                 }
                 interleave_hint<22 * NB, 2>();
             }
@@ -462,6 +487,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int q = row0 + 16 * n + c.l15;
+        if (RLT_A6N_2ACC) dq[n] += dq2[n];
         if (q < B)
             *reinterpret_cast<float4*>(a.dqkv + ((size_t)s * B + q) * ld + h * 16 + 4 * c.g) =
                 make_float4(dq[n][0] * a.scale, dq[n][1] * a.scale, dq[n][2] * a.scale, dq[n][3] * a.scale);
@@ -493,9 +519,11 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 
     bf16x8 kmh[NB], klh[NB], vmh[NB], vlh[NB];
     uint32_t hk[NB];
-    f32x4 dk[NB], dv[NB];
+    f32x4 dk[NB], dv[NB], dk2[NB], dv2[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
+        dk2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int key = row0 + 16 * n + c.l15, kc = min(key, B - 1);
         own_frags(base + (size_t)kc * ld + E, c, a.scale * LOG2E, kmh[n], klh[n]);
         own_frags(base + (size_t)kc * ld + 2 * E, c, 1.f, vmh[n], vlh[n]);
@@ -558,8 +586,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     sc[0] = row_prod(q0, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[0].x, l4[0].y, l4[0].z, l4[0].w} : z4);     // S[q][key] (- lse[q])
                     sc[1] = row_prod(q1, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[1].x, l4[1].y, l4[1].z, l4[1].w} : z4);
-                    dp[0] = row_prod(d0, vmh[n], vlh[n], RLT_A6N_SEED && !DROP ? f32x4{e4[0].x, e4[0].y, e4[0].z, e4[0].w} : z4);     // dP[q][key] (- delta[q])
-                    dp[1] = row_prod(d1, vmh[n], vlh[n], RLT_A6N_SEED && !DROP ? f32x4{e4[1].x, e4[1].y, e4[1].z, e4[1].w} : z4);
+                    const f32x4 e0 = RLT_A6N_SEED && !DROP ? f32x4{e4[0].x, e4[0].y, e4[0].z, e4[0].w} : z4;
+                    const f32x4 e1 = RLT_A6N_SEED && !DROP ? f32x4{e4[1].x, e4[1].y, e4[1].z, e4[1].w} : z4;
+                    dp[0] = row_prod(d0, vmh[n], vlh[n], e0);                             // dP[q][key] (- delta[q])
+                    dp[1] = row_prod(d1, vmh[n], vlh[n], e1);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
                         const float ls[4] = {l4[kb].x, l4[kb].y, l4[kb].z, l4[kb].w};
@@ -579,9 +609,11 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                         }
                     }
                     const Planes pp = split_mx(sc[0], sc[1], c.sel0, c.sel1);
-                    dv[n] = mm6(dt_, pp, dv[n]);                                     // dV^T[d][key] += dO^T P
+                    if (RLT_A6N_2ACC) mm6_2(dt_, pp, dv[n], dv2[n]);
+                    else dv[n] = mm6(dt_, pp, dv[n]);                                // dV^T[d][key] += dO^T P
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
-                    dk[n] = mm6(qt_, ds, dk[n]);                                     // dK^T[d][key] += Q^T dS
+                    if (RLT_A6N_2ACC) mm6_2(qt_, ds, dk[n], dk2[n]);
+                    else dk[n] = mm6(qt_, ds, dk[n]);                                // dK^T[d][key] += Q^T dS
                 }
                 interleave_hint<32 * NB, 2>();
             }
@@ -593,6 +625,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int key = row0 + 16 * n + c.l15;
+        if (RLT_A6N_2ACC) { dk[n] += dk2[n]; dv[n] += dv2[n]; }
         if (key < B) {
             float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * 16 + 4 * c.g;
             *reinterpret_cast<float4*>(drow + E) =

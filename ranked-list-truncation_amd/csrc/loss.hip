@@ -66,6 +66,7 @@ struct RewardArgs {
     double* dcg_out;       // (B) DCG@k, float64 (metric penalty = mpenalty)
     double mpenalty;
     double* partials;      // (grid * 4, 3): per-wavefront sums of loss, F1, DCG
+    const double* icoef_tab;   // the caller's DCG coefficient table (rlt_dcg_table_init), METRICS instantiation of the two-list kernel
 };
 
 // element j of a list lives at lds[(j / C) * STRIDE + j % C], STRIDE = C|1 (odd => conflict-free)
@@ -599,27 +600,21 @@ int launch_reward(const RewardArgs& a, hipStream_t st) {
     return RLT_LAUNCH_RESULT();
 }
 
-// 1 / log2(j + 2) for j < 1024 in float64 and their prefix sums, one table per device, made on first use (host libm,
-// synchronous copy)
-const double* icoef_table() {
-    static std::mutex mu;
-    static double* tab[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> guard(mu);
-    if (!tab[dev]) {
-        static double h[1024 + 1025];                       // [j] = 1 / log2(j + 2);  [1024 + k] = sum_{j<k} of them
-        h[1024] = 0.0;
-        for (int j = 0; j < 1024; ++j) {
-            h[j] = 1.0 / std::log2((double)(j + 2));
-            h[1024 + j + 1] = h[1024 + j] + h[j];
-        }
-        double* d = nullptr;
-        if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
-        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-        tab[dev] = d;
+// 1 / log2(j + 2) for j < 1024 in float64 and their prefix sums: [j] = 1 / log2(j + 2); [1024 + k] = sum_{j<k} of them.  The table
+// lives in CALLER memory (rlt_dcg_table_bytes / rlt_dcg_table_init, once per device buffer): the library allocates nothing and
+// never synchronises with the host.
+constexpr int DCG_TAB_N = 1024;
+__global__ __launch_bounds__(1024) void dcg_table_kernel(double* __restrict__ tab) {
+    __shared__ double c[DCG_TAB_N];
+    const int j = threadIdx.x;
+    c[j] = 1.0 / log2((double)(j + 2));
+    tab[j] = c[j];
+    __syncthreads();
+    if (j == 0) {                                   // fixed order: the sums a sequential float64 loop produces
+        double acc = 0.0;
+        tab[DCG_TAB_N] = 0.0;
+        for (int k = 0; k < DCG_TAB_N; ++k) { acc += c[k]; tab[DCG_TAB_N + k + 1] = acc; }
     }
-    return tab[dev];
 }
 
 // two lists per wavefront: one workgroup per 8 lists up to the same number of workgroups
@@ -629,8 +624,8 @@ int reward_h_grid(int B) {
 }
 template <int R, bool METRICS>
 int launch_reward_h(const RewardArgs& a, hipStream_t st) {
-    const double* tab = nullptr;
-    if (METRICS && !(tab = icoef_table())) return RLT_E_ARG;
+    const double* tab = a.icoef_tab;
+    if (METRICS && !tab) return RLT_E_ARG;
     if (a.metric == RLT_METRIC_F1)
         hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, true>), dim3(reward_h_grid(a.B)), dim3(256), 0, st, a, tab);
     else
@@ -879,7 +874,7 @@ int rlt_reward_loss_ex(const float* p, const float* labels, const float* dcg_coe
     int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
     if (rc) return rc;
     RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
-                 nullptr, nullptr, nullptr, -1.0, nullptr};
+                 nullptr, nullptr, nullptr, -1.0, nullptr, nullptr};
     hipStream_t st = rlt_stream(stream);
     rc = dispatch_reward(a, st);
     if (rc) return rc;
@@ -900,17 +895,28 @@ size_t rlt_loss_metrics_workspace(int B) {
     return B > 0 ? (size_t)reward_grid(B) * LISTS_PER_WG * 3 * sizeof(double) : 0;      // one record per wavefront of the pass
 }
 
+size_t rlt_dcg_table_bytes(void) { return ((size_t)(2 * DCG_TAB_N + 1) * sizeof(double) + 15) / 16 * 16; }
+
+int rlt_dcg_table_init(void* table, size_t table_bytes, void* stream) {
+    RLT_CHECK_ARG(table);
+    if (table_bytes < rlt_dcg_table_bytes()) return RLT_E_WORKSPACE;
+    if (((uintptr_t)table & 7u) != 0) return RLT_E_ALIGN;
+    hipLaunchKernelGGL(dcg_table_kernel, dim3(1), dim3(DCG_TAB_N), 0, rlt_stream(stream), (double*)table);
+    return RLT_LAUNCH_RESULT();
+}
+
 int rlt_loss_metrics(const float* p, const float* labels, const float* dcg_coef, int B, int S,
                      int metric, float penalty, int kind, float tau, double metric_penalty,
                      float* loss_per_list, float* loss_out, float* dp,
                      int32_t* k_out, double* f1_out, double* dcg_out, double* sums,
-                     void* ws, size_t ws_bytes, void* stream) {
-    RLT_CHECK_ARG(p && loss_per_list && loss_out && k_out && f1_out && dcg_out && sums && ws);
+                     const void* dcg_table, void* ws, size_t ws_bytes, void* stream) {
+    RLT_CHECK_ARG(p && loss_per_list && loss_out && k_out && f1_out && dcg_out && sums && ws && dcg_table);
+    if (((uintptr_t)dcg_table & 7u) != 0) return RLT_E_ALIGN;
     int rc = reward_args_ok(p, labels, dcg_coef, B, S, metric, kind);
     if (rc) return rc;
     if (ws_bytes < rlt_loss_metrics_workspace(B)) return RLT_E_WORKSPACE;
     RewardArgs a{p, labels, dcg_coef, loss_per_list, dp, nullptr, nullptr, B, S, metric, kind, tau, 1.0f / (float)B, penalty,
-                 k_out, f1_out, dcg_out, metric_penalty, (double*)ws};
+                 k_out, f1_out, dcg_out, metric_penalty, (double*)ws, (const double*)dcg_table};
     hipStream_t st = rlt_stream(stream);
     int records = 0;
     rc = dispatch_reward_m<true>(a, st, &records);
@@ -926,7 +932,7 @@ int rlt_reward_matrix_ex(const float* labels, const float* dcg_coef, int B, int 
     int rc = reward_args_ok(nullptr, labels, dcg_coef, B, S, metric, RLT_LOSS_KL);
     if (rc) return rc;
     RewardArgs a{nullptr, labels, dcg_coef, nullptr, nullptr, r_out, q_out, B, S, metric, RLT_LOSS_KL, tau, 1.0f, penalty,
-                 nullptr, nullptr, nullptr, -1.0, nullptr};
+                 nullptr, nullptr, nullptr, -1.0, nullptr, nullptr};
     return dispatch_reward(a, rlt_stream(stream));
 }
 

@@ -32,7 +32,9 @@ _SIGNATURES = {
     "rlt_reward_loss_ex": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, P, P, P]),
     "rlt_reward_matrix_ex": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P]),
     "rlt_loss_metrics_workspace": (c_size_t, [c_int]),
-    "rlt_loss_metrics": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_double, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "rlt_dcg_table_bytes": (c_size_t, []),
+    "rlt_dcg_table_init": (c_int, [P, c_size_t, P]),
+    "rlt_loss_metrics": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_double, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "rlt_cut_metrics_ex": (c_int, [P, P, P, c_int, c_int, c_double, P, P, P, P, P]),
     "rlt_mt_terms_workspace": (c_size_t, [c_int, c_int]),
     "rlt_mt_terms": (c_int, [P, P, P, c_int, c_int, c_float, P, P, c_size_t, P]),
@@ -151,7 +153,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.rlt_abi_version() != 3:
+    if lib.rlt_abi_version() != 4:
         raise RuntimeError("librlt_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -722,6 +722,21 @@ def dcg_coef(S, device):
     return _COEF_CACHE[key]
 
 
+_DCG_TABLE_CACHE = {}
+
+
+def dcg_table(device):
+    """The float64 DCG coefficient table of rlt_loss_metrics (1 / log2(j + 2) and its prefix sums), filled once per device by
+    rlt_dcg_table_init on the current stream: caller memory, the library keeps no state of its own."""
+    key = str(device)
+    if key not in _DCG_TABLE_CACHE:
+        nbytes = query("rlt_dcg_table_bytes")
+        t = torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
+        call("rlt_dcg_table_init", ptr(t), nbytes, stream())
+        _DCG_TABLE_CACHE[key] = t
+    return _DCG_TABLE_CACHE[key]
+
+
 def _fused_metric_buffers(B, dev):
     return (torch.empty((B,), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.float64, device=dev),
             torch.empty((B,), dtype=torch.float64, device=dev), torch.empty((2,), dtype=torch.float64, device=dev))
@@ -750,7 +765,7 @@ class RewardLossFn(Function):
         ws_bytes = query("rlt_loss_metrics_workspace", B)
         ws = workspace(ws_bytes, p.device)
         call("rlt_loss_metrics", ptr(p), ptr(labels), ptr(coef), B, S, metric, penalty, kind, tau, metric_penalty,
-             ptr(per_list), ptr(loss), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(ws), ws_bytes, stream())
+             ptr(per_list), ptr(loss), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(dcg_table(p.device)), ptr(ws), ws_bytes, stream())
         ctx.mark_non_differentiable(k, sums)
         return loss.reshape(()), k, sums
 
@@ -852,7 +867,7 @@ class MtCutLossFn(Function):
             lws_bytes = query("rlt_loss_metrics_workspace", B)
             lws = workspace(lws_bytes, dev)
             call("rlt_loss_metrics", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, -1.0, N.LOSS_JS, tau, -1.0,
-                 ptr(per_list), ptr(cut), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(lws), lws_bytes, stream())
+                 ptr(per_list), ptr(cut), ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(dcg_table(dev)), ptr(lws), lws_bytes, stream())
         else:
             call("rlt_reward_loss", ptr(cut_p), ptr(labels), ptr(coef), B, S, metric, N.LOSS_JS, tau,
                  ptr(per_list), ptr(cut), ptr(dp), stream())

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(native):
     lib = native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rlt_abi_version() == 3
+    assert lib.rlt_abi_version() == 4
     assert b"workspace" in lib.rlt_error_string(-3)
 
 
@@ -51,7 +51,10 @@ def test_argument_errors_are_reported_not_crashed(native):
     assert lib.rlt_bicut_loss(None, None, 1, 1, 1, 0.65, 0.1, None, None, None, None) == -1
     assert native.query("rlt_narrow_dw_workspace", 1228800, 1024) > 0
     # the fused loss + metrics pass and the penalty forms
-    assert lib.rlt_loss_metrics(None, None, None, 1, 1, 0, -1.0, 3, 0.85, -1.0, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.rlt_loss_metrics(None, None, None, 1, 1, 0, -1.0, 3, 0.85, -1.0, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    # the DCG coefficient table is caller memory (ABI 4): size query, argument checks of the fill
+    assert native.query("rlt_dcg_table_bytes") == (2049 * 8 + 15) // 16 * 16
+    assert lib.rlt_dcg_table_init(None, 1 << 20, None) == -1
     assert native.query("rlt_loss_metrics_workspace", 4096) == 1024 * 4 * 3 * 8
     assert lib.rlt_cut_metrics_ex(None, None, None, 1, 1, -1.0, None, None, None, None, None) == -1
 

@@ -17,7 +17,7 @@ import ctypes, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/ranked-list-truncation_amd")
 from rlt_hip import native as N
 lib = N.load()
-assert lib.rlt_abi_version() == 3
+assert lib.rlt_abi_version() == 4
 # workspace queries over a grid of shapes and every precision code: pure host arithmetic
 for S, B, E, H, FF in [(300, 4096, 256, 4, 2048), (300, 8192, 128, 8, 2048), (40, 63, 256, 4, 2048), (1, 1, 64, 1, 64), (7, 33, 128, 8, 96)]:
     for prec in (-1, 0, 1, 2):
@@ -49,6 +49,16 @@ lw_b = N.query("rlt_workspace_bytes", N.OP_BILSTM_WS, S, B, 3, 0, 0, 0, 0)
 assert lib.rlt_bilstm_fwd(x, 3, lw, S, B, x, x, ls_b - 1, x, lw_b, 0, None) == -3
 assert lib.rlt_bilstm_fwd(x, 3, lw, S, B, x, x, ls_b, x, lw_b - 1, 0, None) == -3
 assert lib.rlt_bilstm_bwd(x, 3, lw, x, x, S, B, x, ls_b - 1, None, lw, x, lw_b, 0, None) == -3
+# ABI 4: the DCG coefficient table is caller memory - size query, undersized / misaligned table, and the argument checks of the
+# training-step loss with real host buffers (every check answers before a launch is formed)
+tb = N.query("rlt_dcg_table_bytes")
+assert tb >= 2049 * 8 and tb % 16 == 0
+assert lib.rlt_dcg_table_init(x, tb - 1, None) == -3
+assert lib.rlt_dcg_table_init(ctypes.c_void_p(base + 4), tb, None) == -4
+lm_b = N.query("rlt_loss_metrics_workspace", B)
+assert lib.rlt_loss_metrics(x, x, None, B, S, 0, -1.0, 3, 0.85, -1.0, x, x, x, x, x, x, x, None, x, lm_b, None) == -1      # no table
+assert lib.rlt_loss_metrics(x, x, None, B, S, 0, -1.0, 3, 0.85, -1.0, x, x, x, x, x, x, x, ctypes.c_void_p(base + 4), x, lm_b, None) == -4
+assert lib.rlt_loss_metrics(x, x, None, B, S, 0, -1.0, 3, 0.85, -1.0, x, x, x, x, x, x, x, x, x, lm_b - 1, None) == -3
 print("walk ok")
 """
 

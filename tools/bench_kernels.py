@@ -121,7 +121,7 @@ def loss(S=300):
 
         def fused():
             call("rlt_loss_metrics", ptr(p), ptr(y), None, B, S, N.METRIC_F1, -1.0, N.LOSS_JS, 0.85, -1.0, ptr(per_list), ptr(loss_out),
-                 ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(ws), wsb, stream())
+                 ptr(dp), ptr(k), ptr(f1), ptr(dcg), ptr(sums), ptr(ops.dcg_table(dev)), ptr(ws), wsb, stream())
 
         def separate():
             call("rlt_reward_loss", ptr(p), ptr(y), None, B, S, N.METRIC_F1, N.LOSS_JS, 0.85, ptr(per_list), ptr(loss_out), ptr(dp), stream())

@@ -2083,12 +2083,16 @@ def x6_adversarial():
     random-walk level of K fp32 roundings, below which one kernel's rounding pattern against another's is noise (at K = 64
     both errors are ~1e-7 = two ulps of the terms).
     Asserted on all three classes, both kernels: the a-priori bound of an fp32 chain, K 2^-24 of the terms (GEMM).
-    The worst-split class is REPORTED, not held to the 1.25: with every operand carrying the same low bits, rounding errors
-    and dropped terms add coherently instead of as a random walk, in whichever kernel the pattern happens to hit - the f32
-    MFMA chain on `ones` (K = 1,228,800: 1.8e-5 against 5e-7), the six-product kernels on `worst-split` (1.6e-5 against
-    9e-7); the worst over the three classes is the same for both (profiles/r04_notes.md has the table).  In attention the
-    coherent part of dP survives the subtraction of delta = rowsum(dO o O) and is amplified by the conditioning of these
-    all-positive problems: dQ / dK of worst-split are 4-8x the f32 kernels' there (both at 1e-4 .. 3e-3 of the gradient).
+    The worst-split class: with every operand carrying the same low bits, the ROUNDINGS of the (identical) small plane products
+    into one large running sum all go the same way - a coherent drift instead of a random walk, in whichever kernel the
+    pattern happens to hit: the f32 MFMA chain on `ones` (K = 1,228,800: 1.8e-5 against 5e-7), the six-product kernels on
+    `worst-split` (1.6e-5 against 9e-7); the worst over the three classes is the same for both in the GEMM family.  It is NOT
+    the dropped m l' + l m' terms: round 5 measured eight-product contractions (dP; S; the list-contracted outputs; the
+    forward) - errors identical to four digits (profiles/r05_notes.md).  What closes it is keeping the five small products of
+    the list-contracted outputs (O, dQ, dK, dV) in an accumulator of their own, added to the h h' accumulator once at the end:
+    the head-dim-16 kernels (csrc/attention6n.hip) do, and sit at 0.25-1.1 of the f32 kernels' error on EVERY class - held to
+    the 1.25 here, worst-split included.  The head-dim-64 kernels have no registers for a second accumulator set: dQ / dK of
+    worst-split are 4-8x the f32 kernels' there (both at 1e-4 .. 3e-3 of the gradient), bounded at 10x here.
     The mode is an argument of each call here (ops.precision): the two run side by side in one process."""
     def both(fn):
         outs = {}
@@ -2105,8 +2109,18 @@ def x6_adversarial():
         ratio = e6 / max(e32, 1e-300)
         summary.append((name, tag, e32, e6, ratio))
         print(f"     {name} {tag}: err f32-MFMA {e32:.3e}, bf16x6 {e6:.3e}, ratio {ratio:.2f}", flush=True)
-        if tag != "worst-split":
-            report(f"x6 adversarial {name} {tag}: err_x6 <= 1.25 err_f32mfma + sqrt(K) 2^-25", e6, 1.25 * e32 + math.sqrt(K) * 2.0 ** -25)
+        # additive floor: half the random-walk level of K fp32 roundings, but never more than twice the f32 kernel's own error
+        # (at K = 1,228,800 sqrt(K) 2^-25 alone would exceed every measured error: VERDICT r04 weak item 2), plus 2^-27 of the
+        # term scale for the plane products the mode drops by construction (documented: < 2^-23 worst, 2^-29 typical - it shows
+        # where exact pairwise cancellation makes the f32 chain's own error vanish: `cancel` at K = 1,228,800, 1.2e-9 vs 7e-11)
+        floor = min(math.sqrt(K) * 2.0 ** -25, 2.0 * e32) + 2.0 ** -27
+        # worst-split: asserted like the other classes where the kernels keep the small plane products in an accumulator of their
+        # own (list attention at head dim 16, csrc/attention6n.hip); bounded at 10x elsewhere (coherent ROUNDING of the small
+        # products into one large running sum: see the docstring)
+        if tag != "worst-split" or (name.startswith("attn") and "hd16" in name):
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 1.25 err_f32mfma + min(sqrt(K) 2^-25, 2 err_f32mfma) + 2^-27", e6, 1.25 * e32 + floor)
+        elif name.startswith("attn"):
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 10 err_f32mfma (coherent class, one accumulator)", e6, 10.0 * e32)
         if apriori:
             report(f"x6 adversarial {name} {tag}: bf16x6 within the fp32-chain a-priori bound K 2^-24", e6, K * 2.0 ** -24)
             report(f"x6 adversarial {name} {tag}: f32 MFMA within the fp32-chain a-priori bound K 2^-24", e32, K * 2.0 ** -24)
@@ -2188,7 +2202,14 @@ def x6_adversarial():
         print(f"     worst over classes {n}: f32-MFMA {w32:.3e}, bf16x6 {w6:.3e}, ratio {w6 / max(w32, 1e-300):.2f}", flush=True)
         if n.startswith("gemm"):
             K = int(n.split("x")[-1])
-            report(f"x6 adversarial {n}: worst class of bf16x6 <= 1.25 x worst class of the f32 MFMA + sqrt(K) 2^-25", w6, 1.25 * w32 + math.sqrt(K) * 2.0 ** -25)
+            report(f"x6 adversarial {n}: worst class of bf16x6 <= 1.25 x worst class of the f32 MFMA + min(sqrt(K) 2^-25, 2 x it)", w6,
+                   1.25 * w32 + min(math.sqrt(K) * 2.0 ** -25, 2.0 * w32))
+        elif " out" in n or " dv" in n or "hd16" in n:
+            # attention: the same worst-class-vs-worst-class statement - every output at head dim 16 (two accumulators), O and dV
+            # at head dim 64 (dQ / dK there inherit the coherent rounding through delta = rowsum(dO o O) and dS = P (dP - delta))
+            B_ = int(n.split()[1][1:])
+            report(f"x6 adversarial {n}: worst class of bf16x6 <= 1.5 x worst class of the f32 MFMA + min(sqrt(B) 2^-25, 2 x it)", w6,
+                   1.5 * w32 + min(math.sqrt(B_) * 2.0 ** -25, 2.0 * w32))
 
 
 @section
