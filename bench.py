@@ -344,18 +344,27 @@ def main():
         torch.cuda.synchronize()
 
     def timed(n_steps):
-        """n_steps steps bracketed by barrier + synchronize on both sides; (max-over-ranks seconds, last state)."""
+        """n_steps steps bracketed by barrier + synchronize on both sides; (max-over-ranks seconds, last state, per-step HIP-event
+        statistics).  The wall clock around the loop is the contract's number (`ms_per_step`, `value`); SURVEY.md 8(d)'s protocol
+        - median of >= 20 hipEvent-timed steps - rides along: an event pair per step on the launch stream (the library launches
+        on torch's current stream), median / mean / min over the steps, max over ranks of each."""
         fence()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
         t0 = time.perf_counter()
-        for _ in range(n_steps):
+        for i in range(n_steps):
+            evs[i][0].record()
             state = step()
+            evs[i][1].record()
         fence()
         elapsed = time.perf_counter() - t0
+        per = sorted(a.elapsed_time(b) for a, b in evs)
+        stats = [per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]), sum(per) / len(per), per[0]]
         if use_dist:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            tmax = torch.tensor([elapsed] + stats, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
-        return elapsed, state
+            elapsed, stats = float(tmax[0].item()), [float(v) for v in tmax[1:]]
+        return elapsed, state, {"median_ms": round(stats[0], 3), "mean_ms": round(stats[1], 3), "min_ms": round(stats[2], 3), "steps": n_steps,
+                                "timer": "HIP events on the launch stream, one pair per step (max over ranks)"}
 
     def kernel_times(n_steps):
         """HIP-event times (on the launch stream) of the three list-attention launches of REAL training steps, taken
@@ -391,13 +400,13 @@ def main():
             torch.cuda.synchronize()
             if rank == 0:
                 print(f"[bench] {mode}: warm-up step {i + 1}/{n_warm} done", file=sys.stderr, flush=True)
-        elapsed, state = timed(n_steps)
+        elapsed, state, ev_stats = timed(n_steps)
         vals = check_state(state, f"{n_steps} timed {mode} steps")
         if rank == 0:
             print(f"[bench] {mode}: {n_steps} timed steps, {elapsed / n_steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
         ksum = kernel_times(len(batches) * 3)
         return {"mode": mode, "steps": n_steps, "elapsed": elapsed, "ms_per_step": elapsed / n_steps * 1e3,
-                "value": B * world * n_steps / elapsed, "state": vals, "ksum": ksum}
+                "value": B * world * n_steps / elapsed, "state": vals, "ksum": ksum, "ev_stats": ev_stats}
 
     def roofline_block(res):
         """Dominant launch of the step: the attention dK/dV backward (one rlt_list_attention_bwd_dkv call).
@@ -413,8 +422,12 @@ def main():
         if x6_attn:                               # six bf16 MFMA products per fp32 product: peak 2500 / 6
             img_tag = "true" if os.environ.get("RLT_ATTN6_IMG", "0") not in ("", "0") else "false"     # staged from tile images?
             kern, mult, peak = f"attn6_bwd_dkv_kernel<{hd},{drop_tag},{img_tag}>", 6, PEAK_BF16_MFMA_TFLOPS
-            if hd == 64 and os.environ.get("RLT_A6_DKV1", "1") != "0":       # head dim 64: the one-wavefront-per-SIMD form
+            # head dim 64: the one-wavefront-per-SIMD form, under the same condition as attn6_launch (csrc/attention6.hip): its
+            # loaders form B * ld in 24-bit multiplies
+            if hd == 64 and os.environ.get("RLT_A6_DKV1", "1") != "0" and B * 3 * heads_ * hd < (1 << 24):
                 kern = f"attn6_bwd_dkv1_kernel<{drop_tag}>"
+            if hd == 16 and os.environ.get("RLT_A6N", "1") != "0" and img_tag == "false":       # head dim 16: the 16x16x32 kernels (csrc/attention6n.hip)
+                kern = f"attn6n_bwd_dkv_kernel<2,{drop_tag}>"
         elif mode in ("fp32", "bf16x6"):          # (bf16x6 with RLT_ATTN6=0: the exact-fp32 kernels)
             kern, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 1, PEAK_F32_MFMA_TFLOPS
         else:
@@ -490,7 +503,8 @@ def main():
         out = {
             "metric": "ranked-lists/sec (fwd+bwd) at len=300; F1@k vs CPU ref",
             "value": round(main_res["value"], 2), "unit": "lists/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(main_res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(main_res["ms_per_step"], 3), "step_hip_events": main_res["ev_stats"],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPES[precision], "precision_mode": precision,
             "data": "synthetic",
             "config": {"workload": f"{wl}, batch {B} lists/GPU x len {S}, "
@@ -505,7 +519,8 @@ def main():
             m = res["mode"]
             out[BLOCK[m]] = {
                 "dtype": DTYPES[m], "precision_mode": m, "steps": res["steps"],
-                "ms_per_step": round(res["ms_per_step"], 3), "value": round(res["value"], 2), "unit": "lists/s",
+                "ms_per_step": round(res["ms_per_step"], 3), "step_hip_events": res["ev_stats"],
+                "value": round(res["value"], 2), "unit": "lists/s",
                 "roofline": roofline_block(res),
                 "train_state": dict(zip(("loss", "f1", "dcg"), (round(v, 6) for v in res["state"]))),
                 "note": NOTES[m]}

@@ -862,9 +862,10 @@ def scale_models():
         loss_h = make_criterion(hl, cname, case)(out_h, y.to(dev))
         loss_h.backward()
         # un-aligned oracle first: its outputs, loss and cut positions are THE reference; its gradients the printed
-        # diagnostic (bf16x3 mode only: the second oracle backward doubles the CPU time of the section)
+        # diagnostic (bf16x3 and the default bf16x6 mode: the second oracle backward doubles the CPU time of the section, the
+        # exact-fp32 mode goes without)
         plain = None
-        if bf:
+        if bf or N.get_precision() == "bf16x6":
             out_r = ref(x)
             loss_r = make_criterion(ol, cname, case)(out_r, y)
             loss_r.backward()
@@ -1354,6 +1355,70 @@ def full_size_models():
         del res, pa, pb, ga, gb, pc, gc
         torch.cuda.empty_cache()
 
+
+
+@section
+def full_size_oracle():
+    """BASELINE configs[1] AT FULL SIZE against the oracle, directly ("F1@k vs CPU ref"): AttnCut forward on the
+    4096 x 300 benchmark batch (bench.synth_batch, seed 20240) + DivLoss(js, f1, augmented) + the cut metrics, HIP (the
+    process's precision mode; the test runs it in the default bf16x6) against the CPU oracle's forward pass on the same
+    weights and inputs: max |dp| <= 1e-4 (the bound BASELINE.json states), identical cut positions outside the (counted)
+    knife-edge lists, |dF1|, |dDCG|, |dloss| <= 1e-4.  The oracle's encoder layer runs over the position axis in chunks: its
+    list-axis attention, FFN and norms treat the positions independently, so chunking changes nothing
+    but the size of the 4096 x 4096 score matrices held at once."""
+    import bench
+    import models as hm
+    from oracle import losses as ol, metrics as omet, models as om
+    from oracle.weights import fill_state_dict
+    from utils import losses as hl
+    from utils.metrics import Metric
+    Bq, S = 4096, 300
+    t0 = time.time()
+    xg, yg = bench.synth_batch(Bq, S, 3, 20240, dev)
+    ref = om.AttnCut(dropout=0.0)
+    fill_state_dict(ref, 55)
+    hip = hm.AttnCut(dropout=0.0)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    hip.train()
+    with torch.no_grad():
+        p_h = hip(xg)
+        loss_h = hl.DivLoss(metric='f1', div_type='js', augmented=True)(p_h, yg)
+        k_h, f1_h, dcg_h = Metric.evaluate(p_h, yg)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    x, y = xg.cpu(), yg.cpu()
+    try:
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    except AttributeError:
+        pass
+    ref.train()
+    t0 = time.time()
+    with torch.no_grad():
+        h = ref.encoding_layer(x)[0]
+        enc = torch.cat([ref.attention_layer(h[:, s0:s0 + 12].contiguous()) for s0 in range(0, S, 12)], dim=1)
+        p_r = ref.decison_layer(enc)
+        loss_r = ol.DivLoss(metric='f1', div_type='js', augmented=True)(p_r, y)
+    t_cpu = time.time() - t0
+    p_r2 = p_r.squeeze(2)
+    report("full_size_oracle attncut_b4096_s300 p max|d| (BASELINE bound 1e-4)", float((p_h.squeeze(2).cpu() - p_r2).abs().max()), 1e-4)
+    report("full_size_oracle attncut_b4096_s300 p relative", rel(p_h.squeeze(2), p_r2), 2e-4)
+    k_r = omet.cut_positions(p_r2.numpy())
+    k_hn = k_h.cpu().numpy()
+    top2 = torch.topk(p_r2, 2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]).numpy()
+    differ = k_hn != k_r
+    report("full_size_oracle attncut_b4096_s300 k mismatches outside knife-edge lists (gap >= 4e-6)", float((differ & (gap >= 4e-6)).sum()), 0)
+    report(f"full_size_oracle attncut_b4096_s300 k mismatches on knife-edge lists (of {int((gap < 4e-6).sum())})", float(differ.sum()),
+           float((gap < 4e-6).sum()))
+    f1_r, dcg_r = omet.Metric.f1(y.numpy(), k_r), omet.Metric.dcg(y.numpy(), k_r)
+    report("full_size_oracle attncut_b4096_s300 |dF1| vs the oracle's own cut positions", abs(float(f1_h) - f1_r), 1e-4)
+    report("full_size_oracle attncut_b4096_s300 |dDCG| vs the oracle's own cut positions", abs(float(dcg_h) - dcg_r) / max(1.0, abs(dcg_r)), 1e-4)
+    report("full_size_oracle attncut_b4096_s300 |dloss|", abs(float(loss_h) - float(loss_r)) / max(1.0, abs(float(loss_r))), 1e-4)
+    print(f"   (full_size_oracle: HIP {t_hip:.1f} s incl. data, oracle forward {t_cpu:.1f} s on {torch.get_num_threads()} threads; "
+          f"F1 {float(f1_h):.6f} / {f1_r:.6f}, DCG {float(dcg_h):.5f} / {dcg_r:.5f}, loss {float(loss_h):.6e} / {float(loss_r):.6e})", flush=True)
+    del hip, p_h
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1855,7 +1920,7 @@ def path_level():
 
 
 def _trainer_dp_case(tag, model_name, extra_argv, make_ref, make_crit, ckpt_name, port, lengths=(300,), n_train=11, n_test=5,
-                     epochs=3, bs=4):
+                     epochs=3, bs=4, world=2):
     """run.py under torch.distributed with TWO ranks (both on this GPU, gloo - the rehearsal form) against the shard-wise
     reference semantics written with the CPU oracle: every batch is cut by shard_bounds (ragged
     tails and EMPTY shards included), each shard is one reference computation - its own list-axis attention, its own
@@ -1868,7 +1933,7 @@ def _trainer_dp_case(tag, model_name, extra_argv, make_ref, make_crit, ckpt_name
     from oracle import metrics as omet
     from oracle.weights import fill_state_dict
     from rlt_hip.parallel import shard_bounds
-    LR, WD, SEED, WORLD = 1e-4, 0.0025, 7, 2
+    LR, WD, SEED, WORLD = 1e-4, 0.0025, 7, world
     run_py = os.path.join(REPO, "ranked-list-truncation_amd", "run.py")
     with tempfile.TemporaryDirectory() as tmp:
         write_synthetic_robust04(tmp, "robust04", "drmm_tks", n_train=n_train, n_test=n_test, seq_len=300, seed=9,
@@ -1886,15 +1951,15 @@ def _trainer_dp_case(tag, model_name, extra_argv, make_ref, make_crit, ckpt_name
                "--seed", str(SEED), "--ft", "1", "--model-path", os.path.join(ck, ckpt_name), "--history-json", hist,
                "--param-dump-dir", dump, "--tensorboard-dir", ""] + list(extra_argv)
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        report(f"{tag}: 2-rank run.py exit status", float(res.returncode), 0)
+        report(f"{tag}: {WORLD}-rank run.py exit status", float(res.returncode), 0)
         if res.returncode != 0:
             print(res.stderr[-3000:])
             return
         got = json.load(open(hist))
         report(f"{tag}: world size seen by the Trainer", abs(got["world"] - WORLD), 0)
-        p0, p1 = (np.load(os.path.join(dump, f"flat_param_rank{r}.npy")) for r in range(WORLD))
-        report(f"{tag}: the two replicas' parameter buckets after training, bitwise (elements differing)",
-               float((p0.view(np.uint32) != p1.view(np.uint32)).sum()), 0)
+        ps = [np.load(os.path.join(dump, f"flat_param_rank{r}.npy")) for r in range(WORLD)]
+        report(f"{tag}: the {WORLD} replicas' parameter buckets after training, bitwise (elements differing from rank 0's)",
+               float(sum((ps[0].view(np.uint32) != q.view(np.uint32)).sum() for q in ps[1:])), 0)
         # ---- shard-wise reference on the oracle
         opt = torch.optim.Adam(ref.parameters(), lr=LR, weight_decay=WD)
         crit = make_crit()
@@ -1906,8 +1971,12 @@ def _trainer_dp_case(tag, model_name, extra_argv, make_ref, make_crit, ckpt_name
         shapes = []
 
         def batch(x, y, train):
+            """-> (loss, F1, DCG means of the batch, slack): slack = what the knife-edge lists of the batch (top-2 gap < 4e-6 in
+            the oracle's own output: their cut position is a coin toss in fp32) can move the F1 / DCG means by - per LIST, the
+            difference between the metric at the best and at the second-best position, nothing else is exempted"""
             n = x.shape[0]
             tot = np.zeros(3)
+            slack = np.zeros(2)
             if train:
                 opt.zero_grad()
                 shapes.append((int(x.shape[1]), tuple(shard_bounds(n, r, WORLD)[1] - shard_bounds(n, r, WORLD)[0] for r in range(WORLD))))
@@ -1920,37 +1989,46 @@ def _trainer_dp_case(tag, model_name, extra_argv, make_ref, make_crit, ckpt_name
                 if train:
                     (loss * ((hi - lo) / n)).backward()
                 p = (out[-1] if isinstance(out, (list, tuple)) else out).detach().squeeze(2)
-                top2 = torch.topk(p, 2, dim=1).values
-                edge[0] += int(((top2[:, 0] - top2[:, 1]) < 4e-6).sum())      # cut position a coin toss in fp32
+                top2 = torch.topk(p, 2, dim=1)
                 k = omet.cut_positions(p.numpy())
-                tot += (hi - lo) * np.array([loss.item(), omet.Metric.f1(y[lo:hi].numpy(), k), omet.Metric.dcg(y[lo:hi].numpy(), k)])
+                yy = y[lo:hi].numpy()
+                for i in torch.nonzero((top2.values[:, 0] - top2.values[:, 1]) < 4e-6).flatten().tolist():
+                    edge[0] += 1
+                    k_alt = np.array([int(top2.indices[i, 1]) + 1 if int(top2.indices[i, 0]) + 1 == k[i] else int(top2.indices[i, 0]) + 1])
+                    slack += [abs(omet.Metric.f1(yy[i:i + 1], k[i:i + 1]) - omet.Metric.f1(yy[i:i + 1], k_alt)),
+                              abs(omet.Metric.dcg(yy[i:i + 1], k[i:i + 1]) - omet.Metric.dcg(yy[i:i + 1], k_alt))]
+                tot += (hi - lo) * np.array([loss.item(), omet.Metric.f1(yy, k), omet.Metric.dcg(yy, k)])
             if train:
                 opt.step()
-            return tot / n
+            return tot / n, slack / n
 
         for e in range(epochs):
             rows_by = {}
             ref.train()
             edge[0] = 0
-            rows_by["train"] = (np.mean([batch(x, y, True) for x, y in tr], axis=0), edge[0])
+            rows = [batch(x, y, True) for x, y in tr]
+            rows_by["train"] = (np.mean([r_[0] for r_ in rows], axis=0), np.mean([r_[1] for r_ in rows], axis=0), edge[0])
             ref.eval()
             edge[0] = 0
             with torch.no_grad():
-                rows_by["test"] = (np.mean([batch(x, y, False) for x, y in te], axis=0), edge[0])
-            for split, (want, n_edge) in rows_by.items():
+                rows = [batch(x, y, False) for x, y in te]
+            rows_by["test"] = (np.mean([r_[0] for r_ in rows], axis=0), np.mean([r_[1] for r_ in rows], axis=0), edge[0])
+            for split, (want, slack, n_edge) in rows_by.items():
                 g = np.array(got["history"][e][split])
                 report(f"{tag} epoch {e} {split} loss", abs(g[0] - want[0]) / max(1.0, abs(want[0])), 1e-4)
-                if n_edge == 0:
-                    report(f"{tag} epoch {e} {split} F1/DCG", float(np.abs(g[1:] - want[1:]).max() / max(1.0, np.abs(want[1:]).max())), 1e-4)
-                else:
-                    print(f"   ({tag} epoch {e} {split}: {n_edge} knife-edge lists (top-2 gap < 4e-6 in the oracle): F1/DCG means differ by "
-                          f"{float(np.abs(g[1:] - want[1:]).max()):.2e}, not asserted)", flush=True)
+                # F1 / DCG means: 1e-4 plus exactly what the epoch's knife-edge lists can account for
+                for j, nm in ((1, "F1"), (2, "DCG")):
+                    report(f"{tag} epoch {e} {split} {nm}" + (f" ({n_edge} knife-edge lists: + {slack[j - 1]:.1e})" if n_edge else ""),
+                           abs(g[j] - want[j]) / max(1.0, abs(want[j])), 1e-4 + slack[j - 1] / max(1.0, abs(want[j])))
         if len(lengths) > 1:
             seen = sorted({s for s, _ in shapes})
             report(f"{tag}: every length bucket was trained on by both ranks in lock-step (lengths seen {seen})",
                    0.0 if seen == sorted(lengths) else 1.0, 0)
-        ragged = [sh for _, sh in shapes if sh[0] != sh[1]]
+        ragged = [sh for _, sh in shapes if len(set(sh)) > 1]
         report(f"{tag}: the schedule holds ragged shards ({len(ragged)} of {len(shapes)} train batches)", 0.0 if ragged else 1.0, 0)
+        if WORLD > 2:
+            empty = [sh for _, sh in shapes if 0 in sh]
+            report(f"{tag}: ... and EMPTY shards ({len(empty)} of {len(shapes)} train batches)", 0.0 if empty else 1.0, 0)
 
 
 @section
@@ -2306,7 +2384,7 @@ def determinism():
 
 
 @section
-def bench_two_ranks():
+def _bench_ranks(world, batch, tag):
     """`bench.py --gpus 2` end to end: the parent never touches the GPU and starts its own two ranks under
     torch.distributed.run (spawn_ranks); here both ranks share this box's one GPU over gloo (RLT_DIST_BACKEND=gloo
     RLT_BENCH_DEVICE=0 - the rehearsal form; the driver's 8-GPU run uses one GPU per rank over RCCL).  Asserted: exit status,
@@ -2315,32 +2393,57 @@ def bench_two_ranks():
     import json
     import subprocess
     bench_py = os.path.join(REPO, "bench.py")
-    steps, batch = 3, 96
+    steps = 3
     env = dict(os.environ, RLT_DIST_BACKEND="gloo", RLT_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    res = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--batch", str(batch), "--steps", str(steps), "--warmup", "1",
+    res = subprocess.run([sys.executable, bench_py, "--gpus", str(world), "--batch", str(batch), "--steps", str(steps), "--warmup", "1",
                           "--other-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
-    report("bench --gpus 2: exit status", float(res.returncode), 0)
+    report(f"{tag}: exit status", float(res.returncode), 0)
     lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
-    report("bench --gpus 2: exactly one JSON line on stdout", abs(len(lines) - 1), 0)
+    report(f"{tag}: exactly one JSON line on stdout", abs(len(lines) - 1), 0)
     if res.returncode or len(lines) != 1:
         print(res.stdout[-1500:], res.stderr[-3000:])
         return
     d = json.loads(lines[0])
-    report("bench --gpus 2: n_gpus == 2", abs(d["n_gpus"] - 2), 0)
-    report("bench --gpus 2: collective.ranks == 2", abs((d["collective"] or {}).get("ranks", 0) - 2), 0)
-    report("bench --gpus 2: collective.backend == gloo (rehearsal)", 0.0 if (d["collective"] or {}).get("backend") == "gloo" else 1.0, 0)
-    report("bench --gpus 2: config.global_batch == 2 x 96", abs(d["config"]["global_batch"] - 2 * batch), 0)
-    report("bench --gpus 2: config.parallelism == dp2", 0.0 if d["config"]["parallelism"] == "dp2" else 1.0, 0)
-    report("bench --gpus 2: scaling == weak", 0.0 if d["scaling"] == "weak" else 1.0, 0)
+    report(f"{tag}: n_gpus == world", abs(d["n_gpus"] - world), 0)
+    report(f"{tag}: collective.ranks == world", abs((d["collective"] or {}).get("ranks", 0) - world), 0)
+    report(f"{tag}: collective.backend == gloo (rehearsal)", 0.0 if (d["collective"] or {}).get("backend") == "gloo" else 1.0, 0)
+    report(f"{tag}: config.global_batch == world x batch", abs(d["config"]["global_batch"] - world * batch), 0)
+    report(f"{tag}: config.parallelism == dp<world>", 0.0 if d["config"]["parallelism"] == f"dp{world}" else 1.0, 0)
+    report(f"{tag}: scaling == weak", 0.0 if d["scaling"] == "weak" else 1.0, 0)
     elapsed = d["ms_per_step"] * 1e-3 * steps
-    report("bench --gpus 2: value == global batch x steps / elapsed", abs(d["value"] - 2 * batch * steps / elapsed) / d["value"], 1e-3)
-    report("bench --gpus 2: hbm_kernel is None (single-GPU block)", 0.0 if d.get("hbm_kernel") is None else 1.0, 0)
-    report("bench --gpus 2: no cpu_baseline block off rank-0-at-N=1", 0.0 if "cpu_baseline" not in d else 1.0, 0)
+    report(f"{tag}: value == global batch x steps / elapsed", abs(d["value"] - world * batch * steps / elapsed) / d["value"], 1e-3)
+    report(f"{tag}: hbm_kernel is None (single-GPU block)", 0.0 if d.get("hbm_kernel") is None else 1.0, 0)
+    report(f"{tag}: no cpu_baseline block off rank-0-at-N=1", 0.0 if "cpu_baseline" not in d else 1.0, 0)
     vals = [d["train_state"][k] for k in ("loss", "f1", "dcg")]
-    report("bench --gpus 2: finite training state", 0.0 if all(math.isfinite(v) for v in vals) else 1.0, 0)
-    report("bench --gpus 2: headline precision is the library default bf16x6", 0.0 if d.get("precision_mode") == "bf16x6" else 1.0, 0)
+    report(f"{tag}: finite training state", 0.0 if all(math.isfinite(v) for v in vals) else 1.0, 0)
+    report(f"{tag}: headline precision is the library default bf16x6", 0.0 if d.get("precision_mode") == "bf16x6" else 1.0, 0)
+    ev = d.get("step_hip_events") or {}
+    report(f"{tag}: per-step HIP-event statistics present (median <= mean x 1.5, min <= median)",
+           0.0 if ev and ev["min_ms"] <= ev["median_ms"] <= 1.5 * ev["mean_ms"] else 1.0, 0)
+
+
+@section
+def bench_two_ranks():
+    _bench_ranks(2, 96, "bench --gpus 2")
+bench_two_ranks.__doc__ = _bench_ranks.__doc__
+
+
+@section
+def dp_five_ranks():
+    """Many-rank rehearsal: the driver's 8-GPU run starts 8 ranks; a one-GPU box of this pool admits at
+    most SIX processes on the card (the pool's process guard) and this probe process is one of them, so the rehearsal runs
+    the largest world that is allowed here - `bench.py --gpus 5 --batch 32` (its own torch.distributed.run child, five gloo
+    ranks sharing this GPU: LOCAL_RANK 0..4, the MAX all-reduce of the timings over five ranks, global batch 160) and run.py
+    MMOECut(4 experts, tasks 2.1) under five ranks with batches of 4 lists (shards 1,1,1,1,0: ragged AND empty shards every
+    step), replicas bitwise equal.  World size 8 itself is covered on the CPU (tests/test_parallel_gloo.py: eight gloo
+    ranks, gradient average against the shard-wise oracle, empty shards)."""
+    from oracle import losses as ol, models as om
+    _bench_ranks(5, 32, "bench --gpus 5")
+    _trainer_dp_case("dp_five_ranks mmoecut(4e,2.1)", "mmoecut", ["--num-experts", "4", "--num-tasks", "2.1"],
+                     lambda: om.MMOECut(seq_len=300, num_experts=4, num_tasks=2.1, input_size=3, dropout=0.0),
+                     lambda: ol.MtCutLoss(metric="f1", num_tasks=2.1), "mmoecut.pkl", 29741, epochs=1, world=5)
 
 
 if __name__ == "__main__":
