@@ -25,6 +25,7 @@
 // operand of the next product: k slot (g, j) <-> tile row 16 (j >> 2) + 4 g + (j & 3), and the transposed reads deliver the A
 // operand in exactly that order (block rows 4 g .. 4 g + 3 and + 16).
 #include "attention_common.h"
+#include "split6.h"
 #include <stdlib.h>
 
 #ifndef RLT_A6N_NB
@@ -635,10 +636,283 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ dQ / dK+dV: one wavefront per SIMD
+// The two-wavefront kernels above leave the matrix pipe half idle: a wavefront's vector work (exp2, P dP, the conversions) and
+// its MFMAs depend on each other step by step, and a SIMD's second wavefront does not fill the holes - its own stream has the same
+// shape, and the times ADD (ablations in profiles/r05_notes.md: element-wise work 40 % of the dQ kernel's time, every MFMA group
+// its full matrix time on top).  Here ONE 256-thread workgroup per CU owns 256 of its own rows (a wavefront 64 = four blocks of
+// 16), and the tile body is a SOFTWARE PIPELINE over items (a 32-row block of the tile x one own block = 512 scores): in slot s the
+// wavefront issues the row products of item s, the matrix-pipe residuals of item s - 2 and the output products of item s - 3,
+// every MFMA followed by a fenced gap that holds <= ~8 cycles of the vector work of items s - 1 .. s - 3 (what a 16x16x32 MFMA
+// hides: tools/micro/mfma16_gap.hip), the LDS fragment reads of the next 32-row block and the staging of the next tile - placed
+// by tools/gen_attn6n_body.py (dependences, register-ring hazards and operand margins checked at generation time).  The pipeline
+// runs ACROSS tile boundaries (tiles of 128 rows, double-buffered images, one barrier per tile; every LDS read of a tile is
+// issued before the barrier that ends it) and drains on one extra, empty tile (rows beyond B are staged as zeros - in dK+dV with
+// lse = +inf -, so they add nothing: no masks, no special last tile).  No dropout here (train-mode launches take the kernels above).
+#ifndef RLT_A6N_OCC1
+#define RLT_A6N_OCC1 1       // one wavefront per SIMD, 512 registers (compiled with -mllvm -amdgpu-mfma-vgpr-form: rlt_hip/build.py)
+#endif
+constexpr int KTN1 = 128;                   // rows per tile
+constexpr int PLT = KTN1 * 16;              // bf16 elements per plane
+constexpr int IMGT = 3 * PLT;               // ... per image (12 KiB)
+template <bool DKV>
+__global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs a) {
+    constexpr int NB = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][matrix 0 | matrix 1]: dQ: K, V; dK+dV: Q, dO
+    float* tab0 = reinterpret_cast<float*>(img0 + 4 * IMGT);      // dK+dV: [2 buffers][-lse * log2e | -delta][KTN1]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int B = a.B, H = a.H, E = H * 16;
+    const size_t ld = (size_t)3 * E;
+    int pair, rt;
+    map_block(blockIdx.x, a.S * H, rlt_cdiv_dev(B, 256), pair, rt);
+    const int s_ = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s_ * B * ld + h * 16;
+    const float* dobase = a.dout + (size_t)s_ * B * E + h * 16;
+    const float* lsebase = a.lse + ((size_t)s_ * H + h) * B;
+    const float* delbase = a.delta + ((size_t)s_ * H + h) * B;
+    const int row0 = rt * 256 + wv * 64;
+
+    // per-lane constants
+    const int ro = l15 * 16 + 8 * (g & 1);
+    const int offW[3] = {(g < 2 ? 1 : 2) * PLT + ro, (g < 2 ? 0 : 1) * PLT + ro, ro};      // row fragments [m|l], [h|m], [h|h]
+    const int offT = (4 * g + (l15 >> 2)) * 16 + 4 * (l15 & 3);
+    bf16x8 sel[2];
+    {
+        uint32_t s0[2] = {0u, 0u};
+        if ((l15 >> 2) == g) s0[(l15 & 3) >> 1] = (l15 & 1) ? 0xBF800000u : 0x0000BF80u;
+        sel[0] = frag4(s0[0], s0[1], 0u, 0u);
+        sel[1] = frag4(0u, 0u, s0[0], s0[1]);
+    }
+    LaneN c;
+    c.l15 = l15; c.g = g;
+
+    // stationary fragments of the own rows: dQ: Q (scaled) and dO of the queries; dK+dV: K (scaled) and V of the keys
+    bf16x8 amh[NB], alh[NB], bmh[NB], blh[NB];
+    f32x4 seed_s[DKV ? 1 : NB], seed_d[DKV ? 1 : NB];           // dQ: -lse / -delta of the lane's query in all four registers
+    f32x4 acc[DKV ? 2 : 1][NB], acc2[DKV ? 2 : 1][NB];          // dQ: [0] = dQ; dK+dV: [0] = dV, [1] = dK; acc2: the small plane products
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int r = row0 + 16 * n + l15, rc = min(r, B - 1);
+        if (DKV) {
+            own_frags(base + (size_t)rc * ld + E, c, a.scale * LOG2E, amh[n], alh[n]);
+            own_frags(base + (size_t)rc * ld + 2 * E, c, 1.f, bmh[n], blh[n]);
+        } else {
+            own_frags(base + (size_t)rc * ld, c, a.scale * LOG2E, amh[n], alh[n]);
+            own_frags(dobase + (size_t)rc * E, c, 1.f, bmh[n], blh[n]);
+            const float s0 = -lsebase[rc] * LOG2E, d0 = -delbase[rc];
+            seed_s[n] = f32x4{s0, s0, s0, s0};
+            seed_d[n] = f32x4{d0, d0, d0, d0};
+        }
+#pragma unroll
+        for (int w = 0; w < (DKV ? 2 : 1); ++w) {
+            acc[w][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc2[w][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    const int nt = rlt_cdiv_dev(B, KTN1);
+    const float* src0 = DKV ? base : base + E;                  // matrix 0: Q | K
+    const float* src1 = DKV ? dobase : base + 2 * E;            // matrix 1: dO | V
+    const size_t ld1 = DKV ? (size_t)E : ld;
+    const int srow = tid >> 2, sd0 = 4 * (tid & 3);
+    float4 rs[4];                                               // staging units u: matrix u >> 1, rows 64 (u & 1) + srow
+    float rtab = 0.f;                                           // dK+dV: this thread's table entry of the next tile
+    Split6 sg;
+    auto unit_load = [&](int u, int r0) __attribute__((always_inline)) {
+        const int row = r0 + 64 * (u & 1) + srow;
+        const float* sp = (u >> 1) ? src1 : src0;
+        rs[u] = *reinterpret_cast<const float4*>(sp + (size_t)min(row, B - 1) * ((u >> 1) ? ld1 : ld) + sd0);
+    };
+    auto unit_zero = [&](int u, int r0) __attribute__((always_inline)) {
+        const bool ok = r0 + 64 * (u & 1) + srow < B;
+        rs[u] = make_float4(ok ? rs[u].x : 0.f, ok ? rs[u].y : 0.f, ok ? rs[u].z : 0.f, ok ? rs[u].w : 0.f);
+    };
+    auto unit_store = [&](int u, uint16_t* buf) __attribute__((always_inline)) {
+        uint16_t* im = buf + (u >> 1) * IMGT + (64 * (u & 1) + srow) * 16 + sd0;
+        *reinterpret_cast<uint2*>(im) = sg.hi;
+        *reinterpret_cast<uint2*>(im + PLT) = sg.mid;
+        *reinterpret_cast<uint2*>(im + 2 * PLT) = sg.lo;
+    };
+    auto tab_load = [&](int r0) __attribute__((always_inline)) {
+        const int qi = r0 + (tid & (KTN1 - 1)), qc = min(qi, B - 1);
+        const float v = tid < KTN1 ? lsebase[qc] * LOG2E : delbase[qc];
+        rtab = qi < B ? -v : (tid < KTN1 ? -INFINITY : 0.f);      // negated: initial values of the score / dP accumulators
+    };
+    // prologue: tile 0 -> buffer 0
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unit_load(u, 0);
+        unit_zero(u, 0);
+#pragma unroll
+        for (int part = 0; part < 6; ++part) split6_part(sg, rs[u].x, rs[u].y, rs[u].z, rs[u].w, part);
+        unit_store(u, img0);
+    }
+    if (DKV) {
+        tab_load(0);
+        tab0[tid] = rtab;
+    }
+
+    // the pipeline's registers: RING item sets (scores / dP in fp32, the planes of P and dS) and the fragments of the current block
+    f32x4 sc[4][2], dp[4][2];
+    uint32_t pln[2][3][4][4];                                   // [P | dS][h, m, l][ring][dword]
+    bf16x8 fr[2][2][3];                                         // row fragments [matrix][16-row block][which]
+    v4s trf[2][3][2];                                           // transposed fragments [matrix][plane][half]
+    float4 tabv[2][2];                                          // dK+dV: [lse | delta][16-row block] seeds of the block's rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { sc[i][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 2 * 3 * 4 * 4; ++i) (&pln[0][0][0][0])[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) (&fr[0][0][0])[i] = frag4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) (&trf[0][0][0])[i] = v4s{0, 0, 0, 0};
+    tabv[0][0] = tabv[0][1] = tabv[1][0] = tabv[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (int t = 0; t <= nt; ++t) {                             // nt + 1 bodies: the last one drains the pipeline on an empty tile
+        const int cur = t & 1;
+        const uint16_t* Ic = img0 + cur * 2 * IMGT;
+        uint16_t* In = img0 + (cur ^ 1) * 2 * IMGT;
+        const float* Tc = tab0 + cur * 2 * KTN1;
+        float* Tn = tab0 + (cur ^ 1) * 2 * KTN1;
+        const int r_next = (t + 1) * KTN1;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {              // (their only uses are "a" operands: keep them in AGPRs across the back edge)
+            asm volatile("" : "+a"(amh[n]), "+a"(alh[n]), "+a"(bmh[n]), "+a"(blh[n]));
+#pragma unroll
+            for (int w = 0; w < (DKV ? 2 : 1); ++w) asm volatile("" : "+a"(acc[w][n]), "+a"(acc2[w][n]));
+        }
+        asm volatile("" : "+a"(sel[0]), "+a"(sel[1]));
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+        // The MFMAs of the body are asm statements with the accumulator tied in place ("+v"): hipcc's own choice puts the result of
+        // an accumulate somewhere else and reuses the old registers at once - a write-after-read hazard it then pads with s_nop
+        // (80 per tile body).  It sees no MFMA in an asm statement and pads nothing, so the schedule keeps the distances itself
+        // (tools/gen_attn6n_body.py): LAG gaps from an MFMA to the first vector read of its result, MARGIN gaps from a vector /
+        // LDS write of an operand to the MFMA that reads it, and no register of a fragment or tile is rewritten in the gap
+        // behind the MFMA that reads it.  A dependent accumulate straight behind its producer needs no wait states.
+        // Register classes: what the vector ALU touches (score / dP tiles, planes, seeds, staging) in VGPRs; what only MFMAs touch in
+        // AGPRs - the stationary fragments and selection constants ("a" B / A operands), the LDS fragments (read straight into
+        // AGPRs) and the output accumulators (C / D in AGPRs: "+a") - so that nothing is copied between the two halves of the file.
+        auto mma_aa = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {      // tile += A(agpr) B(agpr)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(av), "a"(bv));
+        };
+        auto mma_aa_c = [&](f32x4& d, bf16x8 av, bf16x8 bv, const f32x4& cv) __attribute__((always_inline)) {      // tile = A B + seed
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(av), "a"(bv), "v"(cv));
+        };
+        auto mma_av = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {      // tile += A(agpr) B(vgpr)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(av), "v"(bv));
+        };
+        // (the transposed fragments stay in VGPRs: ds_read_b64_tr_b16 pairs are joined into one operand, and as an "a" operand hipcc
+        // would copy them over with v_accvgpr_write right in front of the MFMA - unpadded in front of an asm statement)
+        auto mma_out = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {     // output accumulator (agpr) += A(vgpr) B(vgpr)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(av), "v"(bv));
+        };
+        auto m_s = [&](int it, int n, int k) __attribute__((always_inline)) {
+            const int kb = k / 3, j = k % 3;
+            if (j == 0) {
+                if (DKV) mma_aa_c(sc[it][kb], fr[0][kb][0], amh[n], f32x4{tabv[0][kb].x, tabv[0][kb].y, tabv[0][kb].z, tabv[0][kb].w});
+                else mma_aa_c(sc[it][kb], fr[0][kb][0], amh[n], seed_s[DKV ? 0 : n]);
+            } else {
+                mma_aa(sc[it][kb], fr[0][kb][j], j == 1 ? alh[n] : amh[n]);
+            }
+        };
+        auto m_d = [&](int it, int n, int k) __attribute__((always_inline)) {
+            const int kb = k / 3, j = k % 3;
+            if (j == 0) {
+                if (DKV) mma_aa_c(dp[it][kb], fr[1][kb][0], bmh[n], f32x4{tabv[1][kb].x, tabv[1][kb].y, tabv[1][kb].z, tabv[1][kb].w});
+                else mma_aa_c(dp[it][kb], fr[1][kb][0], bmh[n], seed_d[DKV ? 0 : n]);
+            } else {
+                mma_aa(dp[it][kb], fr[1][kb][j], j == 1 ? blh[n] : bmh[n]);
+            }
+        };
+        auto plane = [&](int which, int lvl, int it) __attribute__((always_inline)) {
+            return frag4(pln[which][lvl][it][0], pln[which][lvl][it][1], pln[which][lvl][it][2], pln[which][lvl][it][3]);
+        };
+        auto m_r = [&](int it, int which, int level, int kb) __attribute__((always_inline)) {
+            mma_av(which ? dp[it][kb] : sc[it][kb], sel[kb], plane(which, level - 1, it));
+        };
+        auto m_o = [&](int it, int n, int which, int k) __attribute__((always_inline)) {
+            const int ap = k == 0 || k == 3 ? 1 : k == 1 ? 2 : 0, bp = k == 0 || k == 4 ? 1 : k == 2 ? 2 : 0;
+            const int mat = DKV ? (which ? 0 : 1) : 0;          // dQ: K^T; dV: dO^T, dK: Q^T
+            const int w = DKV ? which : 0;
+            typedef short v8s __attribute__((ext_vector_type(8)));
+            const v4s x = trf[mat][ap][0], y = trf[mat][ap][1];
+            const v8s av = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+            mma_out(k < 5 ? acc2[w][n] : acc[w][n], __builtin_bit_cast(bf16x8, av), plane(which, bp, it));
+        };
+        auto e_exp = [&](int it, int kb, int r) __attribute__((always_inline)) { sc[it][kb][r] = rlt_exp2(sc[it][kb][r]); };
+        auto e_mul = [&](int it, int kb, int r) __attribute__((always_inline)) { dp[it][kb][r] *= sc[it][kb][r]; };
+        auto c_pk = [&](int it, int which, int lvl, int j) __attribute__((always_inline)) {
+            const f32x4& tile = which ? dp[it][j >> 1] : sc[it][j >> 1];
+            pln[which][lvl][it][j] = pk2n(tile[2 * (j & 1)], tile[2 * (j & 1) + 1]);
+        };
+        auto rd_row = [&](int mat, int kb, int w, int b32) __attribute__((always_inline)) {
+            fr[mat][kb][w] = *reinterpret_cast<const bf16x8*>(Ic + mat * IMGT + offW[w] + (2 * b32 + kb) * 256);
+        };
+        auto rd_tr = [&](int mat, int pl, int half, int b32) __attribute__((always_inline)) {
+            trf[mat][pl][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (v4s __attribute__((address_space(3)))*)(Ic + mat * IMGT + pl * PLT + offT + b32 * 512 + half * 256));
+        };
+        auto rd_tab = [&](int which, int kb, int b32) __attribute__((always_inline)) {
+            tabv[which][kb] = *reinterpret_cast<const float4*>(Tc + which * KTN1 + b32 * 32 + kb * 16 + 4 * g);
+        };
+        auto st_load = [&](int u) __attribute__((always_inline)) { unit_load(u, r_next); };
+        auto st_split = [&](int u, int part) __attribute__((always_inline)) {
+            if (part == 0) unit_zero(u, r_next);
+            split6_part(sg, rs[u].x, rs[u].y, rs[u].z, rs[u].w, part);
+        };
+        auto st_store = [&](int u) __attribute__((always_inline)) { unit_store(u, In); };
+        auto st_tab_load = [&]() __attribute__((always_inline)) { tab_load(r_next); };
+        auto st_tab_store = [&]() __attribute__((always_inline)) { Tn[tid] = rtab; };
+        if constexpr (DKV) {
+#include "attention6n_dkv1_body.inc"
+        } else {
+#include "attention6n_dq1_body.inc"
+        }
+#undef GAP_END
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int r = row0 + 16 * n + l15;
+        if (r < B) {
+            float* drow = a.dqkv + ((size_t)s_ * B + r) * ld + h * 16 + 4 * g;
+            if (DKV) {
+                const f32x4 dv = acc[0][n] + acc2[0][n], dk = acc[1][n] + acc2[1][n];
+                *reinterpret_cast<float4*>(drow + E) = make_float4(dk[0] * a.scale, dk[1] * a.scale, dk[2] * a.scale, dk[3] * a.scale);
+                *reinterpret_cast<float4*>(drow + 2 * E) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            } else {
+                const f32x4 dq = acc[0][n] + acc2[0][n];
+                *reinterpret_cast<float4*>(drow) = make_float4(dq[0] * a.scale, dq[1] * a.scale, dq[2] * a.scale, dq[3] * a.scale);
+            }
+        }
+    }
+}
+
 template <bool DROP>
 int launch6n(int which, const AttnArgs& a, hipStream_t st) {
     constexpr int NB = RLT_A6N_NB, NBK = RLT_A6N_NBK;
     const size_t shm = (size_t)4 * IMGN * sizeof(uint16_t) + (which == 1 ? 2 * 3 * KT * sizeof(float) : 2 * KT * sizeof(uint32_t));
+    // backward without dropout at 512 lists and more: the one-wavefront pipelined kernels (RLT_A6N_1=0: the kernels above, A/B runs)
+    static const bool one = [] { const char* e = getenv("RLT_A6N_1"); return !e || atoi(e) != 0; }();
+    if (!DROP && one && which != 0 && a.B >= 512) {
+        const size_t shm1 = (size_t)4 * IMGT * sizeof(uint16_t) + (which == 1 ? 2 * 2 * KTN1 * sizeof(float) : 0);
+        const dim3 grid1(a.S * a.H * rlt_cdiv(a.B, 256));
+        int rc;
+        if (which == 1) {
+            if ((rc = rlt_allow_lds(attn6n_bwd1_kernel<true>, shm1))) return rc;
+            hipLaunchKernelGGL((attn6n_bwd1_kernel<true>), grid1, dim3(256), shm1, st, a);
+        } else {
+            if ((rc = rlt_allow_lds(attn6n_bwd1_kernel<false>, shm1))) return rc;
+            hipLaunchKernelGGL((attn6n_bwd1_kernel<false>), grid1, dim3(256), shm1, st, a);
+        }
+        return RLT_LAUNCH_RESULT();
+    }
     if (which == 0)
         hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), dim3(256), shm, st, a);
     else if (which == 1)

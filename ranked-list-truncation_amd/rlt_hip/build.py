@@ -13,7 +13,10 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # per-file extras.  attention6.hip: no SLP packing - v_pk_add_f32 / v_pk_mul_f32 do not run beside a partner wavefront's bf16 MFMAs
 # (tools/micro/mfma_valu_overlap.hip), the unpacked forms do; the exact-fp32 files keep the packing (there every vector instruction
 # adds to the MFMA time, and a packed one does two lanes' work)
-FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"], "attention6n.hip": ["-fno-slp-vectorize"]}
+# attention6n.hip, -amdgpu-mfma-vgpr-form: its one-wavefront kernels own 512 registers, where hipcc would select the AGPR form of every
+# MFMA and move each score register to a VGPR and back around the element-wise work (828 v_accvgpr moves per tile body of the dQ
+# kernel); with the VGPR form the accumulators the vector ALU touches stay where it can reach them
+FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"], "attention6n.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():

@@ -52,8 +52,8 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     precision_argument  two modes side by side in one process through the call argument == the same mode as process default
     determinism  the 4096 x 300 AttnCut and 8192 x 300 Choopy steps twice from one state in each mode: gradient bucket, p, k bitwise
     bench_two_ranks  bench.py --gpus 2 (its own torch.distributed.run child, two gloo ranks on this GPU): the N > 1 JSON line
-    dp_five_ranks  the largest world the box's process guard admits beside the test process: bench.py --gpus 5 --batch 32 and
-                run.py MMOECut(4e, 2.1) under five ranks with ragged and empty shards vs the shard-wise oracle, replicas bitwise equal
+    dp_four_ranks  the largest world the box's process guard admits beside the test process: bench.py --gpus 4 --batch 32 and
+                run.py MMOECut(4e, 2.1) under four ranks with ragged and empty shards vs the shard-wise oracle, replicas bitwise equal
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
     models      all 22 golden model cases: outputs (1e-5), cut positions (identical), F1/DCG (1e-4),
                 every criterion's loss (1e-4), per-parameter gradients (1e-3 of the gradient norm)
@@ -83,7 +83,7 @@ def probe():
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
                   "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging",
-             "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "dp_five_ranks", "trainer_dp_mt"]
+             "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "dp_four_ranks", "trainer_dp_mt"]
 
 
 def _run(probe, name):

@@ -2431,19 +2431,19 @@ bench_two_ranks.__doc__ = _bench_ranks.__doc__
 
 
 @section
-def dp_five_ranks():
+def dp_four_ranks():
     """Many-rank rehearsal: the driver's 8-GPU run starts 8 ranks; a one-GPU box of this pool admits at
-    most SIX processes on the card (the pool's process guard) and this probe process is one of them, so the rehearsal runs
-    the largest world that is allowed here - `bench.py --gpus 5 --batch 32` (its own torch.distributed.run child, five gloo
-    ranks sharing this GPU: LOCAL_RANK 0..4, the MAX all-reduce of the timings over five ranks, global batch 160) and run.py
-    MMOECut(4 experts, tasks 2.1) under five ranks with batches of 4 lists (shards 1,1,1,1,0: ragged AND empty shards every
-    step), replicas bitwise equal.  World size 8 itself is covered on the CPU (tests/test_parallel_gloo.py: eight gloo
-    ranks, gradient average against the shard-wise oracle, empty shards)."""
+    most SIX processes on the card (the pool's process guard: a five-rank attempt was killed at 7 - this probe process and the
+    launcher's parent count too), so the rehearsal runs the largest world that is allowed here - `bench.py --gpus 4 --batch 32`
+    (its own torch.distributed.run child, four gloo ranks sharing this GPU: LOCAL_RANK 0..3, the MAX all-reduce of the timings
+    over four ranks, global batch 128) and run.py MMOECut(4 experts, tasks 2.1) under four ranks with batches of 3 lists
+    (shards 1,1,1,0 and 1,1,0,0: ragged AND empty shards every step), replicas bitwise equal.  World size 8 itself is covered on
+    the CPU (tests/test_parallel_gloo.py: eight gloo ranks, gradient average against the shard-wise oracle, empty shards)."""
     from oracle import losses as ol, models as om
-    _bench_ranks(5, 32, "bench --gpus 5")
-    _trainer_dp_case("dp_five_ranks mmoecut(4e,2.1)", "mmoecut", ["--num-experts", "4", "--num-tasks", "2.1"],
+    _bench_ranks(4, 32, "bench --gpus 4")
+    _trainer_dp_case("dp_four_ranks mmoecut(4e,2.1)", "mmoecut", ["--num-experts", "4", "--num-tasks", "2.1"],
                      lambda: om.MMOECut(seq_len=300, num_experts=4, num_tasks=2.1, input_size=3, dropout=0.0),
-                     lambda: ol.MtCutLoss(metric="f1", num_tasks=2.1), "mmoecut.pkl", 29741, epochs=1, world=5)
+                     lambda: ol.MtCutLoss(metric="f1", num_tasks=2.1), "mmoecut.pkl", 29741, epochs=1, bs=3, world=4)
 
 
 if __name__ == "__main__":
