@@ -427,7 +427,10 @@ def main():
             if hd == 64 and os.environ.get("RLT_A6_DKV1", "1") != "0" and B * 3 * heads_ * hd < (1 << 24):
                 kern = f"attn6_bwd_dkv1_kernel<{drop_tag}>"
             if hd == 16 and os.environ.get("RLT_A6N", "1") != "0" and img_tag == "false":       # head dim 16: the 16x16x32 kernels (csrc/attention6n.hip)
-                kern = f"attn6n_bwd_dkv_kernel<2,{drop_tag}>"
+                seed_tag = "true" if B >= 512 else "false"
+                kern = f"attn6n_bwd_dkv_kernel<2,{drop_tag},{seed_tag}>"
+                if args.dropout == 0 and B >= 512 and os.environ.get("RLT_A6N_1", "1") != "0":     # the pipelined one-wavefront kernel
+                    kern = "attn6n_bwd1_kernel<true>"
         elif mode in ("fp32", "bf16x6"):          # (bf16x6 with RLT_ATTN6=0: the exact-fp32 kernels)
             kern, mult, peak = f"attn_bwd_dkv_kernel<{hd},2,{drop_tag}>", 1, PEAK_F32_MFMA_TFLOPS
         else:

@@ -38,9 +38,10 @@
 #define RLT_A6N_OCC 2       // wavefronts per SIMD the register budget is declared for
 #endif
 
-#ifndef RLT_A6N_SEED
-#define RLT_A6N_SEED 1      // the row / lane constants (-m_run, -lse, -delta) as the INITIAL accumulators of the score / dP products (as attention16.hip): no subtraction per score
-#endif
+// SEED (template parameter of the two-wavefront kernels; the pipelined kernels always): the row / lane constants (-m_run, -lse,
+// -delta) as the INITIAL accumulators of the score / dP products (as attention16.hip) - no subtraction per score.  It rounds every
+// partial sum at the magnitude of the constant: invisible next to the accumulation error of thousands of lists, 2-3x the error
+// of the unseeded form on a few dozen lists (profiles/r05_notes.md) - so launches of fewer than 512 lists run unseeded.
 #ifndef RLT_A6N_2ACC
 #define RLT_A6N_2ACC 1      // 1: the five small plane products of the list-contracted outputs (O, dQ, dK, dV) accumulate in their OWN accumulator, added to the h h' accumulator once at the end
 #endif
@@ -221,7 +222,7 @@ __device__ __forceinline__ float col_sum4(float v) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool SEED>
 __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pe[n][kb][r] = rlt_exp2(RLT_A6N_SEED ? sc[n][kb][r] : sc[n][kb][r] - m_run[n]);
+                            pe[n][kb][r] = rlt_exp2(SEED ? sc[n][kb][r] : sc[n][kb][r] - m_run[n]);
                             psum[n] += pe[n][kb][r];
                         }
                     redo |= !(psum[n] <= 4096.f);
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                             for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[n][kb][r]);
                         tmax = col_max4(tmax);
                         // (seeded: scores are relative to the old reference, d = the move of the reference)
-                        const float mo = RLT_A6N_SEED ? 0.f : m_run[n];
+                        const float mo = SEED ? 0.f : m_run[n];
                         const float m_new = first ? tmax : fmaxf(tmax, mo);
                         const float alpha = first ? 0.f : rlt_exp2(mo - m_new);
                         psum[n] = 0.f;
@@ -332,8 +333,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                                 psum[n] += pe[n][kb][r];
                             }
                         l_run[n] *= alpha;
-                        m_run[n] = RLT_A6N_SEED ? m_run[n] + m_new : m_new;
-                        if (RLT_A6N_SEED) seed[n] = f32x4{-m_run[n], -m_run[n], -m_run[n], -m_run[n]};
+                        m_run[n] = SEED ? m_run[n] + m_new : m_new;
+                        if (SEED) seed[n] = f32x4{-m_run[n], -m_run[n], -m_run[n], -m_run[n]};
                         o[n] *= alpha;
                         if (RLT_A6N_2ACC) o2[n] *= alpha;
                     }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
 
 // ------------------------------------------------------------------------------------------ dQ
 // Keys beyond B: their K and V rows are staged as zeros, so whatever dS they get multiplies a zero column of K^T.
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool SEED>
 __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
         own_frags(a.dout + ((size_t)s * B + qc) * E + h * 16, c, 1.f, dmh[n], dlh[n]);
         lse2[n] = a.lse[((size_t)s * H + h) * B + qc] * LOG2E;
         del[n] = a.delta[((size_t)s * H + h) * B + qc];
-        const float s0 = RLT_A6N_SEED ? -lse2[n] : 0.f, d0 = RLT_A6N_SEED && !DROP ? -del[n] : 0.f;
+        const float s0 = SEED ? -lse2[n] : 0.f, d0 = SEED && !DROP ? -del[n] : 0.f;
         seed_s[n] = f32x4{s0, s0, s0, s0};
         seed_d[n] = f32x4{d0, d0, d0, d0};
         hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)q) : 0u;
@@ -463,10 +464,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (RLT_A6N_ABL & 1) continue;
-                            const float p = rlt_exp2(RLT_A6N_SEED ? sc[kb][r] : sc[kb][r] - lse2[n]);
+                            const float p = rlt_exp2(SEED ? sc[kb][r] : sc[kb][r] - lse2[n]);
                             float dpr = dp[kb][r];
                             if (DROP) dpr = rlt_keep_rc(hq[n], hcs[r], a.drop_thr) ? dpr * inv_keep : 0.f;
-                            dp[kb][r] = RLT_A6N_SEED && !DROP ? p * dpr : p * (dpr - del[n]);     // dS^T
+                            dp[kb][r] = SEED && !DROP ? p * dpr : p * (dpr - del[n]);     // dS^T
                         }
                     }
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
 
 // ------------------------------------------------------------------------------------------ dK, dV
 // Queries beyond B: their Q / dO rows are staged as zeros and their lse entry is +inf, so P = dS = 0.
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool SEED>
 __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][Q image | dO image]
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
             const float l = lsebase[qc], e = delbase[qc];
             rl = qi < B ? l * LOG2E : INFINITY;
             re = qi < B ? e : 0.f;
-            if (RLT_A6N_SEED) { rl = -rl; re = -re; }       // negated: initial values of the score / dP accumulators
+            if (SEED) { rl = -rl; re = -re; }       // negated: initial values of the score / dP accumulators
         }
     };
     auto store_tile = [&](int b, int r0) {
@@ -585,10 +586,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                 for (int n = 0; n < NB; ++n) {
                     f32x4 sc[2], dp[2];
                     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    sc[0] = row_prod(q0, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[0].x, l4[0].y, l4[0].z, l4[0].w} : z4);     // S[q][key] (- lse[q])
-                    sc[1] = row_prod(q1, kmh[n], klh[n], RLT_A6N_SEED ? f32x4{l4[1].x, l4[1].y, l4[1].z, l4[1].w} : z4);
-                    const f32x4 e0 = RLT_A6N_SEED && !DROP ? f32x4{e4[0].x, e4[0].y, e4[0].z, e4[0].w} : z4;
-                    const f32x4 e1 = RLT_A6N_SEED && !DROP ? f32x4{e4[1].x, e4[1].y, e4[1].z, e4[1].w} : z4;
+                    sc[0] = row_prod(q0, kmh[n], klh[n], SEED ? f32x4{l4[0].x, l4[0].y, l4[0].z, l4[0].w} : z4);     // S[q][key] (- lse[q])
+                    sc[1] = row_prod(q1, kmh[n], klh[n], SEED ? f32x4{l4[1].x, l4[1].y, l4[1].z, l4[1].w} : z4);
+                    const f32x4 e0 = SEED && !DROP ? f32x4{e4[0].x, e4[0].y, e4[0].z, e4[0].w} : z4;
+                    const f32x4 e1 = SEED && !DROP ? f32x4{e4[1].x, e4[1].y, e4[1].z, e4[1].w} : z4;
                     dp[0] = row_prod(d0, vmh[n], vlh[n], e0);                             // dP[q][key] (- delta[q])
                     dp[1] = row_prod(d1, vmh[n], vlh[n], e1);
 #pragma unroll
@@ -598,14 +599,14 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                         const uint32_t hrs[4] = {hr[kb].x, hr[kb].y, hr[kb].z, hr[kb].w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float p = rlt_exp2(RLT_A6N_SEED ? sc[kb][r] : sc[kb][r] - ls[r]);
+                            const float p = rlt_exp2(SEED ? sc[kb][r] : sc[kb][r] - ls[r]);
                             if (DROP) {
                                 const float m = rlt_keep_rc(hrs[r], hk[n], a.drop_thr) ? inv_keep : 0.f;
                                 sc[kb][r] = p * m;                                   // dropped P (feeds dV)
-                                dp[kb][r] = RLT_A6N_SEED ? p * (dp[kb][r] * m + es[r]) : p * (dp[kb][r] * m - es[r]);   // dS
+                                dp[kb][r] = SEED ? p * (dp[kb][r] * m + es[r]) : p * (dp[kb][r] * m - es[r]);   // dS
                             } else {
                                 sc[kb][r] = p;
-                                dp[kb][r] = RLT_A6N_SEED ? p * dp[kb][r] : p * (dp[kb][r] - es[r]);
+                                dp[kb][r] = SEED ? p * dp[kb][r] : p * (dp[kb][r] - es[r]);
                             }
                         }
                     }
@@ -652,6 +653,15 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 // lse = +inf -, so they add nothing: no masks, no special last tile).  No dropout here (train-mode launches take the kernels above).
 #ifndef RLT_A6N_OCC1
 #define RLT_A6N_OCC1 1       // one wavefront per SIMD, 512 registers (compiled with -mllvm -amdgpu-mfma-vgpr-form: rlt_hip/build.py)
+#endif
+#ifdef RLT_A6N_STAMPS
+// diagnostic build only: s_memtime at every slot of tiles 8..11 of one workgroup (tools/bench_kernels.py a6n_stamps); entries 16 / 17:
+// before / behind the barrier
+__device__ unsigned long long a6n_stamps[4 * 4 * 18];
+#define A6N_STAMP(k) do { if (blockIdx.x == 64 && lane == 0 && t >= 8 && t < 12) \
+    a6n_stamps[(wv * 4 + (t - 8)) * 18 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define A6N_STAMP(k) do { } while (0)
 #endif
 constexpr int KTN1 = 128;                   // rows per tile
 constexpr int PLT = KTN1 * 16;              // bf16 elements per plane
@@ -738,7 +748,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
     };
     auto tab_load = [&](int r0) __attribute__((always_inline)) {
         const int qi = r0 + (tid & (KTN1 - 1)), qc = min(qi, B - 1);
-        const float v = tid < KTN1 ? lsebase[qc] * LOG2E : delbase[qc];
+        const float* tp = tid < KTN1 ? lsebase : delbase;           // (one load through a selected pointer: no branch in the tile body)
+        float v = tp[qc];
+        asm volatile("" : "+v"(v));                                 // (keeps hipcc from sinking the load into a branch on qi < B, with a vmcnt(0) wait behind it)
+        v *= tid < KTN1 ? LOG2E : 1.f;
         rtab = qi < B ? -v : (tid < KTN1 ? -INFINITY : 0.f);      // negated: initial values of the score / dP accumulators
     };
     // prologue: tile 0 -> buffer 0
@@ -875,7 +888,9 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
 #include "attention6n_dq1_body.inc"
         }
 #undef GAP_END
+        A6N_STAMP(16);
         __syncthreads();
+        A6N_STAMP(17);
     }
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -913,16 +928,28 @@ int launch6n(int which, const AttnArgs& a, hipStream_t st) {
         }
         return RLT_LAUNCH_RESULT();
     }
-    if (which == 0)
-        hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), dim3(256), shm, st, a);
-    else if (which == 1)
-        hipLaunchKernelGGL((attn6n_bwd_dkv_kernel<NBK, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NBK)), dim3(256), shm, st, a);
-    else
-        hipLaunchKernelGGL((attn6n_bwd_dq_kernel<NB, DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), dim3(256), shm, st, a);
+    const bool seed = a.B >= 512;
+    const dim3 gq(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), gk(a.S * a.H * rlt_cdiv(a.B, 64 * NBK));
+    if (which == 0) {
+        if (seed) hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP, true>), gq, dim3(256), shm, st, a);
+        else hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP, false>), gq, dim3(256), shm, st, a);
+    } else if (which == 1) {
+        if (seed) hipLaunchKernelGGL((attn6n_bwd_dkv_kernel<NBK, DROP, true>), gk, dim3(256), shm, st, a);
+        else hipLaunchKernelGGL((attn6n_bwd_dkv_kernel<NBK, DROP, false>), gk, dim3(256), shm, st, a);
+    } else {
+        if (seed) hipLaunchKernelGGL((attn6n_bwd_dq_kernel<NB, DROP, true>), gq, dim3(256), shm, st, a);
+        else hipLaunchKernelGGL((attn6n_bwd_dq_kernel<NB, DROP, false>), gq, dim3(256), shm, st, a);
+    }
     return RLT_LAUNCH_RESULT();
 }
 
 }  // namespace
+
+#ifdef RLT_A6N_STAMPS
+extern "C" int rlt_debug_a6n_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(a6n_stamps), sizeof(unsigned long long) * 4 * 4 * 18);
+}
+#endif
 
 // which = 0 forward, 1 dK/dV, 2 dQ (head dim 16, bf16x6 arithmetic)
 int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st) {

@@ -16,6 +16,8 @@ CASES = [
     (["tools/gen_attn6_body.py", "dq"], "attention6_dq1_body.inc"),
     (["tools/gen_attn6_body.py", "dq", "drop"], "attention6_dq1_body_drop.inc"),
     (["tools/gen_gemm6e_slot.py"], "gemm6e_slot.inc"),
+    (["tools/gen_attn6n_body.py", "dq"], "attention6n_dq1_body.inc"),
+    (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
 ]
 
 
@@ -40,3 +42,48 @@ def test_attention_bodies_cover_every_mfma_once():
         assert [s[1] for s in seen] == [i for _ in range(nstep) for i in range(6)]
         steps = seen[::6]
         assert len(set(steps)) == nstep          # (kind, product 0, block, step in phase) distinct per step
+
+
+def test_attention6n_bodies_cover_every_mfma_and_chunk_once():
+    """The pipelined head-dim-16 bodies: 16 slots of 22 (dQ) / 32 (dK+dV) MFMAs, every (stage, item, index) once; every
+    element-wise chunk, conversion, fragment read and staging call exactly once per tile body."""
+    import re
+    from collections import Counter
+    for inc, per_slot, nconv in (("attention6n_dq1_body.inc", 22, 12), ("attention6n_dkv1_body.inc", 32, 24)):
+        text = open(os.path.join(CSRC, inc)).read()
+        mf = re.findall(r"^(m_[sdro])\(([^)]*)\); GAP_END;", text, flags=re.M)
+        assert len(mf) == 16 * per_slot
+        assert set(Counter(mf).values()) == {4}      # item i and i + 4 share a ring slot and an own-row block: each call 16 / 4 times
+        calls = Counter(re.findall(r"\b([a-z_]+)\(", text))
+        assert calls["e_exp"] == 16 * 8 and calls["e_mul"] == 16 * 8 and calls["c_pk"] == 16 * nconv
+        assert calls["rd_row"] == 4 * 12 and calls["rd_tr"] == 4 * 6 * (2 if per_slot == 32 else 1)
+        assert calls["st_load"] == 4 and calls["st_split"] == 24 and calls["st_store"] == 4
+        # ring-indexed chunks four times per body (once per item of the ring slot), reads and staging calls once
+        ring = Counter(re.findall(r"\b((?:e_exp|e_mul|c_pk)\([^)]*\))", text))
+        assert set(ring.values()) == {4}
+        once = Counter(re.findall(r"\b((?:rd_row|rd_tr|rd_tab|st_load|st_split|st_store)\([^)]*\))", text))
+        assert set(once.values()) == {1}
+
+
+def test_attention6n_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
+    """The MFMAs of the pipelined bodies are asm statements: hipcc pads nothing in front of them, so the tile loop
+    must not contain compiler-made register traffic into their operands - no v_accvgpr_* move and no scratch access inside
+    the loop block, and exactly the generated number of MFMAs.  (A v_accvgpr_write right in front of an asm MFMA is how round 5's
+    first asm build read stale operands.)"""
+    import re
+    import shutil
+    from rlt_hip import build as B
+    if shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "a6n.s"
+    src = os.path.join(CSRC, "attention6n.hip")
+    subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["attention6n.hip"] + ["-S", "--cuda-device-only", src, "-o", str(asm)], check=True,
+                   capture_output=True)
+    text = asm.read_text()
+    for tag, nmf in (("Lb0", 16 * 22), ("Lb1", 16 * 32)):
+        m = re.search(r"^_ZN12_GLOBAL__N_118attn6n_bwd1_kernelI" + tag + r"EEEv8AttnArgs:(.*?)s_endpgm", text, flags=re.S | re.M)
+        assert m, tag
+        blocks = re.split(r"^\.LBB\w+:", m.group(1), flags=re.M)
+        loop = max(blocks, key=lambda b: b.count("v_mfma"))
+        assert loop.count("v_mfma_f32_16x16x32_bf16") == nmf
+        assert "v_accvgpr" not in loop and "scratch_" not in loop

@@ -49,6 +49,9 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
                 2.1 / 2.2) and MtAttnCut(3) on length buckets 100 / 200 / 300 vs the shard-wise oracle; replicas bitwise equal
     x6_adversarial  bf16x6 vs the f32 MFMA kernels on adversarial operands (low significand bits all ones / worst split, one
                 sign; cancelling sums), K = 16 ... 1,228,800, GEMM and attention: err_x6 <= 1.25 err_f32 against fp64
+    x6_fallbacks  the bf16x6 attention forms behind the default dispatch: two-workgroup head-dim-64 backward kernels without image
+                staging, two-wavefront head-dim-16 kernels at scale (child process); the 24-bit row-offset switch-over at
+                B = 21,760 / 21,888 against the exact-fp32 kernels
     precision_argument  two modes side by side in one process through the call argument == the same mode as process default
     determinism  the 4096 x 300 AttnCut and 8192 x 300 Choopy steps twice from one state in each mode: gradient bucket, p, k bitwise
     bench_two_ranks  bench.py --gpus 2 (its own torch.distributed.run child, two gloo ranks on this GPU): the N > 1 JSON line
@@ -82,7 +85,7 @@ def probe():
 
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
                   "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
-MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging",
+MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging", "x6_fallbacks",
              "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "dp_four_ranks", "trainer_dp_mt"]
 
 

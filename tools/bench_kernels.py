@@ -295,6 +295,37 @@ def dkv1_stamps(B=4096, S=60, H=4, HD=64, which="dkv"):
             print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:4d}" for x in d) + f" | {st[65] - st[64]:5d} | {nx - st[0]:6d}")
 
 
+def a6n_stamps(which="dkv", B=8192, S=20, H=8, HD=16):
+    """Slot timeline of the pipelined head-dim-16 backward kernels: needs a -DRLT_A6N_STAMPS library (RLT_HIP_LIB)."""
+    import ctypes
+    E = H * HD
+    T = S * B
+    qkv = torch.randn(T, 3 * E, device=dev); out = torch.randn(T, E, device=dev); lse = torch.randn(S, H, B, device=dev).abs() + 20
+    dout = torch.randn(T, E, device=dev); dqkv = torch.empty_like(qkv)
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    ws = torch.empty(wb // 4 + 4, device=dev)
+    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, None, ptr(ws), wb, N.PRECISION_DEFAULT, stream())
+    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), None, ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    ms = timeit(f)
+    fn = N.load().rlt_debug_a6n_stamps
+    fn.restype = ctypes.c_int
+    buf = (ctypes.c_ulonglong * (4 * 4 * 18))()
+    assert fn(buf) == 0
+    v = list(buf)
+    gs = 32 if which == "dkv" else 22
+    print(f"{which} {ms:.3f} ms; cycles per slot ({gs} MFMAs = {16 * gs} matrix cycles) of tiles 9, 10 of wavefronts 0 and 3, then barrier wait and tile period")
+    for w in (0, 3):
+        for tl in (1, 2):
+            st = v[(w * 4 + tl) * 18:(w * 4 + tl) * 18 + 18]
+            nx = v[(w * 4 + tl + 1) * 18]
+            d = [st[k + 1] - st[k] for k in range(16)]
+            print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:4d}" for x in d) + f" | {st[17] - st[16]:5d} | {nx - st[0]:6d}")
+
+
+def a6n_stamps_dq():
+    a6n_stamps(which="dq")
+
+
 def dq1_stamps():
     dkv1_stamps(which="dq")
 

@@ -217,6 +217,7 @@ CALL = {"S": "m_s", "D": "m_d", "R1": "m_r", "R2": "m_r", "RP1": "m_r", "RD1": "
 out = [f"// generated by tools/gen_attn6n_body.py {MODE} - do not edit"]
 for s in range(NS):
     out.append(f"// slot {s}")
+    out.append(f"A6N_STAMP({s});")
     for g0, (stage, k) in enumerate(LAYOUT):
         i = s - OFFSET[stage]                 # item (negative: of the previous tile - same ring slot, same own-row block)
         it, n = i % RING, i % NB

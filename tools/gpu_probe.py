@@ -2083,6 +2083,47 @@ def x6_image_staging():
 
 
 @section
+def x6_fallbacks():
+    """The bf16x6 attention forms the default dispatch does not reach at the test shapes: (1) in a child
+    process, the two-workgroup backward kernels at head dim 64 WITHOUT image staging (RLT_A6_DKV1=0 RLT_A6_DQ1=0: the IMG = false
+    instantiations, the path of inputs whose B * ld exceeds the one-wavefront kernels' 24-bit row offsets) and the two-wavefront
+    head-dim-16 kernels at every size (RLT_A6N_1=0), on the op-level attention sections; (2) here, the 24-bit switch-over
+    itself: S = 1, H = 4, head dim 64 at B = 21,760 (B * 3 * H * HD = 16,711,680 < 2^24: one-wavefront kernels) and B = 21,888
+    (16,809,984 >= 2^24: two-workgroup kernels), forward + backward against the exact-fp32 kernels on the same inputs."""
+    import subprocess
+    env = dict(os.environ, RLT_PRECISION="bf16x6", RLT_A6_DKV1="0", RLT_A6_DQ1="0", RLT_A6N_1="0")
+    env.pop("RLT_ATTN6_IMG", None)
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "attention", "scale_ops"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    report("x6_fallbacks: child exit status", float(res.returncode), 0)
+    tail = [l for l in res.stdout.strip().splitlines() if " ok, " in l and "failed" in l]
+    ok, failed = (int(tail[-1].split()[0]), int(tail[-1].split()[2])) if tail else (0, 1)
+    report("x6_fallbacks: checks failed in the child", float(failed), 0)
+    report("x6_fallbacks: checks run in the child (>= 100)", 0.0 if ok >= 100 else 1.0, 0)
+    if res.returncode or failed:
+        print(res.stdout[-3000:], res.stderr[-2000:])
+    g = torch.Generator(device=dev).manual_seed(5)
+    S, H, HD = 1, 4, 64
+    E = H * HD
+    for B in (21760, 21888):
+        qkv = torch.randn(B * S, 3 * E, generator=g, device=dev)
+        dout = torch.randn(B * S, E, generator=g, device=dev)
+        outs = {}
+        for mode in ("fp32", "bf16x6"):
+            with ops.precision(mode):
+                qd = qkv.clone().requires_grad_(True)
+                od = ops.list_attention(qd, S, B, H)
+                od.backward(dout)
+                outs[mode] = (od.detach(), qd.grad.detach())
+        side = "below" if B * 3 * E < (1 << 24) else "at or above"
+        report(f"x6_fallbacks B{B} (B*ld {side} 2^24): out vs the exact-fp32 kernels", rel(outs["bf16x6"][0], outs["fp32"][0]), 1e-5)
+        for nm, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+            report(f"x6_fallbacks B{B}: {nm} vs the exact-fp32 kernels", rel(outs["bf16x6"][1][:, sl], outs["fp32"][1][:, sl]), 3e-5)
+        del qkv, dout, outs
+        torch.cuda.empty_cache()
+
+
+@section
 def rccl_one_rank():
     """The RCCL code path on this one-GPU box: bench.py and run.py as fresh children of torch.distributed.run with ONE
     rank and RLT_FORCE_DIST=1 - init_process_group("nccl", device_id=...), the parameter broadcast, the all-reduce(AVG) of
