@@ -41,7 +41,9 @@
 // SEED (template parameter of the two-wavefront kernels; the pipelined kernels always): the row / lane constants (-m_run, -lse,
 // -delta) as the INITIAL accumulators of the score / dP products (as attention16.hip) - no subtraction per score.  It rounds every
 // partial sum at the magnitude of the constant: invisible next to the accumulation error of thousands of lists, 2-3x the error
-// of the unseeded form on a few dozen lists (profiles/r05_notes.md) - so launches of fewer than 512 lists run unseeded.
+// of the unseeded form on a few dozen lists (profiles/r05_notes.md) - so launches of fewer than 512 lists run unseeded.  The same
+// launches also keep ONE accumulator per output (RLT_A6N_2ACC below): with one or two key blocks the second accumulator only adds
+// a rounding at full magnitude (whole-model gradient error 3.5x at 16 lists), what it removes needs thousands of lists to build up.
 #ifndef RLT_A6N_2ACC
 #define RLT_A6N_2ACC 1      // 1: the five small plane products of the list-contracted outputs (O, dQ, dK, dV) accumulate in their OWN accumulator, added to the h h' accumulator once at the end
 #endif
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                         m_run[n] = SEED ? m_run[n] + m_new : m_new;
                         if (SEED) seed[n] = f32x4{-m_run[n], -m_run[n], -m_run[n], -m_run[n]};
                         o[n] *= alpha;
-                        if (RLT_A6N_2ACC) o2[n] *= alpha;
+                        if (RLT_A6N_2ACC && SEED) o2[n] *= alpha;
                     }
                 }
 #pragma unroll
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
                         }
                     }
                     const Planes pp = split_mx(pe[n][0], pe[n][1], c.sel0, c.sel1);
-                    if (RLT_A6N_2ACC) mm6_2(vt, pp, o[n], o2[n]);
+                    if (RLT_A6N_2ACC && SEED) mm6_2(vt, pp, o[n], o2[n]);
                     else o[n] = mm6(vt, pp, o[n]);                  // O^T[d][q] += V^T P^T
                 }
             }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
     for (int n = 0; n < NB; ++n) {
         const float l_tot = col_sum4(l_run[n]);
         const int q = row0 + 16 * n + c.l15;
-        if (RLT_A6N_2ACC) o[n] += o2[n];
+        if (RLT_A6N_2ACC && SEED) o[n] += o2[n];
         if (q < B) {
             const float inv = 1.f / l_tot;
             *reinterpret_cast<float4*>(a.o + ((size_t)s * B + q) * E + h * 16 + 4 * c.g) =
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
                     }
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
                     if (RLT_A6N_ABL & 8) { asm volatile("" :: "v"(ds.h), "v"(ds.m), "v"(ds.l)); continue; }
-                    if (RLT_A6N_2ACC) mm6_2(kt, ds, dq[n], dq2[n]);
+                    if (RLT_A6N_2ACC && SEED) mm6_2(kt, ds, dq[n], dq2[n]);
                     else dq[n] = mm6(kt, ds, dq[n]);                                 // dQ^T[d][q] += K^T dS^T
                 }
                 interleave_hint<22 * NB, 2>();
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dq_kernel(AttnArg
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int q = row0 + 16 * n + c.l15;
-        if (RLT_A6N_2ACC) dq[n] += dq2[n];
+        if (RLT_A6N_2ACC && SEED) dq[n] += dq2[n];
         if (q < B)
             *reinterpret_cast<float4*>(a.dqkv + ((size_t)s * B + q) * ld + h * 16 + 4 * c.g) =
                 make_float4(dq[n][0] * a.scale, dq[n][1] * a.scale, dq[n][2] * a.scale, dq[n][3] * a.scale);
@@ -611,10 +613,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
                         }
                     }
                     const Planes pp = split_mx(sc[0], sc[1], c.sel0, c.sel1);
-                    if (RLT_A6N_2ACC) mm6_2(dt_, pp, dv[n], dv2[n]);
+                    if (RLT_A6N_2ACC && SEED) mm6_2(dt_, pp, dv[n], dv2[n]);
                     else dv[n] = mm6(dt_, pp, dv[n]);                                // dV^T[d][key] += dO^T P
                     const Planes ds = split_mx(dp[0], dp[1], c.sel0, c.sel1);
-                    if (RLT_A6N_2ACC) mm6_2(qt_, ds, dk[n], dk2[n]);
+                    if (RLT_A6N_2ACC && SEED) mm6_2(qt_, ds, dk[n], dk2[n]);
                     else dk[n] = mm6(qt_, ds, dk[n]);                                // dK^T[d][key] += Q^T dS
                 }
                 interleave_hint<32 * NB, 2>();
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int key = row0 + 16 * n + c.l15;
-        if (RLT_A6N_2ACC) { dk[n] += dk2[n]; dv[n] += dv2[n]; }
+        if (RLT_A6N_2ACC && SEED) { dk[n] += dk2[n]; dv[n] += dv2[n]; }
         if (key < B) {
             float* drow = a.dqkv + ((size_t)s * B + key) * ld + h * 16 + 4 * c.g;
             *reinterpret_cast<float4*>(drow + E) =

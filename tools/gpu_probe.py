@@ -1619,7 +1619,16 @@ def flip_aligned_grads():
         wp, wa = max(plain, key=plain.get), max(aligned, key=aligned.get)
         print(f"   ({tag}: {counts[0]} of {counts[2]} FFN units aligned; worst rel-L2 un-aligned {plain[wp]:.2e} ({wp}), "
               f"aligned {aligned[wa]:.2e} ({wa}))", flush=True)
-        report(f"{tag} flip-aligned grad rel-L2 worst ({wa})", aligned[wa], tol)
+        # the bias of a Linear behind a softmax over the positions has an identically ZERO gradient (shift invariance): both sides
+        # hold rounding residue of sum_j dlogit_j, graded against the 1e-3 x largest-gradient floor of _param_rel_l2 - reported on
+        # its own at 3x the tolerance (1.8e-4 / 6.4e-5 / 7.7e-5 measured for the three attention kernel sets at choopy_b16_s40),
+        # the worst of the parameters WITH a gradient at the tolerance itself
+        zero_grad = {n for n in aligned if n.endswith("decison_layer.0.bias") or n.endswith("cut_layer.0.bias")}
+        for n in sorted(zero_grad):
+            report(f"{tag} flip-aligned residue of the zero-gradient softmax bias ({n})", aligned[n], 3 * tol)
+        live = {n: v for n, v in aligned.items() if n not in zero_grad}
+        wa = max(live, key=live.get)
+        report(f"{tag} flip-aligned grad rel-L2 worst ({wa})", live[wa], tol)
 
 
 @section
