@@ -338,6 +338,15 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             for (int i = 0; i < 4; ++i) icf[4 * r + i] = ok(r) ? fast_rcp(a.coef[r * 128 + 4 * hl + i]) : 0.f;
     }
     const float c_exp = (1.f / a.tau) * 1.4426950408889634f;
+    // F1 reward 2c / (k + N): k + N <= 2 S <= 768 is a small integer, so 2 / (k + N) comes from a table in LDS (filled with the same
+    // v_rcp_f32 the per-position form executed, doubled - exact: the products are bit-identical) instead of a quarter-rate
+    // reciprocal per position.  The pass is bound by vector issue (profiles/r04_notes.md), not by loads.
+    __shared__ float rtab[F1 ? 1024 : 1];
+    if (F1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rtab[tid + 256 * i] = 2.f * fast_rcp((float)(tid + 256 * i));
+        __syncthreads();
+    }
     double part_loss = 0.0, part_f1 = 0.0, part_dcg = 0.0;
     const int nwaves = gridDim.x * 4;
     for (int pb = 2 * (blockIdx.x * 4 + wv); pb < B; pb += 2 * nwaves) {
@@ -368,13 +377,11 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 off += half_last(incl, upper);
             }
             n_rel = off;
+            const float* rt = rtab + (4 * hl + 1 + (int)n_rel);       // 2 / (k + N), k = position + 1
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float k0 = (float)(r * 128 + 4 * hl) + n_rel;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    rv[4 * r + i] = (2.f * rv[4 * r + i]) * fast_rcp(k0 + (float)(i + 1));   // c = 0 gives 0 (k + N >= 1)
-                }
+                for (int i = 0; i < 4; ++i) rv[4 * r + i] *= rt[r * 128 + i];              // c = 0 gives 0 (k + N >= 1)
             }
         } else {                                              // utils/metrics.py:93-101: prefix of (+1 | penalty) / log2(j+2)
             float off = 0.f;
@@ -443,15 +450,16 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             float pmin = p[0];
 #pragma unroll
             for (int n = 1; n < N; ++n) pmin = fminf(pmin, p[n]);
-            if (__builtin_amdgcn_ballot_w64(pmin < 1.17549435e-38f && pmin > 0.f) == 0) {
+            if (__builtin_amdgcn_ballot_w64(pmin < 1.17549435e-38f) == 0) {      // (an exactly-zero p too: the fast loop takes log2 p as it is)
 #pragma unroll
                 for (int n = 0; n < N; ++n) {
                     const float sm = p[n] + q[n];
                     const float l2s = __builtin_amdgcn_logf(sm);
                     // log2 q from the exponent it was formed with (exact where v_log_f32 of the rounded q has 1 ulp; a q that
                     // underflowed to 0 - or a position beyond the list - multiplies it by 0); clamped like the log form was
-                    const float dq_ = fmaxf(__builtin_fmaf(rv[n], c_exp, -l2z), -126.f) - l2s;
-                    const float dp_ = __builtin_amdgcn_logf(fmaxf(p[n], 1.17549435e-38f)) - l2s;
+                    // (no clamp at -126: below it q = exp2(.) has flushed to 0 and multiplies a finite number)
+                    const float dq_ = __builtin_fmaf(rv[n], c_exp, -l2z) - l2s;
+                    const float dp_ = __builtin_amdgcn_logf(p[n]) - l2s;
                     part = __builtin_fmaf(q[n], dq_, part);
                     part = __builtin_fmaf(p[n], dp_, part);
                     part += sm;

@@ -17,7 +17,7 @@ import json
 import re
 import sys
 
-KERNEL_RE = re.compile(r"(attn(?:3|6|16)?_\w+|gemm6[bce]?_kernel<[^>]*>|gemm3?b?_kernel<[^>]*>|bilstm[36]?_\w+|splitk_reduce_kernel|add_ln_\w+|heads_\w+|narrow_dw_\w+|"
+KERNEL_RE = re.compile(r"(attn(?:3|6n|6|16)?_\w+|gemm6[bce]?_kernel<[^>]*>|gemm3?b?_kernel<[^>]*>|bilstm[36]?_\w+|splitk_reduce_kernel|add_ln_\w+|heads_\w+|narrow_dw_\w+|"
                        r"reward_loss_kernel|reward_loss_h_kernel|adam_kernel|rlt_rows_reduce_kernel|colsum_\w+|cut_metrics_kernel)")
 
 
