@@ -656,6 +656,10 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_bwd_dkv_kernel(AttnAr
 #ifndef RLT_A6N_OCC1
 #define RLT_A6N_OCC1 1       // one wavefront per SIMD, 512 registers (compiled with -mllvm -amdgpu-mfma-vgpr-form: rlt_hip/build.py)
 #endif
+#ifndef RLT_A6N_DQ1_BODY          // (timing experiments compile other generated bodies: tools/gen_attn6n_body.py with GEN_OMIT)
+#define RLT_A6N_DQ1_BODY "attention6n_dq1_body.inc"
+#define RLT_A6N_DKV1_BODY "attention6n_dkv1_body.inc"
+#endif
 #ifdef RLT_A6N_STAMPS
 // diagnostic build only: s_memtime at every slot of tiles 8..11 of one workgroup (tools/bench_kernels.py a6n_stamps); entries 16 / 17:
 // before / behind the barrier
@@ -773,9 +777,9 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
     // the pipeline's registers: RING item sets (scores / dP in fp32, the planes of P and dS) and the fragments of the current block
     f32x4 sc[4][2], dp[4][2];
     uint32_t pln[2][3][4][4];                                   // [P | dS][h, m, l][ring][dword]
-    bf16x8 fr[2][2][3];                                         // row fragments [matrix][16-row block][which]
-    v4s trf[2][3][2];                                           // transposed fragments [matrix][plane][half]
-    float4 tabv[2][2];                                          // dK+dV: [lse | delta][16-row block] seeds of the block's rows
+    bf16x8 fr[2][2][2][3];                                      // row fragments [buffer = 32-row block & 1][matrix][16-row block][which]
+    v4s trf[2][2][3][2];                                        // transposed fragments [buffer][matrix][plane][half]
+    float4 tabv[2][2][2];                                       // dK+dV: [buffer][lse | delta][16-row block] seeds of the block's rows
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -783,10 +787,11 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
 #pragma unroll
     for (int i = 0; i < 2 * 3 * 4 * 4; ++i) (&pln[0][0][0][0])[i] = 0u;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) (&fr[0][0][0])[i] = frag4(0u, 0u, 0u, 0u);
+    for (int i = 0; i < 24; ++i) (&fr[0][0][0][0])[i] = frag4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) (&trf[0][0][0])[i] = v4s{0, 0, 0, 0};
-    tabv[0][0] = tabv[0][1] = tabv[1][0] = tabv[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 24; ++i) (&trf[0][0][0][0])[i] = v4s{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) (&tabv[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     for (int t = 0; t <= nt; ++t) {                             // nt + 1 bodies: the last one drains the pipeline on an empty tile
@@ -827,22 +832,22 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         auto mma_out = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {     // output accumulator (agpr) += A(vgpr) B(vgpr)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(av), "v"(bv));
         };
-        auto m_s = [&](int it, int n, int k) __attribute__((always_inline)) {
+        auto m_s = [&](int it, int n, int k, int fb) __attribute__((always_inline)) {
             const int kb = k / 3, j = k % 3;
             if (j == 0) {
-                if (DKV) mma_aa_c(sc[it][kb], fr[0][kb][0], amh[n], f32x4{tabv[0][kb].x, tabv[0][kb].y, tabv[0][kb].z, tabv[0][kb].w});
-                else mma_aa_c(sc[it][kb], fr[0][kb][0], amh[n], seed_s[DKV ? 0 : n]);
+                if (DKV) mma_aa_c(sc[it][kb], fr[fb][0][kb][0], amh[n], f32x4{tabv[fb][0][kb].x, tabv[fb][0][kb].y, tabv[fb][0][kb].z, tabv[fb][0][kb].w});
+                else mma_aa_c(sc[it][kb], fr[fb][0][kb][0], amh[n], seed_s[DKV ? 0 : n]);
             } else {
-                mma_aa(sc[it][kb], fr[0][kb][j], j == 1 ? alh[n] : amh[n]);
+                mma_aa(sc[it][kb], fr[fb][0][kb][j], j == 1 ? alh[n] : amh[n]);
             }
         };
-        auto m_d = [&](int it, int n, int k) __attribute__((always_inline)) {
+        auto m_d = [&](int it, int n, int k, int fb) __attribute__((always_inline)) {
             const int kb = k / 3, j = k % 3;
             if (j == 0) {
-                if (DKV) mma_aa_c(dp[it][kb], fr[1][kb][0], bmh[n], f32x4{tabv[1][kb].x, tabv[1][kb].y, tabv[1][kb].z, tabv[1][kb].w});
-                else mma_aa_c(dp[it][kb], fr[1][kb][0], bmh[n], seed_d[DKV ? 0 : n]);
+                if (DKV) mma_aa_c(dp[it][kb], fr[fb][1][kb][0], bmh[n], f32x4{tabv[fb][1][kb].x, tabv[fb][1][kb].y, tabv[fb][1][kb].z, tabv[fb][1][kb].w});
+                else mma_aa_c(dp[it][kb], fr[fb][1][kb][0], bmh[n], seed_d[DKV ? 0 : n]);
             } else {
-                mma_aa(dp[it][kb], fr[1][kb][j], j == 1 ? blh[n] : bmh[n]);
+                mma_aa(dp[it][kb], fr[fb][1][kb][j], j == 1 ? blh[n] : bmh[n]);
             }
         };
         auto plane = [&](int which, int lvl, int it) __attribute__((always_inline)) {
@@ -851,12 +856,12 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         auto m_r = [&](int it, int which, int level, int kb) __attribute__((always_inline)) {
             mma_av(which ? dp[it][kb] : sc[it][kb], sel[kb], plane(which, level - 1, it));
         };
-        auto m_o = [&](int it, int n, int which, int k) __attribute__((always_inline)) {
+        auto m_o = [&](int it, int n, int which, int k, int fb) __attribute__((always_inline)) {
             const int ap = k == 0 || k == 3 ? 1 : k == 1 ? 2 : 0, bp = k == 0 || k == 4 ? 1 : k == 2 ? 2 : 0;
             const int mat = DKV ? (which ? 0 : 1) : 0;          // dQ: K^T; dV: dO^T, dK: Q^T
             const int w = DKV ? which : 0;
             typedef short v8s __attribute__((ext_vector_type(8)));
-            const v4s x = trf[mat][ap][0], y = trf[mat][ap][1];
+            const v4s x = trf[fb][mat][ap][0], y = trf[fb][mat][ap][1];
             const v8s av = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
             mma_out(k < 5 ? acc2[w][n] : acc[w][n], __builtin_bit_cast(bf16x8, av), plane(which, bp, it));
         };
@@ -866,15 +871,15 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
             const f32x4& tile = which ? dp[it][j >> 1] : sc[it][j >> 1];
             pln[which][lvl][it][j] = pk2n(tile[2 * (j & 1)], tile[2 * (j & 1) + 1]);
         };
-        auto rd_row = [&](int mat, int kb, int w, int b32) __attribute__((always_inline)) {
-            fr[mat][kb][w] = *reinterpret_cast<const bf16x8*>(Ic + mat * IMGT + offW[w] + (2 * b32 + kb) * 256);
+        auto rd_row = [&](int fb, int mat, int kb, int w, int b32) __attribute__((always_inline)) {
+            fr[fb][mat][kb][w] = *reinterpret_cast<const bf16x8*>(Ic + mat * IMGT + offW[w] + (2 * b32 + kb) * 256);
         };
-        auto rd_tr = [&](int mat, int pl, int half, int b32) __attribute__((always_inline)) {
-            trf[mat][pl][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        auto rd_tr = [&](int fb, int mat, int pl, int half, int b32) __attribute__((always_inline)) {
+            trf[fb][mat][pl][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (v4s __attribute__((address_space(3)))*)(Ic + mat * IMGT + pl * PLT + offT + b32 * 512 + half * 256));
         };
-        auto rd_tab = [&](int which, int kb, int b32) __attribute__((always_inline)) {
-            tabv[which][kb] = *reinterpret_cast<const float4*>(Tc + which * KTN1 + b32 * 32 + kb * 16 + 4 * g);
+        auto rd_tab = [&](int fb, int which, int kb, int b32) __attribute__((always_inline)) {
+            tabv[fb][which][kb] = *reinterpret_cast<const float4*>(Tc + which * KTN1 + b32 * 32 + kb * 16 + 4 * g);
         };
         auto st_load = [&](int u) __attribute__((always_inline)) { unit_load(u, r_next); };
         auto st_split = [&](int u, int part) __attribute__((always_inline)) {
@@ -885,9 +890,9 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         auto st_tab_load = [&]() __attribute__((always_inline)) { tab_load(r_next); };
         auto st_tab_store = [&]() __attribute__((always_inline)) { Tn[tid] = rtab; };
         if constexpr (DKV) {
-#include "attention6n_dkv1_body.inc"
+#include RLT_A6N_DKV1_BODY
         } else {
-#include "attention6n_dq1_body.inc"
+#include RLT_A6N_DQ1_BODY
         }
 #undef GAP_END
         A6N_STAMP(16);

@@ -53,7 +53,10 @@ def test_attention6n_bodies_cover_every_mfma_and_chunk_once():
         text = open(os.path.join(CSRC, inc)).read()
         mf = re.findall(r"^(m_[sdro])\(([^)]*)\); GAP_END;", text, flags=re.M)
         assert len(mf) == 16 * per_slot
-        assert set(Counter(mf).values()) == {4}      # item i and i + 4 share a ring slot and an own-row block: each call 16 / 4 times
+        # item i and i + 4 share a ring slot and an own-row block (the residual MFMAs m_r: each call 16 / 4 times); the row and
+        # output products also name the fragment buffer of their 32-row block, which alternates: 16 / 8 times
+        assert {name: set(v for (nm, _a), v in Counter(mf).items() if nm == name) for name in ("m_r", "m_s", "m_d", "m_o")} == \
+            {"m_r": {4}, "m_s": {2}, "m_d": {2}, "m_o": {2}}
         calls = Counter(re.findall(r"\b([a-z_]+)\(", text))
         assert calls["e_exp"] == 16 * 8 and calls["e_mul"] == 16 * 8 and calls["c_pk"] == 16 * nconv
         assert calls["rd_row"] == 4 * 12 and calls["rd_tr"] == 4 * 6 * (2 if per_slot == 32 else 1)

@@ -22,9 +22,11 @@ time.  One line of calls per gap; GAP_END (sched_barrier) keeps hipcc from reord
     python tools/gen_attn6n_body.py dq  > ranked-list-truncation_amd/csrc/attention6n_dq1_body.inc
     python tools/gen_attn6n_body.py dkv > ranked-list-truncation_amd/csrc/attention6n_dkv1_body.inc
 """
+import os
 import sys
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "dq"
+OMIT = set(filter(None, os.environ.get("GEN_OMIT", "").split(",")))     # timing experiments: leave out the calls of these names (wrong results)
 NB = 4                       # 16-row blocks of own rows per wavefront
 NB32 = 4                     # 32-row blocks per tile (tile = 128 rows)
 NS = NB * NB32               # slots (= items) per tile body
@@ -32,7 +34,7 @@ RING = 4                     # item register sets
 LAG = 2                      # gaps between an MFMA and the first vector read of its result
 MARGIN = 2                   # a chunk that writes an MFMA operand sits at least this many gaps ahead of the MFMA
 WAR = 2                      # a fragment register is rewritten at the earliest this many gaps behind the last MFMA that reads it
-RD_AHEAD = 6                 # an LDS read is issued at least this many gaps (~100 cycles) ahead of the MFMA that takes its data
+RD_AHEAD = 10                # an LDS read is issued at least this many gaps (~100 cycles) ahead of the MFMA that takes its data
 CAP = 8                      # vector-issue cycles a gap takes before the scheduler looks for another one
 COST = {"exp": 8, "mul": 4, "sub": 4, "cvt": 5, "rd": 2, "ld": 3, "sp": 16, "st": 8, "tb": 3}
 
@@ -118,18 +120,21 @@ for i in range(NS):
             if "P" not in MATS:
                 ep[kb, r].deadline = ed[kb, r].deadline - 1
 
-# ---- LDS fragment reads of 32-row block b32: into the (single) fragment registers, after the last MFMA that uses the previous
-# ---- block's fragment, ahead of the first that uses this one
+# ---- LDS fragment reads of 32-row block b32 into fragment buffer b32 & 1: any time after the last MFMA that uses block b32 - 2
+# ---- (the previous tenant of the buffer; not before the barrier that opens the tile), RD_AHEAD gaps ahead of the first MFMA
+# ---- that uses this one - a window of a whole 32-row block, so the reads spread out instead of arriving in one burst (the
+# ---- single-buffered form made the wavefront wait for every burst: 26 % of the dQ kernel, profiles/r05_notes.md)
 first_item = lambda b32: b32 * NB
 last_item = lambda b32: b32 * NB + NB - 1
 for b32 in range(NB32):
-    prev_last = last_item(b32 - 1) if b32 else None
+    fb = b32 & 1
+    prev_last = last_item(b32 - 2) if b32 >= 2 else None
     for mat, stage in (("k" if MODE == "dq" else "q", "S"), ("v" if MODE == "dq" else "d", "D")):
         for kb in range(2):
             for w in range(3):
                 use = gap_of(stage, 3 * kb + w, first_item(b32))
                 rel = gap_of(stage, 3 * kb + w, prev_last) + WAR if prev_last is not None else 0
-                add(f"r{mat}{b32}.{kb}{w}", [(f"rd_row({0 if stage == 'S' else 1}, {kb}, {w}, {b32});", "rd")], rel, use - RD_AHEAD)
+                add(f"r{mat}{b32}.{kb}{w}", [(f"rd_row({fb}, {0 if stage == 'S' else 1}, {kb}, {w}, {b32});", "rd")], rel, use - RD_AHEAD)
     outs = (("O", 0),) if MODE == "dq" else (("OV", 1), ("OK", 0))      # dq: K^T; dkv: dO^T for dV, Q^T for dK
     for stage, mat in outs:
         # planes in the order the six products take them (A operand): m, l, h, m, h, h -> first uses k = 0 (m), 1 (l), 2 (h);
@@ -138,25 +143,25 @@ for b32 in range(NB32):
             pi = {"h": 0, "m": 1, "l": 2}[pl]
             for half in range(2):
                 use = gap_of(stage, fu, first_item(b32))
-                # (the last item of the previous 32-row block of the PREVIOUS TILE when b32 = 0: its output stage sits in this body's
-                # first slots, and the body is cyclic - handled by the wrap of the timeline)
-                rel = gap_of(stage, lu, last_item(b32 - 1) if b32 else last_item(NB32 - 1) - NS) + WAR
-                add(f"t{mat}{b32}.{pl}{half}", [(f"rd_tr({mat}, {pi}, {half}, {b32});", "rd")], rel, use - RD_AHEAD)
+                # previous tenant of the buffer: block b32 - 2 (of the PREVIOUS TILE for b32 < 2: its output stage sits up to three
+                # slots into this body - the timeline is cyclic)
+                rel = max(0, gap_of(stage, lu, last_item(b32 - 2) if b32 >= 2 else last_item(b32 + NB32 - 2) - NS) + WAR)
+                add(f"t{mat}{b32}.{pl}{half}", [(f"rd_tr({fb}, {mat}, {pi}, {half}, {b32});", "rd")], rel, use - RD_AHEAD)
     if MODE == "dkv":
         # lse / delta seeds of the block's 32 rows (the C operands of S / dP): [kb] float4 each
         for kb in range(2):
             for which, stage in ((0, "S"), (1, "D")):
                 use = gap_of(stage, 3 * kb, first_item(b32))
                 rel = gap_of(stage, 3 * kb, prev_last) + WAR if prev_last is not None else 0
-                add(f"tb{b32}.{kb}{which}", [(f"rd_tab({which}, {kb}, {b32});", "tb")], rel, use - RD_AHEAD)
+                add(f"tb{b32}.{kb}{which}", [(f"rd_tab({fb}, {which}, {kb}, {b32});", "tb")], rel, use - RD_AHEAD)
 
 # ---- staging of the next tile: 4 units (matrix u >> 1, row half u & 1): global load early, split + LDS stores before the barrier
 for u in range(4):
     ld = add(f"sl{u}", [(f"st_load({u});", "ld")], 2 + u, GS * 2)
-    add(f"ss{u}", [(f"st_split({u}, {k});", "sp") for k in range(6)] + [(f"st_store({u});", "st")], GS * (4 + 2 * u), G - 4, [(ld, GS * 3)])
+    add(f"ss{u}", [(f"st_split({u}, {k});", "sp") for k in range(6)] + [(f"st_store({u});", "st")], GS * (9 + u), G - 4, [(ld, GS * 8)])
 if MODE == "dkv":
     tl = add("stl", [("st_tab_load();", "ld")], 8, GS * 2)
-    add("sts", [("st_tab_store();", "st")], GS * 6, G - 4, [(tl, GS * 3)])
+    add("sts", [("st_tab_store();", "st")], GS * 12, G - 4, [(tl, GS * 8)])
 
 
 def place(t, capv):
@@ -221,15 +226,16 @@ for s in range(NS):
     for g0, (stage, k) in enumerate(LAYOUT):
         i = s - OFFSET[stage]                 # item (negative: of the previous tile - same ring slot, same own-row block)
         it, n = i % RING, i % NB
+        fb = (i // NB) & 1                     # fragment buffer of the item's 32-row block (i < 0: blocks 3, 2 of the previous tile)
         if stage in ("S", "D"):
-            call = f"{CALL[stage]}({it}, {n}, {k});"
+            call = f"{CALL[stage]}({it}, {n}, {k}, {fb});"
         elif stage.startswith("R"):
             which = 1 if stage in ("R1", "R2", "RD1", "RD2") else 0
             call = f"m_r({it}, {which}, {1 if stage.endswith('1') else 2}, {k});"
         else:
             which = {"O": 1, "OV": 0, "OK": 1}[stage]
-            call = f"m_o({it}, {n}, {which}, {k});"
-        work = " ".join(c for c, _k, _n in sched[s * GS + g0])
+            call = f"m_o({it}, {n}, {which}, {k}, {fb});"
+        work = " ".join(c for c, _k, _n in sched[s * GS + g0] if c.split("(")[0] not in OMIT)
         out.append(f"{call} GAP_END; {work} GAP_END;".replace("  ", " "))
 out.append(f"// {sum(1 for x in sched if x)} of {G} gaps carry vector work; capacity {cap} cycles per gap")
 print("\n".join(out))
