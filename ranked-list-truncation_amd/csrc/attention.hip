@@ -644,6 +644,17 @@ int rlt_attention_dropout_mask_range(uint32_t seed, int pair0, int npair, int B,
 
 // ---- workspace layout of the backward pass: [ delta (S,H,B) floats, padded to 1 KiB | dO tile records (bf16x3) ]
 static size_t delta_bytes(int S, int B, int H) { return ((size_t)S * H * B * sizeof(float) + 1023) / 1024 * 1024; }
+// bf16x6 at head dim 16, 512 lists and more: the pipelined backward kernels of attention6n.hip stage pre-split tile images of
+// Q, K, V, dO and the rows' seeds from the workspace (behind delta): dO + seeds are written by _bwd_prepare, Q by _bwd_dkv,
+// K / V by _bwd_dq - each part prepares what it reads, so the three entry points stay callable on their own.  RLT_A6N_IMG=0:
+// the two-wavefront kernels (A/B runs).  Train-mode launches (drop_p > 0) do not use the images.
+static bool a6n_images(int HD, int B) {
+    static const bool on = [] {
+        for (const char* v : {"RLT_A6N", "RLT_A6N_1", "RLT_A6N_IMG"}) { const char* e = getenv(v); if (e && atoi(e) == 0) return false; }
+        return true;
+    }();
+    return on && HD == 16 && B >= 512 && attn6_use(HD, 0.f) && !attn6_img(HD);
+}
 
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision) {
     RLT_PREC_SCOPE_SZ(precision);
@@ -691,7 +702,8 @@ size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, int precisi
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1)
-                                                      : attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 1) : 0);
+                                                      : attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 1)
+                                                      : a6n_images(HD, B) ? rlt_attn6n_images_bytes(S, B, H) : 0);
 }
 
 // drop_p < 0: unknown (the stand-alone entry point), the dO records get both images
@@ -701,8 +713,10 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
     RLT_CHECK_SHAPE(hd_ok(HD));
     const bool split = attn_mode(HD) == 1 && images;
     const bool img6 = !split && attn6_img(HD) && images;      // bwd_part hands ws + delta to the kernels as the dO images
+    const bool img6n = !split && a6n_images(HD, B) && drop_p <= 0.f;      // (drop_p < 0: unknown - the images are written in case)
     if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1)
-                                                 : img6 ? rlt_attn6_images_bytes(S, B, H, HD, 1) : 0)) return RLT_E_WORKSPACE;
+                                                 : img6 ? rlt_attn6_images_bytes(S, B, H, HD, 1)
+                                                 : a6n_images(HD, B) ? rlt_attn6n_images_bytes(S, B, H) : 0)) return RLT_E_WORKSPACE;
     hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
@@ -714,6 +728,13 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
             a.dout = dout; a.S = S; a.B = B; a.H = H;
             a.dimg = (uint8_t*)ws + delta_bytes(S, B, H);
             rc = rlt_attn6_run(4, a, HD, st);
+        }
+        if (!rc && img6n) {                                       // head dim 16: the dO tile images and the rows' seeds (-lse, -delta)
+            AttnArgs a{};
+            a.dout = dout; a.lse = lse; a.delta = (const float*)ws; a.S = S; a.B = B; a.H = H;
+            a.img = (uint8_t*)ws + delta_bytes(S, B, H);
+            rc = rlt_attn6n_prepare(3, a, st);
+            if (!rc) rc = rlt_attn6n_prepare(4, a, st);
         }
         return rc;
     }
@@ -744,6 +765,13 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
         if (attn6_img(HD) && images) {                            // (forward wrote the Q / K / V images, bwd_prepare the dO images)
             b.img = images;
             b.dimg = (const uint8_t*)ws + delta_bytes(S, B, H);
+        }
+        if (a6n_images(HD, B) && drop_p == 0.f) {                 // the pipelined head-dim-16 kernels: this part's own images first
+            b.img = (const uint8_t*)ws + delta_bytes(S, B, H);    // (the workspace is scratch: dO images + seeds are there already)
+            int rc = 0;
+            if (which == 1) rc = rlt_attn6n_prepare(0, b, st);                       // dK+dV stages Q (and dO)
+            else { rc = rlt_attn6n_prepare(1, b, st); if (!rc) rc = rlt_attn6n_prepare(2, b, st); }     // dQ stages K and V
+            return rc ? rc : rlt_attn6n_run(which, b, st);
         }
         return rlt_attn6_run(which, b, HD, st);
     }

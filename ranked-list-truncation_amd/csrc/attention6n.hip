@@ -672,6 +672,48 @@ __device__ unsigned long long a6n_stamps[4 * 4 * 18];
 constexpr int KTN1 = 128;                   // rows per tile
 constexpr int PLT = KTN1 * 16;              // bf16 elements per plane
 constexpr int IMGT = 3 * PLT;               // ... per image (12 KiB)
+
+// ---- pre-split tile images for the pipelined kernels ---------------------------------------------------------------------------
+// Without them every workgroup of a (position, head) pair re-splits the same 128-row tiles (32 workgroups per pair at 8192
+// lists), and the split + LDS stores + loads are a fifth of the dK+dV kernel's time (profiles/r05_notes.md).  A prepare pass
+// writes each tile of Q, K, V and dO ONCE as the three-plane image in exactly the LDS layout (12 KiB = twelve 1-KiB LDS-DMA
+// pieces), and the seeds of a tile's rows (-lse log2e | -delta: 1 KiB) next to them; the kernels stage a tile with
+// `global_load_lds_dwordx4` - no registers, no vector instructions.  ntile + 1 records per pair: the last one lies wholly beyond
+// B (zero rows, lse = +inf) - the tile the pipeline drains on.
+//   images: record (matrix m in {Q, K, V, dO}, pair, tile) at (((m * npair + pair) * (ntile + 1)) + tile) * 12288 bytes
+//   seeds:  record (pair, tile) at (pair * (ntile + 1) + tile) * 1024 bytes, behind the four image blocks
+constexpr int RECB = IMGT * 2;                 // bytes per image record
+__host__ __device__ inline size_t a6n_img_block(int npair, int ntile) { return (size_t)npair * (ntile + 1) * RECB; }
+__global__ __launch_bounds__(256) void attn6n_prepare_kernel(const float* __restrict__ src, size_t ld, int cols_per_pos, int S, int B, int H,
+                                                             uint8_t* __restrict__ img) {
+    const int tid = threadIdx.x, ntile = rlt_cdiv_dev(B, KTN1);
+    const int pair = blockIdx.x / (ntile + 1), tile = blockIdx.x % (ntile + 1);
+    const int s_ = pair / H, h = pair % H;
+    (void)cols_per_pos;
+    const float* base = src + (size_t)s_ * B * ld + h * 16;
+    uint16_t* rec = reinterpret_cast<uint16_t*>(img + ((size_t)pair * (ntile + 1) + tile) * RECB);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = 64 * u + (tid >> 2), row = tile * KTN1 + r, d0 = 4 * (tid & 3);
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(row, B - 1) * ld + d0);
+        const bool ok = row < B;
+        uint2 hh_, mm_, ll_;
+        split4v(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f, hh_, mm_, ll_);
+        uint16_t* im = rec + r * 16 + d0;
+        *reinterpret_cast<uint2*>(im) = hh_;
+        *reinterpret_cast<uint2*>(im + PLT) = mm_;
+        *reinterpret_cast<uint2*>(im + 2 * PLT) = ll_;
+    }
+}
+__global__ __launch_bounds__(256) void attn6n_seed_kernel(const float* __restrict__ lse, const float* __restrict__ delta, int S, int B, int H,
+                                                          float* __restrict__ tab) {
+    const int tid = threadIdx.x, ntile = rlt_cdiv_dev(B, KTN1);
+    const int pair = blockIdx.x / (ntile + 1), tile = blockIdx.x % (ntile + 1);
+    const int qi = tile * KTN1 + (tid & (KTN1 - 1)), qc = min(qi, B - 1);
+    const float v = tid < KTN1 ? lse[(size_t)pair * B + qc] * LOG2E : delta[(size_t)pair * B + qc];
+    tab[((size_t)pair * (ntile + 1) + tile) * 256 + tid] = qi < B ? -v : (tid < KTN1 ? -INFINITY : 0.f);
+}
+
 template <bool DKV>
 __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs a) {
     constexpr int NB = 4;
@@ -730,49 +772,29 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
     }
 
     const int nt = rlt_cdiv_dev(B, KTN1);
-    const float* src0 = DKV ? base : base + E;                  // matrix 0: Q | K
-    const float* src1 = DKV ? dobase : base + 2 * E;            // matrix 1: dO | V
-    const size_t ld1 = DKV ? (size_t)E : ld;
-    const int srow = tid >> 2, sd0 = 4 * (tid & 3);
-    float4 rs[4];                                               // staging units u: matrix u >> 1, rows 64 (u & 1) + srow
-    float rtab = 0.f;                                           // dK+dV: this thread's table entry of the next tile
-    Split6 sg;
-    auto unit_load = [&](int u, int r0) __attribute__((always_inline)) {
-        const int row = r0 + 64 * (u & 1) + srow;
-        const float* sp = (u >> 1) ? src1 : src0;
-        rs[u] = *reinterpret_cast<const float4*>(sp + (size_t)min(row, B - 1) * ((u >> 1) ? ld1 : ld) + sd0);
-    };
-    auto unit_zero = [&](int u, int r0) __attribute__((always_inline)) {
-        const bool ok = r0 + 64 * (u & 1) + srow < B;
-        rs[u] = make_float4(ok ? rs[u].x : 0.f, ok ? rs[u].y : 0.f, ok ? rs[u].z : 0.f, ok ? rs[u].w : 0.f);
-    };
-    auto unit_store = [&](int u, uint16_t* buf) __attribute__((always_inline)) {
-        uint16_t* im = buf + (u >> 1) * IMGT + (64 * (u & 1) + srow) * 16 + sd0;
-        *reinterpret_cast<uint2*>(im) = sg.hi;
-        *reinterpret_cast<uint2*>(im + PLT) = sg.mid;
-        *reinterpret_cast<uint2*>(im + 2 * PLT) = sg.lo;
-    };
-    auto tab_load = [&](int r0) __attribute__((always_inline)) {
-        const int qi = r0 + (tid & (KTN1 - 1)), qc = min(qi, B - 1);
-        const float* tp = tid < KTN1 ? lsebase : delbase;           // (one load through a selected pointer: no branch in the tile body)
-        float v = tp[qc];
-        asm volatile("" : "+v"(v));                                 // (keeps hipcc from sinking the load into a branch on qi < B, with a vmcnt(0) wait behind it)
-        v *= tid < KTN1 ? LOG2E : 1.f;
-        rtab = qi < B ? -v : (tid < KTN1 ? -INFINITY : 0.f);      // negated: initial values of the score / dP accumulators
+    // staging: LDS-DMA of the pre-split tile records (attn6n_prepare_kernel): 12 pieces of 1 KiB per image, the two images of a
+    // tile adjacent in LDS; dK+dV: + the piece of the tile's seeds.  Piece j of this wavefront = piece wv + 4 j of the tile.
+    const int npair = a.S * H;
+    const uint8_t* rec0 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)(DKV ? 0 : 1) * npair + pair) * (size_t)(nt + 1) * RECB;
+    const uint8_t* rec1 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)(DKV ? 3 : 2) * npair + pair) * (size_t)(nt + 1) * RECB;
+    const uint8_t* recs = reinterpret_cast<const uint8_t*>(a.img) + 4 * a6n_img_block(npair, nt) + (size_t)pair * (nt + 1) * 1024;
+    auto dma = [&](int j, int tile, uint16_t* ibuf, float* tbuf) __attribute__((always_inline)) {
+        if (j < 6) {                                            // pieces wv + 4 (j % 3) of matrix j / 3 (no branch: j is a constant)
+            const int piece = wv + 4 * (j % 3);
+            const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + piece * 1024 + lane * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + piece * 1024));
+            RLT_DMA_ASM(dst, rec);
+        } else if (DKV) {                                       // the seeds: every wavefront copies the same KiB (no branch on the wavefront)
+            const uint8_t* rec = recs + (size_t)tile * 1024 + lane * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(tbuf)));
+            RLT_DMA_ASM(dst, rec);
+        }
     };
     // prologue: tile 0 -> buffer 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        unit_load(u, 0);
-        unit_zero(u, 0);
-#pragma unroll
-        for (int part = 0; part < 6; ++part) split6_part(sg, rs[u].x, rs[u].y, rs[u].z, rs[u].w, part);
-        unit_store(u, img0);
-    }
-    if (DKV) {
-        tab_load(0);
-        tab0[tid] = rtab;
-    }
+    for (int j = 0; j < 7; ++j) dma(j, 0, img0, tab0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // the pipeline's registers: RING item sets (scores / dP in fp32, the planes of P and dS) and the fragments of the current block
     f32x4 sc[4][2], dp[4][2];
@@ -800,7 +822,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         uint16_t* In = img0 + (cur ^ 1) * 2 * IMGT;
         const float* Tc = tab0 + cur * 2 * KTN1;
         float* Tn = tab0 + (cur ^ 1) * 2 * KTN1;
-        const int r_next = (t + 1) * KTN1;
+        const int t_next = min(t + 1, nt);           // (the body of the drain tile stages that tile once more: never read)
 #pragma unroll
         for (int n = 0; n < NB; ++n) {              // (their only uses are "a" operands: keep them in AGPRs across the back edge)
             asm volatile("" : "+a"(amh[n]), "+a"(alh[n]), "+a"(bmh[n]), "+a"(blh[n]));
@@ -881,14 +903,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         auto rd_tab = [&](int fb, int which, int kb, int b32) __attribute__((always_inline)) {
             tabv[fb][which][kb] = *reinterpret_cast<const float4*>(Tc + which * KTN1 + b32 * 32 + kb * 16 + 4 * g);
         };
-        auto st_load = [&](int u) __attribute__((always_inline)) { unit_load(u, r_next); };
-        auto st_split = [&](int u, int part) __attribute__((always_inline)) {
-            if (part == 0) unit_zero(u, r_next);
-            split6_part(sg, rs[u].x, rs[u].y, rs[u].z, rs[u].w, part);
-        };
-        auto st_store = [&](int u) __attribute__((always_inline)) { unit_store(u, In); };
-        auto st_tab_load = [&]() __attribute__((always_inline)) { tab_load(r_next); };
-        auto st_tab_store = [&]() __attribute__((always_inline)) { Tn[tid] = rtab; };
+        auto st_dma = [&](int j) __attribute__((always_inline)) { dma(j, t_next, In, Tn); };
         if constexpr (DKV) {
 #include RLT_A6N_DKV1_BODY
         } else {
@@ -896,6 +911,7 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
         }
 #undef GAP_END
         A6N_STAMP(16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's LDS-DMA pieces of the next tile have landed
         __syncthreads();
         A6N_STAMP(17);
     }
@@ -922,7 +938,7 @@ int launch6n(int which, const AttnArgs& a, hipStream_t st) {
     const size_t shm = (size_t)4 * IMGN * sizeof(uint16_t) + (which == 1 ? 2 * 3 * KT * sizeof(float) : 2 * KT * sizeof(uint32_t));
     // backward without dropout at 512 lists and more: the one-wavefront pipelined kernels (RLT_A6N_1=0: the kernels above, A/B runs)
     static const bool one = [] { const char* e = getenv("RLT_A6N_1"); return !e || atoi(e) != 0; }();
-    if (!DROP && one && which != 0 && a.B >= 512) {
+    if (!DROP && one && which != 0 && a.B >= 512 && a.img) {
         const size_t shm1 = (size_t)4 * IMGT * sizeof(uint16_t) + (which == 1 ? 2 * 2 * KTN1 * sizeof(float) : 0);
         const dim3 grid1(a.S * a.H * rlt_cdiv(a.B, 256));
         int rc;
@@ -957,6 +973,26 @@ extern "C" int rlt_debug_a6n_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(a6n_stamps), sizeof(unsigned long long) * 4 * 4 * 18);
 }
 #endif
+
+// images of the pipelined backward kernels (see attn6n_prepare_kernel): bytes, and the passes that write them - what = 0 Q, 1 K,
+// 2 V (columns of a.qkv), 3 dO (a.dout), 4 the seeds (a.lse, a.delta) - into a.img
+size_t rlt_attn6n_images_bytes(int S, int B, int H) {
+    const int npair = S * H, ntile = rlt_cdiv(B, KTN1);
+    return 4 * a6n_img_block(npair, ntile) + (size_t)npair * (ntile + 1) * 1024;
+}
+int rlt_attn6n_prepare(int what, const AttnArgs& a, hipStream_t st) {
+    const int npair = a.S * a.H, ntile = rlt_cdiv(a.B, KTN1), E = a.H * 16;
+    uint8_t* img = reinterpret_cast<uint8_t*>(const_cast<void*>(a.img));
+    const dim3 grid(npair * (ntile + 1));
+    if (what < 3)
+        hipLaunchKernelGGL(attn6n_prepare_kernel, grid, dim3(256), 0, st, a.qkv + what * E, (size_t)3 * E, 0, a.S, a.B, a.H, img + what * a6n_img_block(npair, ntile));
+    else if (what == 3)
+        hipLaunchKernelGGL(attn6n_prepare_kernel, grid, dim3(256), 0, st, a.dout, (size_t)E, 0, a.S, a.B, a.H, img + 3 * a6n_img_block(npair, ntile));
+    else
+        hipLaunchKernelGGL(attn6n_seed_kernel, grid, dim3(256), 0, st, a.lse, a.delta, a.S, a.B, a.H,
+                           reinterpret_cast<float*>(img + 4 * a6n_img_block(npair, ntile)));
+    return RLT_LAUNCH_RESULT();
+}
 
 // which = 0 forward, 1 dK/dV, 2 dQ (head dim 16, bf16x6 arithmetic)
 int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st) {

@@ -77,6 +77,10 @@ size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat);
 // ... at head dim 16 on the 16x16x32 MFMA (no padded head-dim axis, plane pairs in the d contraction, the split of P / dS on the
 // matrix pipe), defined in attention6n.hip: which = 0 forward, 1 dK/dV, 2 dQ
 int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st);
+// ... its pipelined backward kernels (512 lists and more, no dropout) stage pre-split tile images + row seeds from a.img:
+// rlt_attn6n_images_bytes bytes, written by rlt_attn6n_prepare (what = 0 Q, 1 K, 2 V, 3 dO, 4 seeds)
+size_t rlt_attn6n_images_bytes(int S, int B, int H);
+int rlt_attn6n_prepare(int what, const AttnArgs& a, hipStream_t st);
 // exact fp32 at head dim 16 on the 16x16x4 MFMA (no padded head-dim axis), defined in attention16.hip: same `which`
 int rlt_attn16_run(int which, const AttnArgs& a, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip

@@ -60,11 +60,11 @@ def test_attention6n_bodies_cover_every_mfma_and_chunk_once():
         calls = Counter(re.findall(r"\b([a-z_]+)\(", text))
         assert calls["e_exp"] == 16 * 8 and calls["e_mul"] == 16 * 8 and calls["c_pk"] == 16 * nconv
         assert calls["rd_row"] == 4 * 12 and calls["rd_tr"] == 4 * 6 * (2 if per_slot == 32 else 1)
-        assert calls["st_load"] == 4 and calls["st_split"] == 24 and calls["st_store"] == 4
+        assert calls["st_dma"] == (7 if per_slot == 32 else 6)       # LDS-DMA pieces of the next tile per wavefront
         # ring-indexed chunks four times per body (once per item of the ring slot), reads and staging calls once
         ring = Counter(re.findall(r"\b((?:e_exp|e_mul|c_pk)\([^)]*\))", text))
         assert set(ring.values()) == {4}
-        once = Counter(re.findall(r"\b((?:rd_row|rd_tr|rd_tab|st_load|st_split|st_store)\([^)]*\))", text))
+        once = Counter(re.findall(r"\b((?:rd_row|rd_tr|rd_tab|st_dma)\([^)]*\))", text))
         assert set(once.values()) == {1}
 
 

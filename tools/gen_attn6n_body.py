@@ -13,7 +13,7 @@ outputs, five small plane products into the second accumulator, h h' into the fi
 same wavefront fills with vector work and LDS reads - a v_mfma_f32_16x16x32_bf16 hides about 8 cycles of vector issue behind
 it (tools/micro/mfma16_gap.hip: two plain instructions, or one v_exp_f32, or a conversion + one plain).  This script places the
 element-wise chunks (exp2, P (dP - delta) or P dP, the v_cvt_pk_bf16_f32 of the three planes), the LDS fragment reads of the next
-32-row block and the staging of the next tile (loads, exact three-way split, LDS stores) into the gaps: list scheduling,
+32-row block and the staging of the next tile (LDS-DMA pieces of the pre-split tile records) into the gaps: list scheduling,
 earliest deadline first, on the CYCLIC timeline of the tile body (the pipeline runs across tile boundaries: work of the last
 three items of a tile sits in the first slots of the next body, on the same ring of registers), with the dependences between
 MFMA results, chunks and MFMA operands - including the write-after-read ones of the register rings - checked at generation
@@ -155,14 +155,10 @@ for b32 in range(NB32):
                 rel = gap_of(stage, 3 * kb, prev_last) + WAR if prev_last is not None else 0
                 add(f"tb{b32}.{kb}{which}", [(f"rd_tab({fb}, {which}, {kb}, {b32});", "tb")], rel, use - RD_AHEAD)
 
-# ---- staging of the next tile: 4 units (matrix u >> 1, row half u & 1): global load early, split + LDS stores before the barrier
-for u in range(4):
-    ld = add(f"sl{u}", [(f"st_load({u});", "ld")], 2 + u, GS * 2)
-    add(f"ss{u}", [(f"st_split({u}, {k});", "sp") for k in range(6)] + [(f"st_store({u});", "st")], GS * (9 + u), G - 4, [(ld, GS * 8)])
-if MODE == "dkv":
-    tl = add("stl", [("st_tab_load();", "ld")], 8, GS * 2)
-    add("sts", [("st_tab_store();", "st")], GS * 12, G - 4, [(tl, GS * 8)])
-
+# ---- staging of the next tile: LDS-DMA pieces of the pre-split tile records (12 + 12 (+ 1: the seeds of dK+dV) pieces of 1 KiB, a
+# ---- wavefront issues every fourth one): early in the body, so that they have landed long before the barrier
+for j in range(7 if MODE == "dkv" else 6):
+    add(f"dma{j}", [(f"st_dma({j});", "ld")], GS + 3 * j, GS * 6)
 
 def place(t, capv):
     lo = t.release
