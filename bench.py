@@ -44,7 +44,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 PEAK_HBM_BPS = 8.0e12
 # HBM traffic per launch / per step is NOT measured by this script: it comes from separate rocprofv3 --pmc passes of
 # this same command (tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) committed here:
-PMC_TRAFFIC_FILES = {m: tuple(os.path.join("profiles", f"{r}_pmc_traffic_{m}.json") for r in ("r04", "r03"))
+PMC_TRAFFIC_FILES = {m: tuple(os.path.join("profiles", f"{r}_pmc_traffic_{m}.json") for r in ("r05", "r04", "r03"))
                      for m in ("bf16x6", "fp32", "bf16x3")}
 
 

@@ -277,19 +277,23 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision);
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* images, size_t images_bytes, int precision, void* stream);
-/* backward: ws = [delta (S,H,B) | dO tile records], rlt_list_attention_bwd_workspace bytes.
+/* backward: ws = [delta (S,H,B) | tile records], rlt_list_attention_bwd_workspace bytes.
  *   _bwd_prepare: delta = rowsum(dout*out) and (split-bf16 mode) the dO records;
  *   _bwd_dkv:     dK, dV columns of dqkv;   _bwd_dq: dQ columns of dqkv;
- *   _bwd:         the three in sequence.  `images` = the forward's buffer (NULL => exact-fp32 kernels). */
+ *   _bwd:         the three in sequence.  `images` = the forward's buffer (NULL => exact-fp32 kernels).
+ * BF16X6 at head dim 16 with 512 lists and more (Choopy / MtChoopy at scale; csrc/attention6n.hip): the backward kernels stage
+ * pre-split 128-row tile images of Q, K, V, dO and the rows' seeds (-lse, -delta) from ws - _bwd_prepare writes the dO images and
+ * the seeds, _bwd_dkv the Q images, _bwd_dq the K and V images, each before its kernel (so the three entry points stay callable
+ * on their own; ws is scratch of ONE backward pass: the parts of a pass run on one stream, in any order after _bwd_prepare). */
 size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, int precision);
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
                            void* ws, size_t ws_bytes, int precision, void* stream);
 int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
                                    const void* images, void* ws, size_t ws_bytes, int precision, void* stream);
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
                                int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream);
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream);
 /* keep-mask of the attention-probability dropout as data (tests, small B): out (S,H,B,B) =
  * keep ? 1/(1-p) : 0 for (position, head, query, key) */

@@ -751,7 +751,7 @@ int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const fl
     return bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, -1.f, stream);
 }
 
-static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
                     int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
     RLT_CHECK_ARG(qkv && dout && lse && ws && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(hd_ok(HD));
@@ -759,7 +759,7 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     const AttnArgs a = bwd_args(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
     if (attn_mode(HD) == 1 && images)
-        return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)const_cast<void*>(ws) + delta_bytes(S, B, H), st);
+        return rlt_attn3_run(which, a, HD, const_cast<void*>(images), (uint8_t*)ws + delta_bytes(S, B, H), st);
     if (attn6_use(HD, drop_p)) {
         AttnArgs b = a;
         if (attn6_img(HD) && images) {                            // (forward wrote the Q / K / V images, bwd_prepare the dO images)
@@ -788,13 +788,13 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     return launch_dq<16>(a, st);
 }
 
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
                                int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
     RLT_PREC_SCOPE(precision);
     return bwd_part(1, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
 }
 
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, const void* ws,
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
     RLT_PREC_SCOPE(precision);
     return bwd_part(2, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
