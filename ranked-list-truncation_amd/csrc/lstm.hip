@@ -20,6 +20,7 @@
 // (deterministic).  dA is written in place over the gate stash; dW_ih, dW_hh, db and dx are then
 // plain GEMMs / column sums on it (position-major layout makes h_{t-1} a row offset of B).
 #include "common.h"
+#include "lstm_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -36,13 +37,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // recurrence computes the 16 pre-activations of a lane from the I input values of its list and a per-direction table
 // (row -> W_ih[row][0..2], b_ih[row] + b_hh[row]) kept in LDS (8 KB; all lanes of a wavefront read the same two
 // addresses, a broadcast).
-struct XIn {
-    const float* x;            // (S*B, I) position-major, or null: `gates` holds the pre-activations
-    const float* w_ih[2];      // (512, I) per direction
-    const float* b_ih[2];
-    const float* b_hh[2];
-    int I;
-};
+using XIn = RltXIn;
 __device__ __forceinline__ void xin_table(const XIn& xi, int dir, int tid, int nthreads, float4* tab) {
     for (int row = tid; row < 4 * 128; row += nthreads) {
         const float* wr = xi.w_ih[dir] + (size_t)row * xi.I;
@@ -740,7 +735,11 @@ static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w
     const dim3 grid(rlt_cdiv(B, LISTS), 2), block(1024);
     hipStream_t st = rlt_stream(stream);
     static const bool lstm6_on = [] { const char* e = getenv("RLT_LSTM6"); return !e || atoi(e) != 0; }();      // RLT_LSTM6=0: the f32 MFMA kernels (A/B runs)
-    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on) {
+    static const bool lstm6w_on = [] { const char* e = getenv("RLT_LSTM6W"); return !e || atoi(e) != 0; }();    // RLT_LSTM6W=0: round 4's two-phase kernel
+    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on && lstm6w_on) {
+        const int rc = rlt_lstm6w_fwd(gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi, stream);
+        if (rc) return rc;
+    } else if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on) {
         auto go = [&](auto kern) {
             const int rc = rlt_allow_lds(kern, LSTM6_LDS);
             if (rc) return rc;

@@ -18,6 +18,8 @@ CASES = [
     (["tools/gen_gemm6e_slot.py"], "gemm6e_slot.inc"),
     (["tools/gen_attn6n_body.py", "dq"], "attention6n_dq1_body.inc"),
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
+    (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
+    (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
 ]
 
 

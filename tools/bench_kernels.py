@@ -146,6 +146,36 @@ def lstm(B=4096, S=300):
     print(f"bilstm_bwd B{B} S{S}: {ms:8.3f} ms  {fl / ms:7.1f} TF/s", flush=True)
 
 
+def lstm_x(B=4096, S=300):
+    """Layer 0: the recurrence with the fused input projection (I = 3)."""
+    T = S * B
+    x = torch.randn(T, 3, device=dev)
+    gates = torch.empty(T, 1024, device=dev)
+    w = torch.randn(2, 512, 128, device=dev) / 12
+    wi = torch.randn(2, 512, 3, device=dev) / 2
+    bi = torch.randn(2, 512, device=dev) / 4
+    bh = torch.randn(2, 512, device=dev) / 4
+    h = torch.empty(T, 256, device=dev)
+    c = torch.empty(T, 256, device=dev)
+    ms = timeit(lambda: call("rlt_bilstm_rec_fwd_x", ptr(x), 3, ptr(wi[0]), ptr(bi[0]), ptr(bh[0]), ptr(wi[1]), ptr(bi[1]), ptr(bh[1]),
+                             ptr(w[0]), ptr(w[1]), S, B, ptr(gates), ptr(h), ptr(c), N.PRECISION_DEFAULT, stream()), reps=2)
+    print(f"bilstm_fwd_x B{B} S{S}: {ms:8.3f} ms", flush=True)
+
+
+def lstm_w():
+    """Forward recurrences (layer 1 form and layer 0 with the fused input projection) over batch sizes."""
+    for B in (32, 63, 512, 4096):
+        S = 300
+        T = S * B
+        gates = torch.randn(T, 1024, device=dev) * 0.5
+        w = torch.randn(2, 512, 128, device=dev) / 12
+        h = torch.empty(T, 256, device=dev)
+        c = torch.empty(T, 256, device=dev)
+        ms = timeit(lambda: call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), N.PRECISION_DEFAULT, stream()), reps=3)
+        print(f"bilstm_fwd   B{B} S{S}: {ms:8.3f} ms  {ms / S * 1e3:6.2f} us / step", flush=True)
+        lstm_x(B, S)
+
+
 def lstm_small():
     for B in (32, 64, 256):
         lstm(B=B)

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Tick bodies of the whole-weights BiLSTM recurrences (csrc/lstm6w.hip): one wavefront per SIMD runs the MFMA chain of one
+16-list half while the vector ALU works through the element-wise part of the OTHER half, so every MFMA is followed by a fenced
+gap with ~8 cycles of vector / LDS / memory work (what a v_mfma_f32_16x16x32_bf16 hides, profiles/r05_notes.md).
+
+    python tools/gen_lstm6w_body.py fwd|fwd_xin|bwd > ranked-list-truncation_amd/csrc/lstm6w_<kind>_body.inc
+
+A body is a flat list of macro calls; the kernel defines them (chain half X, element-wise half Y).  The chain: 4 k-steps
+(forward: of the 128 hidden units; backward: 16 k-steps of the 512 gate rows) x the six plane products, smallest first per
+accumulator, consecutive MFMAs on different accumulators.  The element-wise work is emitted in dependence order, breadth
+first over the four units a lane holds per 16-unit block, so neighbours in the list are independent; the filler gives every gap
+up to BUDGET cycles of it.  LDS fragment reads of the chain sit at fixed positions ahead of their first use."""
+import sys
+
+BUDGET = 8
+PROD = [("m", "m"), ("l", "h"), ("h", "l"), ("m", "h"), ("h", "m"), ("h", "h")]      # (W plane, operand plane), smallest first
+
+
+def fwd_elem(xin):
+    """Element-wise micro-ops of one half: (text, cycles)."""
+    ops = []
+    for u in (0, 1):
+        if not xin:
+            for g in range(4):
+                ops.append((f"EA({u}, {g})", 8))           # acc += pre-activation
+            for g in range(4):
+                ops.append((f"LG({u}, {g})", 4))           # fetch the next step's pre-activations into the freed registers
+        for g in range(4):
+            ops.append((f"ES({u}, {g})", 8))               # scale for exp2
+        for g in range(4):
+            for r in range(4):
+                ops.append((f"EX({u}, {g}, {r})", 8))
+        for g in range(4):
+            ops.append((f"E1({u}, {g})", 8))
+        for g in range(4):
+            for r in range(4):
+                ops.append((f"ER({u}, {g}, {r})", 8))
+        ops.append((f"EG({u})", 8))                        # tanh of the cell candidate from its sigmoid form
+        for g in range(4):
+            ops.append((f"SG({u}, {g})", 4))               # store the activated gates
+        ops.append((f"EC1({u})", 8))
+        ops.append((f"EC2({u})", 8))
+        ops.append((f"SC({u})", 4))
+        ops.append((f"ET({u})", 8))
+        for r in range(4):
+            ops.append((f"EXC({u}, {r})", 8))
+        ops.append((f"E1C({u})", 8))
+        for r in range(4):
+            ops.append((f"ERC({u}, {r})", 8))
+        ops.append((f"EH1({u})", 8))
+        ops.append((f"EH2({u})", 8))
+        ops.append((f"SH({u})", 4))
+        for part, cyc in enumerate((8, 16, 16, 8, 16, 16, 8)):
+            ops.append((f"SP({u}, {part})", cyc))          # three-way split of the four new h values, in seven pieces
+        for pl in range(3):
+            ops.append((f"LW({u}, {pl})", 4))
+    if xin:
+        for part in range(4):
+            ops.append((f"XB({part})", 8))                 # the input-projection operand of this half's next chain + the next x fetch
+    return ops
+
+
+def fwd_body(xin):
+    mf = []
+    if xin:
+        for rb in range(8):
+            mf.append(f"MX({rb})")
+    for ks in range(4):
+        for rq in range(2):
+            for p, (wp, bp) in enumerate(PROD):
+                for j in range(4):
+                    rb = 4 * rq + j
+                    first = (not xin) and ks == 0 and p == 0
+                    mf.append(f"MF({rb}, {ks}, {p}, {1 if first else 0})")
+    nx = 8 if xin else 0
+    fixed = {}                                             # gap index -> LDS reads of the chain
+    for G in range(8):
+        ks, rq = divmod(G, 2)
+        base = nx + 24 * G
+        for j in range(4):                                 # l fragments of the next group (the last group: of the next tick's first)
+            Gn = (G + 1) % 8
+            fixed.setdefault(base + 8 + j, []).append(f"RL({4 * (Gn % 2) + j}, {Gn // 2}, {j})")
+        if rq == 1 and ks < 3:
+            for pl in range(3):
+                fixed.setdefault(base + 12 + pl, []).append(f"RB({ks + 1}, {pl})")
+    ops = fwd_elem(xin)
+    out = []
+    qi = 0
+    for i, m in enumerate(mf):
+        line = [m]
+        budget = BUDGET
+        for f in fixed.get(i, []):
+            line.append(f)
+            budget -= 4
+        while qi < len(ops) and (ops[qi][1] <= budget or budget == BUDGET):
+            line.append(ops[qi][0])
+            budget -= ops[qi][1]
+            qi += 1
+        out.append("; ".join(line) + "; GAP_END;")
+    rest = []
+    while qi < len(ops):
+        rest.append(ops[qi][0])
+        qi += 1
+    if rest:
+        out.append("; ".join(rest) + "; GAP_END;")
+    return out
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+    if kind in ("fwd", "fwd_xin"):
+        lines = fwd_body(kind == "fwd_xin")
+    else:
+        raise SystemExit("kind: fwd | fwd_xin")
+    print(f"// generated by tools/gen_lstm6w_body.py {kind} - do not edit")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
