@@ -799,7 +799,15 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
     int rc = rlt_allow_lds(bilstm_bwd_kernel, shm);
     if (!rc) rc = rlt_allow_lds(bilstm3_bwd8_kernel, shm8);
     if (rc) return rc;
-    if (rlt_precision() == RLT_PRECISION_BF16X3)
+    static const bool lstm6w_bwd_on = [] {        // RLT_LSTM6W=0 / RLT_LSTM6W_BWD=0: the f32 MFMA backward recurrence of rounds 1-4 (A/B runs)
+        const char* e = getenv("RLT_LSTM6W");
+        const char* b = getenv("RLT_LSTM6W_BWD");
+        return (!e || atoi(e) != 0) && (!b || atoi(b) != 0);
+    }();
+    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6w_bwd_on) {
+        rc = rlt_lstm6w_bwd(gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B, stream);
+        if (rc) return rc;
+    } else if (rlt_precision() == RLT_PRECISION_BF16X3)
         hipLaunchKernelGGL(bilstm3_bwd8_kernel, dim3(rlt_cdiv(B, LISTS), 2), dim3(512), shm8, rlt_stream(stream),
                            gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B);
     else

@@ -310,6 +310,257 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_fwd_kernel(float* __restrict_
 #undef GAP_END
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward recurrence, same scheme.  dh_{t-1}[unit][list] = sum over the 512 gate rows of W_hh[row][unit] dA_t[row][list]: wavefront w
+// owns OUTPUT units 32w .. 32w+31 (two 16-unit blocks) over the whole contraction - no partial sums cross wavefronts (rounds 1-4
+// split the rows over 16 wavefronts and reduced 16 partial tiles through LDS, two barriers and 132 KB per step).  A operand =
+// W_hh^T (row l&15 = output unit, k slot 32 ks + 8 (l>>4) + j <-> gate row of unit 8 ks + 2 (l>>4) + (j>>2), gate j&3), B = the
+// three planes of dA_t, which every wavefront reads whole from LDS: [plane][list][512 slots] bf16, 16-byte chunks XOR-swizzled
+// with the list (no padding: LDS is full).  W_hh^T: h and m planes = the 256 AGPRs, l plane half in VGPRs (k-steps 0-7) and half in
+// LDS (k-steps 8-15, 64 KB); dA planes of the two halves 96 KB: 160 KB exactly.  C: lane holds units 4 (l>>4) + r of list l&15 -
+// where the gate arithmetic of those units runs (dA of unit u, gates i f g o = slots 4u .. 4u+3: a lane's four units are 32
+// contiguous bytes of a plane).  Inputs of a step (gates, c_{t-1}, dL/dh) are fetched ONE tick ahead into a 12 x 4 register
+// pool that both halves share, each slot reloaded for the other half as soon as this half has consumed it.
+constexpr int WB_PLANE = 16 * 1024;                 // one plane of dA of a half: 16 lists x 512 bf16
+constexpr int WB_HALF = 3 * WB_PLANE;
+constexpr int WB_WL = 4 * 2 * 8 * 64 * 16;          // l plane of W_hh^T, k-steps 8-15: [wavefront][block][k-step - 8][lane] x 16 B
+constexpr size_t WB_LDS = (size_t)2 * WB_HALF + WB_WL;
+static_assert(WB_LDS == 160 * 1024, "the backward recurrence fills LDS exactly");
+
+__global__ __launch_bounds__(256, 1) void bilstm6w_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                              const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
+                                                              const float* __restrict__ d_hout, int S, int B) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm6w[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 32;
+    uint8_t* dax = sm6w;                                                    // [half][plane][list][64 chunks]
+    uint4* wl_s = reinterpret_cast<uint4*>(sm6w + 2 * WB_HALF);
+
+    // ---- stationary operand: W_hh^T ----
+    bf16x8 wh[2][16], wm[2][16], wlv[2][8];
+    {
+        const float* whh = dir ? w_hh_r : w_hh_f;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            const float* wp = whh + 32 * w + 16 * ub + n + (size_t)(2 * q) * HID;      // column = output unit
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                asm volatile("" : "+v"(wp));              // (opaque: hipcc would form all 256 addresses up front and spill them)
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = wp[(size_t)((j & 3) * HID + 8 * ks + (j >> 2)) * HID];
+                uint2 h0, m0, l0, h1, m1, l1;
+                split4w(v[0], v[1], v[2], v[3], h0, m0, l0);
+                split4w(v[4], v[5], v[6], v[7], h1, m1, l1);
+                wh[ub][ks] = frag8(h0.x, h0.y, h1.x, h1.y);
+                wm[ub][ks] = frag8(m0.x, m0.y, m1.x, m1.y);
+                asm volatile("" : "+a"(wh[ub][ks]), "+a"(wm[ub][ks]) : : "memory");     // ("memory": the loads of later fragments stay behind)
+                if (ks >= 8) wl_s[((w * 2 + ub) * 8 + (ks - 8)) * 64 + lane] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        }
+        // the l fragments of k-steps 0-7 in a second pass, when the other planes are in their AGPRs (in one pass hipcc spills them
+        // through scratch during the set-up - harmless, but with a scratch access on record it waits with vmcnt(0) in every tick)
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            const float* wp = whh + 32 * w + 16 * ub + n + (size_t)(2 * q) * HID;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                asm volatile("" : "+v"(wp));
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = wp[(size_t)((j & 3) * HID + 8 * ks + (j >> 2)) * HID];
+                uint2 h0, m0, l0, h1, m1, l1;
+                split4w(v[0], v[1], v[2], v[3], h0, m0, l0);
+                split4w(v[4], v[5], v[6], v[7], h1, m1, l1);
+                wlv[ub][ks] = frag8(l0.x, l0.y, l1.x, l1.y);
+                asm volatile("" : "+v"(wlv[ub][ks]) : : "memory");
+            }
+        }
+    }
+
+    // ---- per-lane addresses ----
+    const uint32_t voff_g[2] = {(uint32_t)(b0 + n) * 4096u + dir * 2048u + 128u * w + 16u * q,
+                                (uint32_t)(b0 + 16 + n) * 4096u + dir * 2048u + 128u * w + 16u * q};      // gate rows: + 512 g + 64 ub
+    const uint32_t voff_h[2] = {(uint32_t)(b0 + n) * 1024u + dir * 512u + 128u * w + 16u * q,
+                                (uint32_t)(b0 + 16 + n) * 1024u + dir * 512u + 128u * w + 16u * q};       // c / dh rows: + 64 ub
+    // reads of dA: chunk 4 ks + q of list n sits at (4 ks + q) ^ n = 4 (ks ^ (n >> 2)) + (q ^ (n & 3)): one base per ks & 3, + 256 (ks >> 2)
+    const uint8_t* drd[2][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) drd[hf][j] = dax + hf * WB_HALF + n * 1024 + 64 * (j ^ (n >> 2)) + 16 * (q ^ (n & 3));
+    // writes: a lane's block-ub units are chunks 16 w + 8 ub + 2 q (units r = 0, 1) and the next one (r = 2, 3)
+    uint32_t dwr[2][2];                 // (byte offsets into LDS: a pointer that has been through an integer XOR becomes a FLAT access)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) dwr[hf][ub] = hf * WB_HALF + n * 1024 + 16 * ((16 * w + 8 * ub + 2 * q) ^ n);
+    const uint8_t* wlrd = sm6w + 2 * WB_HALF + w * 16384 + lane * 16;                                       // + 1024 (8 ub + ks - 8)
+    // elem index tt = 0 .. S-1 walks time backwards: t = S-1-tt, position s = t (forward direction) or S-1-t (reverse)
+    auto pos_of = [&](int tt) { return dir ? tt : S - 1 - tt; };
+    auto rs_gates = [&](int tt) { return rsrc_of(gates + (size_t)pos_of(tt) * B * (8 * HID), (uint32_t)B * 4096u); };
+    auto rs_dh = [&](int tt) { return rsrc_of(d_hout + (size_t)pos_of(tt) * B * (2 * HID), (uint32_t)B * 1024u); };
+    auto rs_cprev = [&](int tt) {      // c_{t-1}: the position one step earlier in time; t = 0 has none (bound 0: reads return zero)
+        const int sp = dir ? pos_of(tt) + 1 : pos_of(tt) - 1;
+        const bool has = tt + 1 < S;
+        return rsrc_of(cst + (size_t)(has ? sp : 0) * B * (2 * HID), has ? (uint32_t)B * 1024u : 0u);
+    };
+
+    // ---- state ----
+    f32x4 in[12], ct[2][2], dc[2][2], acc[2][2], tcv, dhv, dcu, t0, t1, t2;
+    bf16x8 bfr[2][3], lfr[2];
+    uint32_t h4[4], m4[4], l4[4];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) { dc[hf][ub] = z4; acc[hf][ub] = z4; }
+    tcv = dhv = dcu = t0 = t1 = t2 = z4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h4[i] = m4[i] = l4[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) (&bfr[0][0])[i] = frag8(0u, 0u, 0u, 0u);
+    lfr[0] = lfr[1] = frag8(0u, 0u, 0u, 0u);
+    {
+        const __amdgpu_buffer_rsrc_t rc = rsrc_of(cst + (size_t)pos_of(0) * B * (2 * HID), (uint32_t)B * 1024u);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+                ct[hf][ub] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, voff_h[hf] + 64 * ub, 0, 0));
+    }
+    auto load_slot = [&](int k, int hf, __amdgpu_buffer_rsrc_t rg, __amdgpu_buffer_rsrc_t rcp, __amdgpu_buffer_rsrc_t rdh) __attribute__((always_inline)) {
+        if (k < 8) in[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, voff_g[hf] + 512 * (k & 3) + 64 * (k >> 2), 0, 0));
+        else if (k < 10) in[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rcp, voff_h[hf] + 64 * (k - 8), 0, 0));
+        else in[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdh, voff_h[hf] + 64 * (k - 10), 0, 0));
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rg = rs_gates(0), rcp = rs_cprev(0), rdh = rs_dh(0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) load_slot(k, 0, rg, rcp, rdh);
+    }
+    // consumed here: no load is pending when the first tick starts (hipcc would carry the prologue's vmcnt picture into the loop)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" : "+v"(in[k]));
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) asm volatile("" : "+v"(ct[hf][0]), "+v"(ct[hf][1]));
+    __syncthreads();
+
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+    // One tick: chain of half X on the dA its last element-wise tick left in LDS; element-wise step ttY of half Y = 1 - X, whose pool slots
+    // are reloaded for half X's step ttN as they are consumed.
+    auto tick = [&](auto XC, auto MC, int ttY, int ttN) __attribute__((always_inline)) {
+        constexpr int X = decltype(XC)::value, Y = 1 - X, MODE = decltype(MC)::value;
+        constexpr bool CH = MODE != TICK_ELEM, EL = MODE != TICK_CHAIN;
+        const __amdgpu_buffer_rsrc_t rgY = rs_gates(ttY), rgN = rs_gates(ttN), rcpN = rs_cprev(ttN), rdhN = rs_dh(ttN);
+        auto RB = [&](int ks, int pl) __attribute__((always_inline)) {
+            if (CH) bfr[ks & 1][pl] = *reinterpret_cast<const bf16x8*>(drd[X][ks & 3] + pl * WB_PLANE + 256 * (ks >> 2));
+        };
+        auto RL = [&](int ub, int ks) __attribute__((always_inline)) {
+            if (CH) lfr[ub] = *reinterpret_cast<const bf16x8*>(wlrd + 1024 * (8 * ub + ks - 8));
+        };
+        auto MB = [&](int ub, int ks, int p, int first) __attribute__((always_inline)) {
+            if (!CH || (RLT_W6_ABL & 4)) return;
+            const int bp = p == 2 ? 2 : (p == 0 || p == 4) ? 1 : 0;              // dA plane: m, h, l, h, m, h
+            const bf16x8 bv = bfr[ks & 1][bp];
+            f32x4& d = acc[X][ub];
+            if (p == 1) {                                                        // W plane l: registers (k-steps 0-7) or the LDS fragment
+                const bf16x8 lv = ks < 8 ? wlv[ub][ks < 8 ? ks : 0] : lfr[ub];
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(lv), "v"(bv));
+            } else {
+                const bf16x8 av = (p == 0 || p == 3) ? wm[ub][ks] : wh[ub][ks];
+                // (the first product of a chain reads a zero C operand but keeps the accumulator TIED: as a plain output hipcc gives it
+                //  fresh registers every tick and moves pool slots - still being loaded - out of their way, waiting with vmcnt(0))
+                if (first) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+v"(d) : "a"(av), "v"(bv));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(av), "v"(bv));
+            }
+        };
+        // ---- element-wise side: i, f, g, o of block u in in[4u .. 4u+3], c_{t-1} in in[8+u], dL/dh in in[10+u] ----
+        auto T1 = [&](int u) __attribute__((always_inline)) { if (EL) tcv = ct[Y][u] * (-2.f * LOG2E); };
+        auto TX = [&](int u, int r) __attribute__((always_inline)) { if (EL) tcv[r] = rlt_exp2(tcv[r]); };
+        auto T3 = [&](int u) __attribute__((always_inline)) { if (EL) tcv += 1.f; };
+        auto TR = [&](int u, int r) __attribute__((always_inline)) { if (EL) tcv[r] = __builtin_amdgcn_rcpf(tcv[r]); };
+        auto T5 = [&](int u) __attribute__((always_inline)) { if (EL) tcv = 2.f * tcv - 1.f; };                         // tanh(c_t)
+        auto B1 = [&](int u) __attribute__((always_inline)) { if (EL) dhv = in[10 + u] + acc[Y][u]; };
+        auto LDN = [&](int k) __attribute__((always_inline)) { if (EL && !(RLT_W6_ABL & 2)) load_slot(k, X, rgN, rcpN, rdhN); };
+        auto B2 = [&](int u) __attribute__((always_inline)) { if (EL) t0 = dhv * in[4 * u + 3]; };
+        auto B3 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = tcv * tcv; t1 = 1.f - t1; } };
+        auto B5 = [&](int u) __attribute__((always_inline)) { if (EL) { t0 = t0 * t1; dcu = t0 + dc[Y][u]; } };
+        auto B6 = [&](int u) __attribute__((always_inline)) { if (EL) t0 = dhv * tcv; };
+        auto B7 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = 1.f - in[4 * u + 3]; t1 = t1 * in[4 * u + 3]; } };
+        auto B8 = [&](int u) __attribute__((always_inline)) { if (EL) in[4 * u + 3] = t0 * t1; };                      // dA_o
+        auto B9 = [&](int u) __attribute__((always_inline)) { if (EL) t2 = dcu * in[4 * u]; };
+        auto B10 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = 1.f - in[4 * u]; t1 = t1 * in[4 * u]; } };
+        auto B11 = [&](int u) __attribute__((always_inline)) { if (EL) { t0 = dcu * in[4 * u + 2]; in[4 * u] = t0 * t1; } };   // dA_i
+        auto B12 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = in[4 * u + 2] * in[4 * u + 2]; t1 = 1.f - t1; } };
+        auto B13 = [&](int u) __attribute__((always_inline)) { if (EL) in[4 * u + 2] = t2 * t1; };                     // dA_g
+        auto B14 = [&](int u) __attribute__((always_inline)) { if (EL) t0 = dcu * in[8 + u]; };
+        auto B15 = [&](int u) __attribute__((always_inline)) {          // c_{t-1} is the next step's c_t: four real moves HERE (as a plain copy
+            if (!EL) return;                                            // hipcc renames the slot instead and shuffles at the loop head, behind vmcnt(0))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(ct[Y][u][r]) : "v"(in[8 + u][r]));
+        };
+        auto B16 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = 1.f - in[4 * u + 1]; t1 = t1 * in[4 * u + 1]; } };
+        auto B17 = [&](int u) __attribute__((always_inline)) { if (EL) dc[Y][u] = dcu * in[4 * u + 1]; };
+        auto B18 = [&](int u) __attribute__((always_inline)) { if (EL) in[4 * u + 1] = t0 * t1; };                     // dA_f
+        auto ST = [&](int u, int g) __attribute__((always_inline)) {
+            if (EL && !(RLT_W6_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, in[4 * u + g]), rgY, voff_g[Y] + 512 * g + 64 * u, 0, 0);
+        };
+        // split of the chunk of units r = 2 ch, 2 ch + 1 (slots i f g o | i f g o), residuals in place
+        auto SP = [&](int u, int ch, int part) __attribute__((always_inline)) {
+            if (!EL) return;
+            f32x4 &vi = in[4 * u], &vf = in[4 * u + 1], &vg = in[4 * u + 2], &vo = in[4 * u + 3];
+            const int r0 = 2 * ch, r1 = 2 * ch + 1;
+            auto hi4 = [&](uint32_t (&o4)[4]) __attribute__((always_inline)) {
+                o4[0] = pk2w(vi[r0], vf[r0]); o4[1] = pk2w(vg[r0], vo[r0]); o4[2] = pk2w(vi[r1], vf[r1]); o4[3] = pk2w(vg[r1], vo[r1]);
+                asm("" : "+v"(o4[0]), "+v"(o4[1]), "+v"(o4[2]), "+v"(o4[3]));
+            };
+            auto res = [&](const uint32_t (&o4)[4], int r, int k) __attribute__((always_inline)) {
+                vi[r] -= bf_lo(o4[k]); vf[r] -= bf_hi(o4[k]); vg[r] -= bf_lo(o4[k + 1]); vo[r] -= bf_hi(o4[k + 1]);
+            };
+            if (part == 0) hi4(h4);
+            if (part == 1) res(h4, r0, 0);
+            if (part == 2) res(h4, r1, 2);
+            if (part == 3) hi4(m4);
+            if (part == 4) res(m4, r0, 0);
+            if (part == 5) res(m4, r1, 2);
+            if (part == 6) hi4(l4);
+        };
+        auto LW = [&](int u, int ch, int pl) __attribute__((always_inline)) {
+            if (!EL) return;
+            const uint32_t (&o4)[4] = pl == 0 ? h4 : pl == 1 ? m4 : l4;
+            *reinterpret_cast<uint4*>(dax + ((dwr[Y][u] ^ (ch ? 16u : 0u)) + pl * WB_PLANE)) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        };
+        if (CH) { RB(0, 0); RB(0, 1); RB(0, 2); }
+        GAP_END;
+#include "lstm6w_bwd_body.inc"
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    const std::integral_constant<int, 0> H0;
+    const std::integral_constant<int, 1> H1;
+    const std::integral_constant<int, TICK_FULL> MFULL;
+    const std::integral_constant<int, TICK_ELEM> MELEM;
+
+    tick(H1, MELEM, 0, 0);                                  // element-wise step 0 of half 0; its slots reloaded for half 1's step 0
+    if (S > 1) {                                            // (first tick pair outside the loop, as in the forward kernel)
+        tick(H0, MFULL, 0, 1);                              // chain of half 0 | step 0 of half 1, slots -> half 0's step 1
+        tick(H1, MFULL, 1, 1);                              // chain of half 1 | step 1 of half 0, slots -> half 1's step 1
+    }
+    for (int tt = 1; tt + 1 < S; ++tt) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                asm volatile("" : "+a"(wh[ub][4 * k4]), "+a"(wh[ub][4 * k4 + 1]), "+a"(wh[ub][4 * k4 + 2]), "+a"(wh[ub][4 * k4 + 3]),
+                             "+a"(wm[ub][4 * k4]), "+a"(wm[ub][4 * k4 + 1]), "+a"(wm[ub][4 * k4 + 2]), "+a"(wm[ub][4 * k4 + 3]));
+        tick(H0, MFULL, tt, tt + 1);
+        tick(H1, MFULL, tt + 1, tt + 1);
+    }
+    tick(H0, MELEM, S - 1, S - 1);                          // the last step of half 1 (reloads: the same rows once more, never used)
+#undef GAP_END
+}
+
 }  // namespace
 
 int rlt_lstm6w_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B, float* h_out, float* c_out,
@@ -325,5 +576,14 @@ int rlt_lstm6w_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, i
         if (rc) return rc;
         hipLaunchKernelGGL(bilstm6w_fwd_kernel<false>, grid, block, W6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
     }
+    return 0;
+}
+
+int rlt_lstm6w_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev, const float* d_hout, int S, int B,
+                   void* stream) {
+    const int rc = rlt_allow_lds(bilstm6w_bwd_kernel, WB_LDS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bilstm6w_bwd_kernel, dim3(rlt_cdiv(B, 32), 2), dim3(256), WB_LDS, rlt_stream(stream), gates, c, w_hh_fwd,
+                       w_hh_rev, d_hout, S, B);
     return 0;
 }

@@ -14,3 +14,5 @@ struct RltXIn {
 // lstm6w.hip: bf16x6 recurrences with one wavefront per SIMD; 0 or a hip error code
 int rlt_lstm6w_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B, float* h_out, float* c_out,
                    const RltXIn& xi, void* stream);
+int rlt_lstm6w_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev, const float* d_hout, int S, int B,
+                   void* stream);

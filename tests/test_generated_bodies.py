@@ -20,6 +20,7 @@ CASES = [
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
+    (["tools/gen_lstm6w_body.py", "bwd"], "lstm6w_bwd_body.inc"),
 ]
 
 
@@ -92,3 +93,55 @@ def test_attention6n_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
         loop = max(blocks, key=lambda b: b.count("v_mfma"))
         assert loop.count("v_mfma_f32_16x16x32_bf16") == nmf
         assert "v_accvgpr" not in loop and "scratch_" not in loop
+
+
+def test_lstm6w_bodies_cover_every_mfma_once():
+    """Tick bodies of the whole-weights BiLSTM recurrences: every (block, k-step, product) of the chain exactly once, each element-wise
+    micro-op and each LDS fragment read exactly once."""
+    import re
+    from collections import Counter
+    for inc, nmf, macro in (("lstm6w_fwd_body.inc", 192, "MF"), ("lstm6w_fwd_xin_body.inc", 192, "MF"), ("lstm6w_bwd_body.inc", 192, "MB")):
+        text = open(os.path.join(CSRC, inc)).read()
+        mf = re.findall(r"\b" + macro + r"\((\d+), (\d+), (\d+), (\d+)\)", text)
+        assert len(mf) == nmf and len(set(m[:3] for m in mf)) == nmf
+        firsts = [m for m in mf if m[3] == "1"]
+        if inc == "lstm6w_fwd_body.inc":
+            assert sorted(int(m[0]) for m in firsts) == list(range(8)) and all(m[1] == "0" and m[2] == "0" for m in firsts)
+        elif inc == "lstm6w_bwd_body.inc":
+            assert sorted(int(m[0]) for m in firsts) == [0, 1] and all(m[1] == "0" and m[2] == "0" for m in firsts)
+        else:
+            assert not firsts and len(re.findall(r"\bMX\(", text)) == 8       # the input projection starts the accumulators
+        calls = Counter(re.findall(r"\b([A-Z][A-Z0-9]*\([^)]*\))", text))
+        assert set(calls.values()) == {1}
+        # every accumulator's products in the order smallest first within a k-step
+        seq = {}
+        for a, ks, p, _f in mf:
+            seq.setdefault((a, ks), []).append(int(p))
+        assert all(v == [0, 1, 2, 3, 4, 5] for v in seq.values())
+
+
+def test_lstm6w_loops_have_no_compiler_register_traffic(tmp_path):
+    """The MFMAs of the recurrences are asm statements (nothing is padded in front of them): their tick loops must hold no
+    v_accvgpr_* move, no scratch access and no FLAT access (a FLAT access makes hipcc wait with vmcnt(0) / lgkmcnt(0) in every tick)."""
+    import re
+    import shutil
+    from rlt_hip import build as B
+    if shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "w6.s"
+    src = os.path.join(CSRC, "lstm6w.hip")
+    subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["lstm6w.hip"] + ["-S", "--cuda-device-only", src, "-o", str(asm)], check=True,
+                   capture_output=True)
+    text = asm.read_text()
+    kernels = re.findall(r"^(_ZN12_GLOBAL__N_119bilstm6w_\w+):(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 3
+    for name, body in kernels:
+        assert "scratch_" not in body, name                       # nothing spills anywhere in the kernel
+        blocks = re.split(r"^\.LBB\w+:", body, flags=re.M)
+        ticks = [b for b in blocks if b.count("v_mfma") >= 192]                 # every block that holds tick bodies
+        loops = [b for b in ticks if b.count("v_mfma_f32_16x16x32_bf16") in (384, 400) and "s_cbranch" in b]      # the steady-state tick pair
+        assert loops, name
+        for b in ticks:
+            assert "v_accvgpr" not in b and "flat_" not in b, name
+        for loop in loops:
+            assert "vmcnt(0)" not in loop, name

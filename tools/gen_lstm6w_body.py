@@ -12,7 +12,7 @@ first over the four units a lane holds per 16-unit block, so neighbours in the l
 up to BUDGET cycles of it.  LDS fragment reads of the chain sit at fixed positions ahead of their first use."""
 import sys
 
-BUDGET = 8
+BUDGET = int(__import__('os').environ.get('GEN_BUDGET', '8'))
 PROD = [("m", "m"), ("l", "h"), ("h", "l"), ("m", "h"), ("h", "m"), ("h", "h")]      # (W plane, operand plane), smallest first
 
 
@@ -106,12 +106,83 @@ def fwd_body(xin):
     return out
 
 
+def bwd_elem():
+    """Element-wise micro-ops of one half of the backward step (csrc/lstm6w.hip names them)."""
+    ops = []
+    for u in (0, 1):
+        ops.append((f"T1({u})", 8))
+        for r in range(4):
+            ops.append((f"TX({u}, {r})", 8))
+        ops.append((f"T3({u})", 8))
+        for r in range(4):
+            ops.append((f"TR({u}, {r})", 8))
+        ops.append((f"T5({u})", 16))
+        for name, cyc in (("B1", 8), ("LDN10", 4), ("B2", 8), ("B3", 16), ("B5", 16), ("B6", 8), ("B7", 16), ("B8", 8), ("ST3", 4),
+                          ("B9", 8), ("B10", 16), ("B11", 16), ("ST0", 4), ("B12", 16), ("B13", 8), ("ST2", 4), ("B14", 8), ("B15", 16),
+                          ("LDN8", 4), ("B16", 16), ("B17", 8), ("B18", 8), ("ST1", 4)):
+            if name.startswith("LDN"):
+                ops.append((f"LDN({int(name[3:]) + u})", cyc))
+            elif name.startswith("ST"):
+                ops.append((f"ST({u}, {name[2:]})", cyc))
+            else:
+                ops.append((f"{name}({u})", cyc))
+        for ch in (0, 1):
+            for part, cyc in enumerate((16, 24, 24, 16, 24, 24, 16)):
+                ops.append((f"SP({u}, {ch}, {part})", cyc))
+            for pl in range(3):
+                ops.append((f"LW({u}, {ch}, {pl})", 4))
+        for g in range(4):
+            ops.append((f"LDN({4 * u + g})", 4))
+    return ops
+
+
+def bwd_body():
+    mf = []
+    for ks in range(16):
+        for p in range(6):
+            for ub in range(2):
+                mf.append(f"MB({ub}, {ks}, {p}, {1 if ks == 0 and p == 0 else 0})")
+    fixed = {}
+    for ks in range(16):
+        base = 12 * ks
+        if ks < 15:
+            for pl in range(3):
+                fixed.setdefault(base + 5 + pl, []).append(f"RB({ks + 1}, {pl})")
+        if 7 <= ks < 15:                                   # the l fragments of k-steps 8-15 come from LDS, one k-step ahead
+            for ub in range(2):
+                fixed.setdefault(base + 9 + ub, []).append(f"RL({ub}, {ks + 1})")
+    ops = bwd_elem()
+    return fill(mf, fixed, ops)
+
+
+def fill(mf, fixed, ops):
+    out = []
+    qi = 0
+    for i, m in enumerate(mf):
+        line = [m]
+        budget = BUDGET
+        for f in fixed.get(i, []):
+            line.append(f)
+            budget -= 4
+        while qi < len(ops) and (ops[qi][1] <= budget or budget == BUDGET):
+            line.append(ops[qi][0])
+            budget -= ops[qi][1]
+            qi += 1
+        out.append("; ".join(line) + "; GAP_END;")
+    rest = [o[0] for o in ops[qi:]]
+    if rest:
+        out.append("; ".join(rest) + "; GAP_END;")
+    return out
+
+
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
     if kind in ("fwd", "fwd_xin"):
         lines = fwd_body(kind == "fwd_xin")
+    elif kind == "bwd":
+        lines = bwd_body()
     else:
-        raise SystemExit("kind: fwd | fwd_xin")
+        raise SystemExit("kind: fwd | fwd_xin | bwd")
     print(f"// generated by tools/gen_lstm6w_body.py {kind} - do not edit")
     print("\n".join(lines))
 
