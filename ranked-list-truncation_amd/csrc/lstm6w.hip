@@ -63,17 +63,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, uint32_
 }
 
 enum { TICK_FULL = 0, TICK_CHAIN = 1, TICK_ELEM = 2 };
+#ifndef RLT_W6_STAGGER
+#define RLT_W6_STAGGER 0    // experiment: wavefront w starts a tick 16 * w * RLT_W6_STAGGER cycles late (memory / LDS instructions of the four out of step)
+#endif
 #ifndef RLT_W6_ABL
 #define RLT_W6_ABL 0        // timing ablations (tools/build_variant.py; wrong results): 1 no stores, 2 no pre-activation loads, 4 no MFMAs, 8 no exp / rcp
 #endif
 
-template <bool XIN>
+// SINGLE (batches that give every CU at most one 16-list half: B <= 16 x 128 per direction): a workgroup owns ONE half and a step is
+// chain tick, then element-wise tick of the SAME half (nothing to overlap, but a step is one chain long instead of two: the latency
+// of the recurrence halves - the reference's batch sizes, hyper_parameter_*.conf batch_size = 63 / 64).
+template <bool XIN, bool SINGLE>
 __global__ __launch_bounds__(256, 1) void bilstm6w_fwd_kernel(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                               const float* __restrict__ w_hh_r, int S, int B,
                                                               float* __restrict__ h_out, float* __restrict__ c_out, RltXIn xi) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm6w[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
-    const int dir = blockIdx.y, b0 = blockIdx.x * 32;
+    const int dir = blockIdx.y, b0 = blockIdx.x * (SINGLE ? 16 : 32);
     uint4* wl_s = reinterpret_cast<uint4*>(sm6w);
     uint8_t* hx = sm6w + W6_WL;
 
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_fwd_kernel(float* __restrict_
 #include "lstm6w_fwd_body.inc"
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i = 0; i < w * RLT_W6_STAGGER; ++i) asm volatile("s_nop 15");
     };
     const std::integral_constant<int, 0> H0;
     const std::integral_constant<int, 1> H1;
@@ -291,6 +298,17 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_fwd_kernel(float* __restrict_
     const std::integral_constant<int, TICK_CHAIN> MCHAIN;
     const std::integral_constant<int, TICK_ELEM> MELEM;
 
+    if constexpr (SINGLE) {
+        for (int t = 0; t < S; ++t) {
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb)
+                asm volatile("" : "+a"(wh[rb][0]), "+a"(wh[rb][1]), "+a"(wh[rb][2]), "+a"(wh[rb][3]), "+a"(wm[rb][0]), "+a"(wm[rb][1]),
+                             "+a"(wm[rb][2]), "+a"(wm[rb][3]));
+            tick(H0, MCHAIN, t, t);                 // chain of half 0
+            tick(H1, MELEM, t, t);                  // its element-wise step (Y = 0)
+        }
+        return;
+    }
     tick(H0, MCHAIN, 0, 0);
     if (S > 1) {       // the first tick pair outside the loop: the loop is then entered with the picture of outstanding loads and stores
                        // its back edge carries, and hipcc's vmcnt counts in it are the steady-state ones (not the prologue's few)
@@ -328,12 +346,13 @@ constexpr int WB_WL = 4 * 2 * 8 * 64 * 16;          // l plane of W_hh^T, k-step
 constexpr size_t WB_LDS = (size_t)2 * WB_HALF + WB_WL;
 static_assert(WB_LDS == 160 * 1024, "the backward recurrence fills LDS exactly");
 
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 1) void bilstm6w_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                               const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
                                                               const float* __restrict__ d_hout, int S, int B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm6w[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
-    const int dir = blockIdx.y, b0 = blockIdx.x * 32;
+    const int dir = blockIdx.y, b0 = blockIdx.x * (SINGLE ? 16 : 32);
     uint8_t* dax = sm6w;                                                    // [half][plane][list][64 chunks]
     uint4* wl_s = reinterpret_cast<uint4*>(sm6w + 2 * WB_HALF);
 
@@ -483,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_bwd_kernel(float* __restrict_
         auto TR = [&](int u, int r) __attribute__((always_inline)) { if (EL) tcv[r] = __builtin_amdgcn_rcpf(tcv[r]); };
         auto T5 = [&](int u) __attribute__((always_inline)) { if (EL) tcv = 2.f * tcv - 1.f; };                         // tanh(c_t)
         auto B1 = [&](int u) __attribute__((always_inline)) { if (EL) dhv = in[10 + u] + acc[Y][u]; };
-        auto LDN = [&](int k) __attribute__((always_inline)) { if (EL && !(RLT_W6_ABL & 2)) load_slot(k, X, rgN, rcpN, rdhN); };
+        auto LDN = [&](int k) __attribute__((always_inline)) { if (EL && !(RLT_W6_ABL & 2)) load_slot(k, SINGLE ? Y : X, rgN, rcpN, rdhN); };
         auto B2 = [&](int u) __attribute__((always_inline)) { if (EL) t0 = dhv * in[4 * u + 3]; };
         auto B3 = [&](int u) __attribute__((always_inline)) { if (EL) { t1 = tcv * tcv; t1 = 1.f - t1; } };
         auto B5 = [&](int u) __attribute__((always_inline)) { if (EL) { t0 = t0 * t1; dcu = t0 + dc[Y][u]; } };
@@ -536,12 +555,27 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_bwd_kernel(float* __restrict_
         GAP_END;
 #include "lstm6w_bwd_body.inc"
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i = 0; i < w * RLT_W6_STAGGER; ++i) asm volatile("s_nop 15");
     };
     const std::integral_constant<int, 0> H0;
     const std::integral_constant<int, 1> H1;
     const std::integral_constant<int, TICK_FULL> MFULL;
     const std::integral_constant<int, TICK_ELEM> MELEM;
 
+    const std::integral_constant<int, TICK_CHAIN> MCHAIN;
+    if constexpr (SINGLE) {
+        for (int tt = 0; tt < S; ++tt) {
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+                    asm volatile("" : "+a"(wh[ub][4 * k4]), "+a"(wh[ub][4 * k4 + 1]), "+a"(wh[ub][4 * k4 + 2]), "+a"(wh[ub][4 * k4 + 3]),
+                                 "+a"(wm[ub][4 * k4]), "+a"(wm[ub][4 * k4 + 1]), "+a"(wm[ub][4 * k4 + 2]), "+a"(wm[ub][4 * k4 + 3]));
+            tick(H1, MELEM, tt, tt + 1 < S ? tt + 1 : tt);      // element-wise step of half 0 (Y = 0), slots reloaded for its next step
+            tick(H0, MCHAIN, tt, tt);                           // chain of half 0 (the one behind the last step is not needed: one tick of S)
+        }
+        return;
+    }
     tick(H1, MELEM, 0, 0);                                  // element-wise step 0 of half 0; its slots reloaded for half 1's step 0
     if (S > 1) {                                            // (first tick pair outside the loop, as in the forward kernel)
         tick(H0, MFULL, 0, 1);                              // chain of half 0 | step 0 of half 1, slots -> half 0's step 1
@@ -563,27 +597,36 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_bwd_kernel(float* __restrict_
 
 }  // namespace
 
+// one 16-list half per workgroup while that still gives every workgroup its own CU (256 CUs, two directions)
+static bool w6_single(int B) {
+    static const int on = [] { const char* e = getenv("RLT_LSTM6W_SINGLE"); return e ? atoi(e) : 1; }();      // 0: always two halves (A/B runs)
+    return on && B <= 16 * 128;
+}
+
 int rlt_lstm6w_fwd(float* gates, const float* w_hh_fwd, const float* w_hh_rev, int S, int B, float* h_out, float* c_out,
                    const RltXIn& xi, void* stream) {
-    const dim3 grid(rlt_cdiv(B, 32), 2), block(256);
+    const bool single = w6_single(B);
+    const dim3 grid(rlt_cdiv(B, single ? 16 : 32), 2), block(256);
     hipStream_t st = rlt_stream(stream);
-    if (xi.x) {
-        const int rc = rlt_allow_lds(bilstm6w_fwd_kernel<true>, W6_LDS);
+    auto go = [&](auto kern) {
+        const int rc = rlt_allow_lds(kern, W6_LDS);
         if (rc) return rc;
-        hipLaunchKernelGGL(bilstm6w_fwd_kernel<true>, grid, block, W6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
-    } else {
-        const int rc = rlt_allow_lds(bilstm6w_fwd_kernel<false>, W6_LDS);
-        if (rc) return rc;
-        hipLaunchKernelGGL(bilstm6w_fwd_kernel<false>, grid, block, W6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
-    }
-    return 0;
+        hipLaunchKernelGGL(kern, grid, block, W6_LDS, st, gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi);
+        return 0;
+    };
+    if (xi.x) return single ? go(bilstm6w_fwd_kernel<true, true>) : go(bilstm6w_fwd_kernel<true, false>);
+    return single ? go(bilstm6w_fwd_kernel<false, true>) : go(bilstm6w_fwd_kernel<false, false>);
 }
 
 int rlt_lstm6w_bwd(float* gates, const float* c, const float* w_hh_fwd, const float* w_hh_rev, const float* d_hout, int S, int B,
                    void* stream) {
-    const int rc = rlt_allow_lds(bilstm6w_bwd_kernel, WB_LDS);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bilstm6w_bwd_kernel, dim3(rlt_cdiv(B, 32), 2), dim3(256), WB_LDS, rlt_stream(stream), gates, c, w_hh_fwd,
-                       w_hh_rev, d_hout, S, B);
-    return 0;
+    const bool single = w6_single(B);
+    auto go = [&](auto kern) {
+        const int rc = rlt_allow_lds(kern, WB_LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(rlt_cdiv(B, single ? 16 : 32), 2), dim3(256), WB_LDS, rlt_stream(stream), gates, c, w_hh_fwd, w_hh_rev,
+                           d_hout, S, B);
+        return 0;
+    };
+    return single ? go(bilstm6w_bwd_kernel<true>) : go(bilstm6w_bwd_kernel<false>);
 }

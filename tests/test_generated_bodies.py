@@ -134,12 +134,12 @@ def test_lstm6w_loops_have_no_compiler_register_traffic(tmp_path):
                    capture_output=True)
     text = asm.read_text()
     kernels = re.findall(r"^(_ZN12_GLOBAL__N_119bilstm6w_\w+):(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 3
+    assert len(kernels) == 6                  # forward: {pre-activations | fused input projection} x {two halves | one half}; backward x 2
     for name, body in kernels:
         assert "scratch_" not in body, name                       # nothing spills anywhere in the kernel
         blocks = re.split(r"^\.LBB\w+:", body, flags=re.M)
         ticks = [b for b in blocks if b.count("v_mfma") >= 192]                 # every block that holds tick bodies
-        loops = [b for b in ticks if b.count("v_mfma_f32_16x16x32_bf16") in (384, 400) and "s_cbranch" in b]      # the steady-state tick pair
+        loops = [b for b in ticks if b.count("v_mfma_f32_16x16x32_bf16") in (192, 200, 384, 400) and "s_cbranch_scc" in b and "Loop Header" in b]   # the steady state
         assert loops, name
         for b in ticks:
             assert "v_accvgpr" not in b and "flat_" not in b, name

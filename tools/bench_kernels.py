@@ -174,6 +174,9 @@ def lstm_w():
         ms = timeit(lambda: call("rlt_bilstm_rec_fwd", ptr(gates), ptr(w[0]), ptr(w[1]), S, B, ptr(h), ptr(c), N.PRECISION_DEFAULT, stream()), reps=3)
         print(f"bilstm_fwd   B{B} S{S}: {ms:8.3f} ms  {ms / S * 1e3:6.2f} us / step", flush=True)
         lstm_x(B, S)
+        dh = torch.randn(T, 256, device=dev)
+        ms = timeit(lambda: call("rlt_bilstm_rec_bwd", ptr(gates), ptr(c), ptr(w[0]), ptr(w[1]), ptr(dh), S, B, N.PRECISION_DEFAULT, stream()), reps=3)
+        print(f"bilstm_bwd   B{B} S{S}: {ms:8.3f} ms  {ms / S * 1e3:6.2f} us / step", flush=True)
 
 
 def lstm_small():
