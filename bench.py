@@ -224,6 +224,52 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode        # rank 0 writes the JSON line to the inherited stdout
 
 
+def small_batch_block(dev, S):
+    """The reference's own batch sizes (hyper_parameter_*.conf: batch_size = 63 / 64; robust04 has 194 training lists): full training
+    steps of AttnCut at 63 lists and Choopy at 32, default precision mode, median of 30 HIP-event-timed steps after 5 warm-ups.  There the
+    step is the serial BiLSTM recurrences (1,200 time steps) and launch-bound encoder work, not a roofline - reported, not the headline."""
+    import models as hip_models
+    from utils import losses as hip_losses
+    from utils.metrics import Metric
+    from rlt_hip.parallel import FlatModel, FusedAdam
+    out = {}
+    for name, Bs in (("attncut", 63), ("choopy", 32)):
+        torch.manual_seed(4321)
+        if name == "attncut":
+            model, crit, n_feat = hip_models.AttnCut(input_size=3, dropout=0.0).to(dev), hip_losses.DivLoss(metric="f1", div_type="js", augmented=True), 3
+        else:
+            model, crit, n_feat = hip_models.Choopy(seq_len=S, dropout=0.0).to(dev), hip_losses.ChoopyLoss(metric="f1"), 1
+        flat = FlatModel(model)
+        opt = FusedAdam(flat, lr=3e-5, weight_decay=0.0014756345581373493)
+        x, y = synth_batch(Bs, S, n_feat, 777, dev)
+
+        def step():
+            model.train()
+            opt.zero_grad()
+            loss, _k, _f1, _dcg = Metric.step(crit, model(x), y)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for a, b in evs:
+            a.record()
+            loss = step()
+            b.record()
+        torch.cuda.synchronize()
+        per = sorted(a.elapsed_time(b) for a, b in evs)
+        med = 0.5 * (per[14] + per[15])
+        if not math.isfinite(float(loss.detach())):
+            raise SystemExit(f"bench.py: non-finite loss in the small-batch {name} steps")
+        out[f"{name}_b{Bs}"] = {"batch": Bs, "seq_len": S, "median_ms_per_step": round(med, 3), "min_ms": round(per[0], 3),
+                               "lists_per_s": round(Bs / med * 1e3, 1), "steps": 30}
+    out["note"] = ("the reference's configured batch sizes: full train steps incl. Adam and cut metrics, default precision mode, HIP events "
+                   "per step; latency-bound (serial recurrences), not a roofline figure")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,8 +528,8 @@ def main():
                      "against the 157.3 TFLOP/s f32 MFMA peak",
              "bf16x3": "the library's opt-in split-bf16 product mode: inside the 1e-4 parity bound of BASELINE.json (GPU suite green in "
                        "this mode), but its products carry 16 operand bits where the reference's fp32 carries 24 - never the headline",
-             "bf16x6": "the library's default: GEMM family (csrc/gemm.hip gemm6*_kernel), list attention (csrc/attention6.hip) and BiLSTM "
-                       "recurrences (csrc/lstm.hip bilstm6_*) on the exact three-way bf16 split, six MFMA products per fp32 product"}
+             "bf16x6": "the library's default: GEMM family (csrc/gemm.hip gemm6*_kernel), list attention (csrc/attention6.hip, attention6n.hip) "
+                       "and both BiLSTM recurrences (csrc/lstm6w.hip) on the exact three-way bf16 split, six MFMA products per fp32 product"}
     main_res = run_mode(precision, args.steps, args.warmup)
     other_res = [run_mode(m, args.other_steps, 1) for m in others] if args.other_steps > 0 else []
     native.set_precision(precision)
@@ -527,6 +573,8 @@ def main():
                 "roofline": roofline_block(res),
                 "train_state": dict(zip(("loss", "f1", "dcg"), (round(v, 6) for v in res["state"]))),
                 "note": NOTES[m]}
+        if world == 1 and headline and args.dropout == 0 and os.environ.get("RLT_BENCH_SMALL", "1") != "0":
+            out["small_batch"] = small_batch_block(dev, S)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.cpu_sample_batch, args.cpu_loop_batch)
         print(json.dumps(out), flush=True)

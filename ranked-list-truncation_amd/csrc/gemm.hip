@@ -10,6 +10,7 @@
 // prefetch of the next K tile overlaps the MFMAs of the current one.  blockIdx is remapped so that
 // the tiles an XCD runs are contiguous (they share the A panel in that XCD's L2).
 #include "common.h"
+#include "gemm6s.h"
 #include "split6.h"
 #include <stdlib.h>
 #include <string.h>
@@ -2144,6 +2145,16 @@ static int gemm_run(int ta, int tb, int M, int N, int K,
     hipStream_t st = rlt_stream(stream);
     dim3 grid(g.tiles_m * g.tiles_n * (g.slab_xcd ? ns : 1), 1, g.slab_xcd ? 1 : ns);
     int rc = 0;
+    // K = 256 with the long dimension in M (the Linear layers of the encoder, the LSTM input projection): the weights-stationary
+    // streaming kernel (csrc/gemm6s.hip) - no K loop, nothing re-split per tile
+    if (gemm_mode() == 2 && !ta && ns == 1 && !relu_mask && !colsum_a && drop_p == 0.f && !(flags & RLT_GEMM_ACCUMULATE) &&
+        (!bits_in || (!bias && !bias2 && !(flags & RLT_GEMM_RELU)))) {
+        const Gemm6sArgs s6{A, B, C, bias, bias2, M, N, K, lda, ldb, ldc, bits_out, bits_in, mask_scale};
+        if (rlt_gemm6s_ok(s6)) {
+            rc = rlt_gemm6s_launch(s6, tb != 0, (flags & RLT_GEMM_RELU) != 0, stream);
+            return rc ? rc : RLT_LAUNCH_RESULT();
+        }
+    }
     static const bool x6_small_only = getenv("RLT_GEMM6_SMALL") != nullptr;      // A/B switch: 256 x 128 tiles everywhere
     static const bool x6_no_c = [] { const char* e = getenv("RLT_GEMM6C"); return e && atoi(e) == 0; }();   // A/B switch: RLT_GEMM6C=0 -> gemm6b
     if (gemm_mode() == 2 && gemm6_ok(g) && g.N % BN2 == 0 && !x6_small_only && !x6_no_c && g.kchunk / BK3 >= 2 &&

@@ -18,7 +18,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # kernel); with the VGPR form the accumulators the vector ALU touches stay where it can reach them
 # lstm6w.hip, no SLP packing: the split residuals of values that sit in different registers would be packed by first MOVING them into pairs
 FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"], "attention6n.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
-              "lstm6w.hip": ["-fno-slp-vectorize"]}
+              "lstm6w.hip": ["-fno-slp-vectorize"], "gemm6s.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

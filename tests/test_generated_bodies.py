@@ -21,12 +21,13 @@ CASES = [
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
     (["tools/gen_lstm6w_body.py", "bwd"], "lstm6w_bwd_body.inc"),
+    (["tools/gen_gemm6s_body.py"], "gemm6s_body.inc"),
 ]
 
 
 @pytest.mark.parametrize("cmd,inc", CASES, ids=[c[1] for c in CASES])
 def test_generated_body_is_current(cmd, inc):
-    env = {k: v for k, v in os.environ.items() if k != "GEN_OMIT"}
+    env = {k: v for k, v in os.environ.items() if k not in ("GEN_OMIT", "GEN_BUDGET")}
     out = subprocess.run([sys.executable] + cmd, cwd=REPO, env=env, check=True, capture_output=True, text=True).stdout
     with open(os.path.join(CSRC, inc)) as f:
         assert f.read() == out, f"{inc} is not the output of {' '.join(cmd)}"
@@ -145,3 +146,37 @@ def test_lstm6w_loops_have_no_compiler_register_traffic(tmp_path):
             assert "v_accvgpr" not in b and "flat_" not in b, name
         for loop in loops:
             assert "vmcnt(0)" not in loop, name
+
+
+def test_gemm6s_body_and_loop(tmp_path):
+    """The weights-stationary K = 256 product: 384 MFMAs per block - every (half, k-step, product, column block) once, smallest product first
+    per accumulator and k-step - each staging / store call once; and the block loop of every instantiation is ONE basic block without
+    compiler register traffic, FLAT accesses, waterfall loops around buffer instructions or vmcnt(0)."""
+    import re
+    import shutil
+    from collections import Counter
+    text = open(os.path.join(CSRC, "gemm6s_body.inc")).read()
+    mf = re.findall(r"\bMG\((\d), (\d), (\d), (\d), (\d)\)", text)
+    assert len(mf) == 384 and len(set(m[:4] for m in mf)) == 384
+    assert sorted((m[0], m[3]) for m in mf if m[4] == "1") == sorted((str(h), str(c)) for h in range(2) for c in range(4))
+    seq = {}
+    for h, ks, p, cb, _f in mf:
+        seq.setdefault((h, ks, cb), []).append(int(p))
+    assert all(v == [0, 1, 2, 3, 4, 5] for v in seq.values())
+    calls = Counter(re.findall(r"\b([A-Z][A-Z]\([^)]*\))", text))
+    assert set(calls.values()) == {1} and sum(1 for c in calls if c.startswith("EP(")) == 8 and sum(1 for c in calls if c.startswith("SX(")) == 28
+    from rlt_hip import build as B
+    if shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "g6s.s"
+    subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["gemm6s.hip"] + ["-S", "--cuda-device-only", os.path.join(CSRC, "gemm6s.hip"), "-o", str(asm)],
+                   check=True, capture_output=True)
+    kernels = re.findall(r"^(_ZN12_GLOBAL__N_113gemm6s_kernel\w+):(.*?)s_endpgm", asm.read_text(), flags=re.S | re.M)
+    assert len(kernels) == 8
+    for name, body in kernels:
+        assert "scratch_" not in body, name
+        blocks = re.split(r"^\.LBB\w+:", body, flags=re.M)
+        loops = [b for b in blocks if b.count("v_mfma_f32_16x16x32_bf16") == 768]
+        assert len(loops) == 1, name                                # two blocks per iteration, one basic block
+        loop = loops[0]
+        assert "v_accvgpr" not in loop and "flat_" not in loop and "vmcnt(0)" not in loop and "s_cbranch_execnz" not in loop, name
