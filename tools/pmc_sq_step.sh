@@ -1,5 +1,6 @@
 # SQ counters of every kernel of the AttnCut training step (one PMC pass, kernel trace only): clock, matrix-pipe occupancy and the
 # wavefront-cycle split (parked at s_waitcnt / barrier, issue-stalled, issuing) per kernel -> gpurun_out/TAG_pmc_sq.txt
+export RLT_BENCH_SMALL=0
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

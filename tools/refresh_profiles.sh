@@ -10,6 +10,7 @@ O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err
 tail -c 600 $O/${TAG}_bench_n1.json; echo
+export RLT_BENCH_SMALL=0      # (the profiled runs: the headline step only, not the small-batch block of the bench line)
 for MODE in fp32 bf16x3 bf16x6; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_attncut_$MODE -o p -- python3 $R/bench.py --precision $MODE --steps 6 --warmup 2 --no-cpu-baseline --other-steps 0 > $O/${TAG}_prof_attncut_$MODE.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch_$MODE -o p -- python3 $R/bench.py --precision $MODE --steps 2 --warmup 1 --no-cpu-baseline --other-steps 0 > $O/${TAG}_pmc_fetch_$MODE.log 2>&1
