@@ -284,8 +284,15 @@ __global__ __launch_bounds__(256, 1) void bilstm6w_fwd_kernel(float* __restrict_
         };
         if (CH) { RB(0, 0); RB(0, 1); RB(0, 2); }
         GAP_END;
-        if constexpr (XIN) {
+        // two orders of the element-wise work: both unit blocks in lock step (the two-half kernels: the 64-byte halves of a 128-byte
+        // line are loaded / stored back to back - forward layer 1 at 4096 lists 3.65 -> 2.75 ms) or block after block (SINGLE: a step
+        // is latency there, 3.36 against 3.67 us)
+        if constexpr (XIN && SINGLE) {
+#include "lstm6w_fwd_xin_seq_body.inc"
+        } else if constexpr (XIN) {
 #include "lstm6w_fwd_xin_body.inc"
+        } else if constexpr (SINGLE) {
+#include "lstm6w_fwd_seq_body.inc"
         } else {
 #include "lstm6w_fwd_body.inc"
         }

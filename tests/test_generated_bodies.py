@@ -20,6 +20,8 @@ CASES = [
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
+    (["tools/gen_lstm6w_body.py", "fwd_seq"], "lstm6w_fwd_seq_body.inc"),
+    (["tools/gen_lstm6w_body.py", "fwd_xin_seq"], "lstm6w_fwd_xin_seq_body.inc"),
     (["tools/gen_lstm6w_body.py", "bwd"], "lstm6w_bwd_body.inc"),
     (["tools/gen_gemm6s_body.py"], "gemm6s_body.inc"),
 ]
@@ -101,12 +103,13 @@ def test_lstm6w_bodies_cover_every_mfma_once():
     micro-op and each LDS fragment read exactly once."""
     import re
     from collections import Counter
-    for inc, nmf, macro in (("lstm6w_fwd_body.inc", 192, "MF"), ("lstm6w_fwd_xin_body.inc", 192, "MF"), ("lstm6w_bwd_body.inc", 192, "MB")):
+    for inc, nmf, macro in (("lstm6w_fwd_body.inc", 192, "MF"), ("lstm6w_fwd_xin_body.inc", 192, "MF"), ("lstm6w_fwd_seq_body.inc", 192, "MF"),
+                            ("lstm6w_fwd_xin_seq_body.inc", 192, "MF"), ("lstm6w_bwd_body.inc", 192, "MB")):
         text = open(os.path.join(CSRC, inc)).read()
         mf = re.findall(r"\b" + macro + r"\((\d+), (\d+), (\d+), (\d+)\)", text)
         assert len(mf) == nmf and len(set(m[:3] for m in mf)) == nmf
         firsts = [m for m in mf if m[3] == "1"]
-        if inc == "lstm6w_fwd_body.inc":
+        if inc in ("lstm6w_fwd_body.inc", "lstm6w_fwd_seq_body.inc"):
             assert sorted(int(m[0]) for m in firsts) == list(range(8)) and all(m[1] == "0" and m[2] == "0" for m in firsts)
         elif inc == "lstm6w_bwd_body.inc":
             assert sorted(int(m[0]) for m in firsts) == [0, 1] and all(m[1] == "0" and m[2] == "0" for m in firsts)

@@ -3,7 +3,7 @@
 16-list half while the vector ALU works through the element-wise part of the OTHER half, so every MFMA is followed by a fenced
 gap with ~8 cycles of vector / LDS / memory work (what a v_mfma_f32_16x16x32_bf16 hides, profiles/r05_notes.md).
 
-    python tools/gen_lstm6w_body.py fwd|fwd_xin|bwd > ranked-list-truncation_amd/csrc/lstm6w_<kind>_body.inc
+    python tools/gen_lstm6w_body.py fwd|fwd_xin|fwd_seq|fwd_xin_seq|bwd > ranked-list-truncation_amd/csrc/lstm6w_<kind>_body.inc
 
 A body is a flat list of macro calls; the kernel defines them (chain half X, element-wise half Y).  The chain: 4 k-steps
 (forward: of the 128 hidden units; backward: 16 k-steps of the 512 gate rows) x the six plane products, smallest first per
@@ -17,16 +17,72 @@ PROD = [("m", "m"), ("l", "h"), ("h", "l"), ("m", "h"), ("h", "m"), ("h", "h")] 
 
 
 def fwd_elem(xin):
-    """Element-wise micro-ops of one half: (text, cycles)."""
+    """Element-wise micro-ops of one half: (text, cycles).  Both 16-unit blocks of the lane advance in lock step, so that the loads /
+    stores of the two 64-byte halves of a 128-byte line (block 0 | block 1 of a wavefront's 32 units) are issued back to back."""
+    ops = []
+    U = (0, 1)
+    if not xin:
+        for g in range(4):
+            for u in U:
+                ops.append((f"EA({u}, {g})", 8))           # acc += pre-activation
+        for g in range(4):
+            for u in U:
+                ops.append((f"LG({u}, {g})", 4))           # fetch the next step's pre-activations into the freed registers
+    for g in range(4):
+        for u in U:
+            ops.append((f"ES({u}, {g})", 8))               # scale for exp2
+    for g in range(4):
+        for u in U:
+            for r in range(4):
+                ops.append((f"EX({u}, {g}, {r})", 8))
+    for g in range(4):
+        for u in U:
+            ops.append((f"E1({u}, {g})", 8))
+    for g in range(4):
+        for u in U:
+            for r in range(4):
+                ops.append((f"ER({u}, {g}, {r})", 8))
+    for u in U:
+        ops.append((f"EG({u})", 8))                        # tanh of the cell candidate from its sigmoid form
+    for g in range(4):
+        for u in U:
+            ops.append((f"SG({u}, {g})", 4))               # store the activated gates
+    for name, cyc in (("EC1", 8), ("EC2", 8), ("SC", 4), ("ET", 8)):
+        for u in U:
+            ops.append((f"{name}({u})", cyc))
+    for u in U:
+        for r in range(4):
+            ops.append((f"EXC({u}, {r})", 8))
+    for u in U:
+        ops.append((f"E1C({u})", 8))
+    for u in U:
+        for r in range(4):
+            ops.append((f"ERC({u}, {r})", 8))
+    for name, cyc in (("EH1", 8), ("EH2", 8), ("SH", 4)):
+        for u in U:
+            ops.append((f"{name}({u})", cyc))
+    for u in U:
+        for part, cyc in enumerate((8, 16, 16, 8, 16, 16, 8)):
+            ops.append((f"SP({u}, {part})", cyc))          # three-way split of the four new h values, in seven pieces
+        for pl in range(3):
+            ops.append((f"LW({u}, {pl})", 4))
+    if xin:
+        for part in range(4):
+            ops.append((f"XB({part})", 8))                 # the input-projection operand of this half's next chain + the next x fetch
+    return ops
+
+
+def fwd_elem_seq(xin):
+    """... block after block (the single-half kernels: a step is latency there, and the shorter dependence distance of this order wins)."""
     ops = []
     for u in (0, 1):
         if not xin:
             for g in range(4):
-                ops.append((f"EA({u}, {g})", 8))           # acc += pre-activation
+                ops.append((f"EA({u}, {g})", 8))
             for g in range(4):
-                ops.append((f"LG({u}, {g})", 4))           # fetch the next step's pre-activations into the freed registers
+                ops.append((f"LG({u}, {g})", 4))
         for g in range(4):
-            ops.append((f"ES({u}, {g})", 8))               # scale for exp2
+            ops.append((f"ES({u}, {g})", 8))
         for g in range(4):
             for r in range(4):
                 ops.append((f"EX({u}, {g}, {r})", 8))
@@ -35,9 +91,9 @@ def fwd_elem(xin):
         for g in range(4):
             for r in range(4):
                 ops.append((f"ER({u}, {g}, {r})", 8))
-        ops.append((f"EG({u})", 8))                        # tanh of the cell candidate from its sigmoid form
+        ops.append((f"EG({u})", 8))
         for g in range(4):
-            ops.append((f"SG({u}, {g})", 4))               # store the activated gates
+            ops.append((f"SG({u}, {g})", 4))
         ops.append((f"EC1({u})", 8))
         ops.append((f"EC2({u})", 8))
         ops.append((f"SC({u})", 4))
@@ -51,16 +107,16 @@ def fwd_elem(xin):
         ops.append((f"EH2({u})", 8))
         ops.append((f"SH({u})", 4))
         for part, cyc in enumerate((8, 16, 16, 8, 16, 16, 8)):
-            ops.append((f"SP({u}, {part})", cyc))          # three-way split of the four new h values, in seven pieces
+            ops.append((f"SP({u}, {part})", cyc))
         for pl in range(3):
             ops.append((f"LW({u}, {pl})", 4))
     if xin:
         for part in range(4):
-            ops.append((f"XB({part})", 8))                 # the input-projection operand of this half's next chain + the next x fetch
+            ops.append((f"XB({part})", 8))
     return ops
 
 
-def fwd_body(xin):
+def fwd_body(xin, seq=False):
     mf = []
     if xin:
         for rb in range(8):
@@ -83,7 +139,7 @@ def fwd_body(xin):
         if rq == 1 and ks < 3:
             for pl in range(3):
                 fixed.setdefault(base + 12 + pl, []).append(f"RB({ks + 1}, {pl})")
-    ops = fwd_elem(xin)
+    ops = fwd_elem_seq(xin) if seq else fwd_elem(xin)
     out = []
     qi = 0
     for i, m in enumerate(mf):
@@ -106,37 +162,62 @@ def fwd_body(xin):
     return out
 
 
-def bwd_elem():
-    """Element-wise micro-ops of one half of the backward step (csrc/lstm6w.hip names them)."""
+def bwd_elem(paired=True):
+    """Element-wise micro-ops of one half of the backward step (csrc/lstm6w.hip names them).  paired: the dA stores and the gate reloads
+    of the two unit blocks (the 64-byte halves of a 128-byte line) back to back - both blocks' dA first, then the stores, the splits, the
+    reloads; otherwise block after block."""
+    arith = (("B1", 8), ("LDN10", 4), ("B2", 8), ("B3", 16), ("B5", 16), ("B6", 8), ("B7", 16), ("B8", 8), ("ST3", 4),
+             ("B9", 8), ("B10", 16), ("B11", 16), ("ST0", 4), ("B12", 16), ("B13", 8), ("ST2", 4), ("B14", 8), ("B15", 16),
+             ("LDN8", 4), ("B16", 16), ("B17", 8), ("B18", 8), ("ST1", 4))
+
+    def tanh_ops(u):
+        o = [(f"T1({u})", 8)]
+        o += [(f"TX({u}, {r})", 8) for r in range(4)]
+        o.append((f"T3({u})", 8))
+        o += [(f"TR({u}, {r})", 8) for r in range(4)]
+        o.append((f"T5({u})", 16))
+        return o
+
+    def split_ops(u):
+        o = []
+        for ch in (0, 1):
+            o += [(f"SP({u}, {ch}, {part})", cyc) for part, cyc in enumerate((16, 24, 24, 16, 24, 24, 16))]
+            o += [(f"LW({u}, {ch}, {pl})", 4) for pl in range(3)]
+        return o
+
     ops = []
+    if not paired:
+        for u in (0, 1):
+            ops += tanh_ops(u)
+            for name, cyc in arith:
+                if name.startswith("LDN"):
+                    ops.append((f"LDN({int(name[3:]) + u})", cyc))
+                elif name.startswith("ST"):
+                    ops.append((f"ST({u}, {name[2:]})", cyc))
+                else:
+                    ops.append((f"{name}({u})", cyc))
+            ops += split_ops(u)
+            ops += [(f"LDN({4 * u + g})", 4) for g in range(4)]
+        return ops
     for u in (0, 1):
-        ops.append((f"T1({u})", 8))
-        for r in range(4):
-            ops.append((f"TX({u}, {r})", 8))
-        ops.append((f"T3({u})", 8))
-        for r in range(4):
-            ops.append((f"TR({u}, {r})", 8))
-        ops.append((f"T5({u})", 16))
-        for name, cyc in (("B1", 8), ("LDN10", 4), ("B2", 8), ("B3", 16), ("B5", 16), ("B6", 8), ("B7", 16), ("B8", 8), ("ST3", 4),
-                          ("B9", 8), ("B10", 16), ("B11", 16), ("ST0", 4), ("B12", 16), ("B13", 8), ("ST2", 4), ("B14", 8), ("B15", 16),
-                          ("LDN8", 4), ("B16", 16), ("B17", 8), ("B18", 8), ("ST1", 4)):
+        ops += tanh_ops(u)
+        for name, cyc in arith:
             if name.startswith("LDN"):
                 ops.append((f"LDN({int(name[3:]) + u})", cyc))
-            elif name.startswith("ST"):
-                ops.append((f"ST({u}, {name[2:]})", cyc))
-            else:
+            elif not name.startswith("ST"):
                 ops.append((f"{name}({u})", cyc))
-        for ch in (0, 1):
-            for part, cyc in enumerate((16, 24, 24, 16, 24, 24, 16)):
-                ops.append((f"SP({u}, {ch}, {part})", cyc))
-            for pl in range(3):
-                ops.append((f"LW({u}, {ch}, {pl})", 4))
-        for g in range(4):
+    for g in (3, 0, 2, 1):
+        for u in (0, 1):
+            ops.append((f"ST({u}, {g})", 4))
+    for u in (0, 1):
+        ops += split_ops(u)
+    for g in range(4):
+        for u in (0, 1):
             ops.append((f"LDN({4 * u + g})", 4))
     return ops
 
 
-def bwd_body():
+def bwd_body(paired=True):
     mf = []
     for ks in range(16):
         for p in range(6):
@@ -151,7 +232,7 @@ def bwd_body():
         if 7 <= ks < 15:                                   # the l fragments of k-steps 8-15 come from LDS, one k-step ahead
             for ub in range(2):
                 fixed.setdefault(base + 9 + ub, []).append(f"RL({ub}, {ks + 1})")
-    ops = bwd_elem()
+    ops = bwd_elem(paired)
     return fill(mf, fixed, ops)
 
 
@@ -177,12 +258,12 @@ def fill(mf, fixed, ops):
 
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-    if kind in ("fwd", "fwd_xin"):
-        lines = fwd_body(kind == "fwd_xin")
-    elif kind == "bwd":
-        lines = bwd_body()
+    if kind in ("fwd", "fwd_xin", "fwd_seq", "fwd_xin_seq"):
+        lines = fwd_body(kind.startswith("fwd_xin"), kind.endswith("_seq"))
+    elif kind in ("bwd", "bwd_seq"):
+        lines = bwd_body(kind == "bwd")
     else:
-        raise SystemExit("kind: fwd | fwd_xin | bwd")
+        raise SystemExit("kind: fwd | fwd_xin | fwd_seq | fwd_xin_seq | bwd")
     print(f"// generated by tools/gen_lstm6w_body.py {kind} - do not edit")
     print("\n".join(lines))
 

@@ -36,7 +36,11 @@ def main():
     shapes = [("in_proj fwd NT", 0, 1, T, 768, 256), ("out_proj fwd NT", 0, 1, T, 256, 256), ("ffn1 fwd NT", 0, 1, T, 2048, 256),
               ("ffn2 fwd NT", 0, 1, T, 256, 2048), ("ffn1 dX NN", 0, 0, T, 256, 2048), ("ffn2 dX NN", 0, 0, T, 2048, 256),
               ("ffn1 dW TN", 1, 0, 2048, 256, T), ("ffn2 dW TN", 1, 0, 256, 2048, T), ("in_proj dW TN", 1, 0, 768, 256, T),
-              ("lstm dWhh TN", 1, 0, 512, 128, T), ("lstm in NT", 0, 1, T, 1024, 256)]
+              ("lstm dWhh TN", 1, 0, 512, 128, T), ("lstm in NT", 0, 1, T, 1024, 256), ("lstm dX NN", 0, 0, T, 256, 1024),
+              ("in_proj dX NN", 0, 0, T, 256, 768), ("lstm dWih TN", 1, 0, 1024, 256, T)]
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+    if only:
+        shapes = [sh for sh in shapes if any(o in sh[0] for o in only[0].split(","))]
     g = torch.Generator(device=dev).manual_seed(1)
     tot = {m: 0.0 for m in modes}
     for name, ta, tb, M, Nn, K in shapes:
