@@ -22,11 +22,13 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GS_PLANE = 32 * 512;               // one plane of a 32-row block: 32 rows x 256 bf16
-constexpr int GS_BUF = 3 * GS_PLANE;
-constexpr int GS_WL = 4 * 4 * 4 * 64 * 16;       // l plane of the panel, k-steps 4-7: [wavefront][column block][k-step - 4][lane] x 16 B
-constexpr size_t GS_LDS = (size_t)2 * GS_BUF + GS_WL;
-static_assert(GS_LDS == 160 * 1024, "the streaming product fills LDS exactly");
+// KS = K / 32 k-steps: 8 (K = 256: AttnCut's d_model) or 4 (K = 128: Choopy's; the whole l plane of the panel fits the VGPRs, no LDS part)
+template <int KS> constexpr int gs_rowb() { return 64 * KS; }                  // bytes per row of a plane: K bf16
+template <int KS> constexpr int gs_plane() { return 32 * gs_rowb<KS>(); }      // one plane of a 32-row block
+template <int KS> constexpr int gs_buf() { return 3 * gs_plane<KS>(); }
+template <int KS> constexpr int gs_wl() { return KS > 4 ? 4 * 4 * (KS - 4) * 64 * 16 : 0; }      // l plane, k-steps 4..: [wavefront][column block][k-step - 4][lane] x 16 B
+template <int KS> constexpr size_t gs_lds() { return (size_t)2 * gs_buf<KS>() + gs_wl<KS>(); }
+static_assert(gs_lds<8>() == 160 * 1024, "the K = 256 streaming product fills LDS exactly");
 
 __device__ __forceinline__ uint32_t pk2s(float a, float b) {
     typedef __bf16 v2 __attribute__((ext_vector_type(2)));
@@ -56,8 +58,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_s(const void* p, uint32_t
 // TB: B stored [N][K] (y = x W^T, W row-major) or [K][N].  EPI: 0 plain, 1 C = max(C, 0), 2 the same + the 1-bit mask (C > 0) written,
 // 3 C = mask bit ? C * mask_scale : 0.  A mask word holds the 32 rows of a block for one column: a half block writes its 16 bits as a
 // short (ballot over the 16 lanes that hold a column's rows), reads its bit out of the word every lane of the column loads.
-template <bool TB, int EPI>
+template <int KS, bool TB, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
+    constexpr int GS_PLANE = gs_plane<KS>(), GS_BUF = gs_buf<KS>(), ROWB = gs_rowb<KS>(), CPR = 4 * KS, RPP = 256 / CPR, NI = 32 / RPP;
     extern __shared__ __attribute__((aligned(16))) uint8_t sm6s[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
     const int npanel = g.N / 256;
@@ -67,9 +70,10 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
               nstream = __builtin_amdgcn_readfirstlane(gridDim.x / npanel);
     const int nblk = (g.M + 31) / 32;
     uint4* wl_s = reinterpret_cast<uint4*>(sm6s + 2 * GS_BUF);
+    (void)wl_s;
 
     // ---- the stationary panel: column 256 panel + 64 w + 16 cb + n, k = 32 ks + 8 q + j ----
-    bf16x8 wh[4][8], wm[4][8], wlv[4][4];
+    bf16x8 wh[4][KS], wm[4][KS], wlv[4][4];
     f32x4 bv[4];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {             // (second pass: the l fragments kept in VGPRs, when the others are in their AGPRs)
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
             const int col = 256 * panel + 64 * w + 16 * cb + n;
             const float* wp = TB ? g.B + (size_t)col * g.ldb + 8 * q : g.B + (size_t)(8 * q) * g.ldb + col;
 #pragma unroll
-            for (int ks = 0; ks < (pass ? 4 : 8); ++ks) {
+            for (int ks = 0; ks < (pass ? 4 : KS); ++ks) {
                 asm volatile("" : "+v"(wp));          // (opaque: hipcc would form every address up front and spill them)
                 float v[8];
                 if (TB) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
                     wh[cb][ks] = frag8s(h0.x, h0.y, h1.x, h1.y);
                     wm[cb][ks] = frag8s(m0.x, m0.y, m1.x, m1.y);
                     asm volatile("" : "+a"(wh[cb][ks]), "+a"(wm[cb][ks]) : : "memory");
-                    if (ks >= 4) wl_s[((w * 4 + cb) * 4 + (ks - 4)) * 64 + lane] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    if (KS > 4 && ks >= 4) wl_s[((w * 4 + cb) * (KS - 4) + (ks - 4)) * 64 + lane] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 } else {
                     wlv[cb][ks] = frag8s(l0.x, l0.y, l1.x, l1.y);
                     asm volatile("" : "+v"(wlv[cb][ks]) : : "memory");
@@ -112,16 +116,18 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     }
 
     // ---- per-lane addresses ----
-    // staging: thread -> rows (tid >> 5) + 8 i (i = 0..3), 32-byte chunk c = tid & 31 of the row's 256 floats
-    const int sc = tid & 31, sr = tid >> 5;
-    const uint32_t voff_a = (uint32_t)sr * g.lda * 4u + sc * 32u;                       // + 8 i lda 4 (soffset) + 16
-    // LDS writes: row rr, chunk c at rr * 512 + 16 (c ^ (rr & 15)); rr & 15 = sr (i even) or sr + 8 (i odd)
-    const uint32_t wro[2] = {(uint32_t)sr * 512u + 16u * (sc ^ sr), (uint32_t)(sr + 8) * 512u + 16u * (sc ^ (sr + 8))};      // + 8192 (i >> 1)
+    // staging: thread -> rows sr + RPP i (i = 0 .. NI-1), 32-byte chunk sc of the row's K floats
+    const int sc = tid % CPR, sr = tid / CPR;
+    const uint32_t voff_a = (uint32_t)sr * g.lda * 4u + sc * 32u;                       // + RPP i lda 4 (soffset) + 16
+    // LDS writes: row rr = sr + RPP i, chunk c at rr * ROWB + 16 (c ^ (rr & 15))
+    uint32_t wro[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wro[i] = (uint32_t)(sr + RPP * i) * ROWB + 16u * (sc ^ ((sr + RPP * i) & 15));
     // fragment reads of a half: row n, chunk 4 ks + q at (4 ks + q) ^ n = 4 (ks ^ (n >> 2)) + (q ^ (n & 3)): one base per ks & 3
     uint32_t rdo[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rdo[j] = n * 512u + 64u * (j ^ (n >> 2)) + 16u * (q ^ (n & 3));      // + buffer + plane + 8192 half + 256 (ks >> 2)
-    const uint8_t* wlrd = sm6s + 2 * GS_BUF + w * 16384 + lane * 16;                      // + 1024 (4 cb + ks - 4)
+    for (int j = 0; j < 4; ++j) rdo[j] = n * ROWB + 64u * (j ^ (n >> 2)) + 16u * (q ^ (n & 3));      // + buffer + plane + 16 ROWB half + 256 (ks >> 2)
+    const uint8_t* wlrd = sm6s + 2 * GS_BUF + w * (4 * (KS - 4) * 1024) + lane * 16;     // + 1024 ((KS - 4) cb + ks - 4)
     const uint32_t voff_c = (uint32_t)n * g.ldc * 4u + (64u * w + 4u * q) * 4u;            // + 16 half ldc 4 (soffset) + 64 cb
     // mask words of the block: [column] within the panel's 256; written by lanes 0-15 (column 16 cb + lane), the others out of bounds
     const uint32_t voff_bo = lane < 16 ? (64u * w + lane) * 4u : 0x7fff0000u;               // + 64 cb + 2 half
@@ -146,13 +152,15 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     const int nb = __builtin_amdgcn_readfirstlane(stream < nblk ? (nblk - stream + nstream - 1) / nstream : 0);      // blocks of this workgroup
 
     // ---- state ----
-    f32x4 acc[2][4], xs[8];
+    f32x4 acc[2][4], xs[2 * NI];
     u32x4 bw[4];                         // EPI 3: the mask words of the lane's columns, per column block
     bf16x8 bfr[2][3], lfr[4];
     uint4 sph, spm, spl;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) { acc[i >> 2][i & 3] = z4; }
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i) xs[i] = z4;
 #pragma unroll
     for (int i = 0; i < 6; ++i) (&bfr[0][0])[i] = frag8s(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) bw[cb] = u32x4{0u, 0u, 0u, 0u};
     auto load_x = [&](int i4, int part, __amdgpu_buffer_rsrc_t r) __attribute__((always_inline)) {
-        xs[2 * i4 + part] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_a + 16u * part, (uint32_t)(8 * i4) * g.lda * 4u, 0));
+        xs[2 * i4 + part] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_a + 16u * part, (uint32_t)(RPP * i4) * g.lda * 4u, 0));
     };
     auto split_x = [&](int i4, int part) __attribute__((always_inline)) {         // pieces of split4s on xs[2 i4], xs[2 i4 + 1] (residuals in place)
         f32x4 &a = xs[2 * i4], &b = xs[2 * i4 + 1];
@@ -174,15 +182,15 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
         if (part == 6) spl = make_uint4(pk2s(a[0], a[1]), pk2s(a[2], a[3]), pk2s(b[0], b[1]), pk2s(b[2], b[3]));
     };
     auto write_x = [&](int buf, int i4, int pl) __attribute__((always_inline)) {
-        *reinterpret_cast<uint4*>(sm6s + buf * GS_BUF + pl * GS_PLANE + (i4 >> 1) * 8192 + wro[i4 & 1]) = pl == 0 ? sph : pl == 1 ? spm : spl;
+        *reinterpret_cast<uint4*>(sm6s + buf * GS_BUF + pl * GS_PLANE + wro[i4]) = pl == 0 ? sph : pl == 1 ? spm : spl;
     };
     // prologue: block 0 split into buffer 0, block 1 into the staging registers
     {
         const __amdgpu_buffer_rsrc_t r0 = rs_a(0), r1 = rs_a(1);
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) { load_x(i4, 0, r0); load_x(i4, 1, r0); }
+        for (int i4 = 0; i4 < NI; ++i4) { load_x(i4, 0, r0); load_x(i4, 1, r0); }
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
+        for (int i4 = 0; i4 < NI; ++i4) {
 #pragma unroll
             for (int part = 0; part < 7; ++part) split_x(i4, part);
 #pragma unroll
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
             load_x(i4, 1, r1);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(xs[i]));       // consumed: no load is pending when the first block starts (see lstm6w.hip)
+        for (int i = 0; i < 2 * NI; ++i) asm volatile("" : "+v"(xs[i]));       // consumed: no load is pending when the first block starts (see lstm6w.hip)
     }
     __syncthreads();
 
@@ -204,12 +212,12 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
         const __amdgpu_buffer_rsrc_t rb0 = EPI >= 2 ? rs_bits(i) : rc0, rb1 = EPI == 2 ? rs_bits(i - 1) : rc1;
         (void)rb0; (void)rb1;
         auto RB = [&](int half, int ks, int pl) __attribute__((always_inline)) {
-            bfr[(8 * half + ks) & 1][pl] = *reinterpret_cast<const bf16x8*>(sm6s + X * GS_BUF + pl * GS_PLANE + half * 8192 + 256 * (ks >> 2) + rdo[ks & 3]);
+            bfr[(KS * half + ks) & 1][pl] = *reinterpret_cast<const bf16x8*>(sm6s + X * GS_BUF + pl * GS_PLANE + half * 16 * ROWB + 256 * (ks >> 2) + rdo[ks & 3]);
         };
-        auto RL = [&](int ks, int cb) __attribute__((always_inline)) { lfr[cb] = *reinterpret_cast<const bf16x8*>(wlrd + 1024 * (4 * cb + ks - 4)); };
+        auto RL = [&](int ks, int cb) __attribute__((always_inline)) { lfr[cb] = *reinterpret_cast<const bf16x8*>(wlrd + 1024 * ((KS - 4) * cb + ks - 4)); };
         auto MG = [&](int half, int ks, int p, int cb, int first) __attribute__((always_inline)) {
             const int bp = p == 2 ? 2 : (p == 0 || p == 4) ? 1 : 0;                  // streamed plane: m, h, l, h, m, h
-            const bf16x8 xv = bfr[(8 * half + ks) & 1][bp];
+            const bf16x8 xv = bfr[(KS * half + ks) & 1][bp];
             f32x4& d = acc[half][cb];
             if (p == 1) {                                                            // weight plane l: registers (k-steps 0-3) or the LDS fragment
                 const bf16x8 lv = ks < 4 ? wlv[cb][ks < 4 ? ks : 0] : lfr[cb];
@@ -248,7 +256,11 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
         auto WX = [&](int i4, int pl) __attribute__((always_inline)) { write_x(Y, i4, pl); };
         RB(0, 0, 0); RB(0, 0, 1); RB(0, 0, 2);
         GAP_END;
+        if constexpr (KS == 8) {
 #include "gemm6s_body.inc"
+        } else {
+#include "gemm6s_k128_body.inc"
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     const std::integral_constant<int, 0> H0;
@@ -258,9 +270,10 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     for (int i = 0; i < nb + 1; i += 2) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-            asm volatile("" : "+a"(wh[cb][0]), "+a"(wh[cb][1]), "+a"(wh[cb][2]), "+a"(wh[cb][3]), "+a"(wh[cb][4]), "+a"(wh[cb][5]), "+a"(wh[cb][6]),
-                         "+a"(wh[cb][7]), "+a"(wm[cb][0]), "+a"(wm[cb][1]), "+a"(wm[cb][2]), "+a"(wm[cb][3]), "+a"(wm[cb][4]), "+a"(wm[cb][5]),
-                         "+a"(wm[cb][6]), "+a"(wm[cb][7]));
+#pragma unroll
+            for (int k4 = 0; k4 < KS; k4 += 4)
+                asm volatile("" : "+a"(wh[cb][k4]), "+a"(wh[cb][k4 + 1]), "+a"(wh[cb][k4 + 2]), "+a"(wh[cb][k4 + 3]), "+a"(wm[cb][k4]), "+a"(wm[cb][k4 + 1]),
+                             "+a"(wm[cb][k4 + 2]), "+a"(wm[cb][k4 + 3]));
         tick(H0, i);
         tick(H1, i + 1);
     }
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
 
 bool rlt_gemm6s_ok(const Gemm6sArgs& g) {
     static const bool on = [] { const char* e = getenv("RLT_GEMM6S"); return !e || atoi(e) != 0; }();      // RLT_GEMM6S=0: the tiled kernels (A/B runs)
-    return on && g.K == 256 && g.N % 256 == 0 && g.N <= 256 * 256 && g.M >= 32 * 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.ldc % 4 == 0 &&
+    return on && (g.K == 256 || g.K == 128) && g.N % 256 == 0 && g.N <= 256 * 256 && g.M >= 32 * 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.ldc % 4 == 0 &&
            rlt_aligned16(g.A) && rlt_aligned16(g.B) && rlt_aligned16(g.C) && (!g.bias || rlt_aligned16(g.bias)) &&
            (!g.bias2 || rlt_aligned16(g.bias2)) && (size_t)g.lda * 4 * 32 < (1u << 31) && (size_t)g.ldc * 4 * 32 < (1u << 31) &&
            !(g.bits_out && g.bits_in) && (!g.bits_out || rlt_aligned16(g.bits_out)) && (!g.bits_in || rlt_aligned16(g.bits_in));
@@ -283,14 +296,17 @@ int rlt_gemm6s_launch(const Gemm6sArgs& g, bool tb, bool relu, void* stream) {
     int nstream = 256 / npanel;                      // one workgroup per CU: the panels x as many row streams as fill the chip
     if (nstream < 1) nstream = 1;
     if (nstream > nblk) nstream = nblk;
+    const size_t lds = g.K == 256 ? gs_lds<8>() : gs_lds<4>();
     auto go = [&](auto kern) {
-        const int rc = rlt_allow_lds(kern, GS_LDS);
+        const int rc = rlt_allow_lds(kern, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(npanel * nstream), dim3(256), GS_LDS, rlt_stream(stream), g);
+        hipLaunchKernelGGL(kern, dim3(npanel * nstream), dim3(256), lds, rlt_stream(stream), g);
         return 0;
     };
     if (g.bits_out && !relu) return -1;
     const int epi = g.bits_in ? 3 : g.bits_out ? 2 : relu ? 1 : 0;
-    if (tb) return epi == 3 ? go(gemm6s_kernel<true, 3>) : epi == 2 ? go(gemm6s_kernel<true, 2>) : epi == 1 ? go(gemm6s_kernel<true, 1>) : go(gemm6s_kernel<true, 0>);
-    return epi == 3 ? go(gemm6s_kernel<false, 3>) : epi == 2 ? go(gemm6s_kernel<false, 2>) : epi == 1 ? go(gemm6s_kernel<false, 1>) : go(gemm6s_kernel<false, 0>);
+#define GS_GO(KS_) (tb ? (epi == 3 ? go(gemm6s_kernel<KS_, true, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, true, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, true, 1>) : go(gemm6s_kernel<KS_, true, 0>)) \
+                       : (epi == 3 ? go(gemm6s_kernel<KS_, false, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, false, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, false, 1>) : go(gemm6s_kernel<KS_, false, 0>)))
+    return g.K == 256 ? GS_GO(8) : GS_GO(4);
+#undef GS_GO
 }

@@ -97,18 +97,17 @@ def gemm():
         report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
     # K = 256 with >= 8192 rows: the weights-stationary streaming kernel of the bf16x6 mode (csrc/gemm6s.hip) - ragged last block, rows
     # behind the end untouched, one / three / four panels, both layouts of the weight, two biases, strided A and C
-    for (M, Nn) in [(8209, 256), (8192 + 31, 768), (12000, 1024)]:
-        K = 256
+    for (M, Nn, K) in [(8209, 256, 256), (8192 + 31, 768, 256), (12000, 1024, 256), (8192 + 7, 512, 128), (20000, 2048, 128)]:
         A, W, W2, b1, b2 = torch.randn(M, K + 4), torch.randn(Nn, K) / 16, torch.randn(K, Nn) / 16, torch.randn(Nn), torch.randn(Nn)
         for tb, Bm in ((1, W), (0, W2)):
             C = torch.full((M + 3, Nn + 4), 7.0, device=dev)
             ops.gemm(0, tb, M, Nn, K, A.to(dev), K + 4, Bm.to(dev), Bm.shape[1], C, Nn + 4, bias=b1.to(dev), bias2=b2.to(dev))
             ref = A[:, :K].double() @ (Bm.t() if tb else Bm).double() + b1.double() + b2.double()
-            report(f"gemm K=256 stream tb={tb} {M}x{Nn}", rel(C[:M, :Nn], ref), mfma_tol(2e-6 * 16 + 1e-6))
-            report(f"gemm K=256 stream tb={tb} {M}x{Nn}: rows / columns outside C untouched",
+            report(f"gemm K={K} stream tb={tb} {M}x{Nn}", rel(C[:M, :Nn], ref), mfma_tol(2e-6 * 16 + 1e-6))
+            report(f"gemm K={K} stream tb={tb} {M}x{Nn}: rows / columns outside C untouched",
                    float((C[M:] != 7.0).sum() + (C[:, Nn:] != 7.0).sum()), 0)
     # 1-bit ReLU mask pair (rlt_gemm_bits): interior and edge tiles; the last two shapes take the streaming kernel in bf16x6 mode
-    for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256), (512, 512, 128), (8192 + 45, 512, 256), (16384, 256, 256)]:
+    for (M, Nn, K) in [(256, 128, 64), (300, 96, 40), (1000, 2048, 256), (512, 512, 128), (8192 + 45, 512, 256), (16384, 256, 256), (8192 + 45, 512, 128)]:
         A, W, bias = torch.randn(M, K), torch.randn(Nn, K), torch.randn(Nn)
         H = torch.empty(M, Nn, device=dev)
         bits = ops.alloc_relu_bits(M, Nn, dev)
@@ -133,7 +132,7 @@ def gemm():
                       drop_p=pd, seed=sd)
         # (K = 256 with >= 8192 rows: in bf16x6 mode the dropout-free product ran on the streaming kernel, this one on the tiled kernel:
         #  two roundings of the same sum)
-        report(f"gemm_bits relu+dropout fwd {M}x{Nn}x{K}", rel(Hd, H.double() * mk.double()), 1e-6 if M < 8192 else 5e-6)
+        report(f"gemm_bits relu+dropout fwd {M}x{Nn}x{K}", rel(Hd, H.double() * mk.double()), 1e-6 if M < 8192 else 5e-6)       # (K = 128 alike)
         unpacked = ops.unpack_relu_bits(bits, M).cpu()
         report(f"gemm_bits relu+dropout bits {M}x{Nn}x{K}", float((unpacked != (Hd.cpu() > 0)).sum()), 0)
         report(f"gemm_bits dropout keep fraction {M}x{Nn}x{K}", abs(float((mk > 0).float().mean()) - (1 - pd)), 8e-3)
