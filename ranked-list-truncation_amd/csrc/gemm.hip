@@ -1984,10 +1984,14 @@ int gemm_mode() {
 
 int choose_split(int M, int N, int K) {
     const long long tiles = (long long)rlt_cdiv(M, BM) * rlt_cdiv(N, BN);
-    if (tiles >= 256 || K < 4096) return 1;
+    // (K from 1024: the reference's own batch sizes - 32 / 63 lists x 300 positions = 9,600 / 18,900 rows - leave the K = 2048 products
+    //  of the encoder with 75-150 output tiles: unsplit, a third of the chip ran 2048-long loops, 160-200 us per product at batch 32)
+    static const int kmin = [] { const char* e = getenv("RLT_GEMM_SPLIT_KMIN"); return e ? atoi(e) : 1024; }();
+    if (tiles >= 256 || K < kmin) return 1;
     static const int target = [] { const char* e = getenv("RLT_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 1024; }();
     long long want = target / tiles > 0 ? target / tiles : 1;     // workgroups in flight: a whole number of waves of the grid
-    const long long maxs = K / 512 > 0 ? K / 512 : 1;        // keep >= 512 of K per slice
+    const long long per = K >= 4096 ? 512 : 256;             // keep >= 512 of K per slice (>= 256 below K = 4096)
+    const long long maxs = K / per > 0 ? K / per : 1;
     if (want > maxs) want = maxs;
     if (want > 256) want = 256;
     if (want >= 8) want = want / 8 * 8;       // whole groups of 8 slabs: one slab per XCD and round (decode_block)
