@@ -2124,6 +2124,18 @@ def x6_fallbacks():
     report("x6_fallbacks: checks run in the child (>= 100)", 0.0 if ok >= 100 else 1.0, 0)
     if res.returncode or failed:
         print(res.stdout[-3000:], res.stderr[-2000:])
+    # (3) round 5's A/B switches: the recurrences of round 4 (six-product forward in two phases, f32 MFMA backward: RLT_LSTM6W=0), the
+    # two-half kernels at every batch size (RLT_LSTM6W_SINGLE=0) and the tiled kernels for the K = 256 / 128 products (RLT_GEMM6S=0)
+    for tag, extra, sections, least in (("lstm6w off", {"RLT_LSTM6W": "0"}, ["lstm"], 100), ("lstm6w two halves", {"RLT_LSTM6W_SINGLE": "0"}, ["lstm"], 100),
+                                        ("gemm6s off", {"RLT_GEMM6S": "0"}, ["gemm"], 60)):
+        env2 = dict(os.environ, RLT_PRECISION="bf16x6", **extra)
+        res2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + sections, env=env2, capture_output=True, text=True, timeout=600)
+        tail2 = [l for l in res2.stdout.strip().splitlines() if " ok, " in l and "failed" in l]
+        ok2, failed2 = (int(tail2[-1].split()[0]), int(tail2[-1].split()[2])) if tail2 else (0, 1)
+        report(f"x6_fallbacks ({tag}): child exit status / failed checks", float(abs(res2.returncode) + failed2), 0)
+        report(f"x6_fallbacks ({tag}): checks run in the child (>= {least})", 0.0 if ok2 >= least else 1.0, 0)
+        if res2.returncode or failed2:
+            print(res2.stdout[-3000:], res2.stderr[-2000:])
     g = torch.Generator(device=dev).manual_seed(5)
     S, H, HD = 1, 4, 64
     E = H * HD
