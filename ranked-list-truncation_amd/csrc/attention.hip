@@ -656,11 +656,22 @@ static bool a6n_images(int HD, int B) {
     return on && HD == 16 && B >= 512 && attn6_use(HD, 0.f) && !attn6_img(HD);
 }
 
+// bf16x6 at head dim 16, 512 lists and more in whole 128-row tiles, no dropout: the pipelined forward kernel of attention6n.hip stages
+// pre-split K / V tile images (written by two prepare passes of the call) and leaves a flag word per workgroup for the fix-up
+// launch - both in the forward's `images` buffer (K images | V images | flags).
+// RLT_A6N_F1=0: the two-wavefront kernel (A/B runs)
+static bool a6n_fwd_images(int HD, int B) {
+    static const bool on = [] { const char* e = getenv("RLT_A6N_F1"); return !e || atoi(e) != 0; }();
+    return on && a6n_images(HD, B) && B % 128 == 0;
+}
+static size_t a6n_flags_bytes(int S, int B, int H) { return ((size_t)S * H * rlt_cdiv(B, 256) * sizeof(uint32_t) + 255) / 256 * 256; }
+
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision) {
     RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
+    if (a6n_fwd_images(HD, B)) return rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
     return attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 3) : 0;
 }
 
@@ -681,6 +692,15 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
         return rlt_attn3_run(0, a, HD, images, nullptr, st);
     }
     if (attn6_use(HD, drop_p)) {
+        if (drop_p <= 0.f && a6n_fwd_images(HD, B) && images && rlt_aligned16(images) &&
+            images_bytes >= rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H)) {
+            a.img = images;
+            a.redo = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(images) + rlt_attn6n_fwd_images_bytes(S, B, H));
+            int rc = rlt_attn6n_prepare_at(1, 0, a, st);          // K, V tile images of this call
+            if (!rc) rc = rlt_attn6n_prepare_at(2, 1, a, st);
+            if (rc) return rc;
+            return rlt_attn6n_run(0, a, st);
+        }
         if (attn6_img(HD) && images) {       // the backward kernels will stage from these images: they must all be written
             if (images_bytes < rlt_attn6_images_bytes(S, B, H, HD, 3)) return RLT_E_WORKSPACE;
             if (!rlt_aligned16(images)) return RLT_E_ALIGN;

@@ -241,6 +241,8 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC) void attn6n_fwd_kernel(AttnArgs a
     const int row0 = qt * GROWS + wv * WROWS;
     const bool wave_live = row0 < B;
     const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    // second launch behind the pipelined forward kernel: only the workgroups it flagged (same grid, same block -> rows map)
+    if (a.redo && a.redo[blockIdx.x] == 0u) return;
 
     bf16x8 qmh[NB], qlh[NB];
     uint32_t hq[NB];
@@ -932,6 +934,186 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward: one wavefront per SIMD
+// The same item pipeline as the backward kernels above, for the FORWARD pass: S(s) x6 | R1(s-2) x2 | R2(s-2) x2 | O(s-3) x6 - 16 MFMAs per
+// item of 512 scores - with exp2, the row sums, the plane conversions, the fragment reads and the LDS-DMA staging of the pre-split K / V tile
+// images in the gaps (tools/gen_attn6n_body.py fwd).  A pipeline four items deep cannot move a running maximum, so the reference of a
+// query's weights is FIXED before it starts: the maximum of the scores against the first 32 keys (what the two-wavefront kernel
+// above uses too, until a block's weights leave the comfortable range).  fp32 and the exact split are scale-free, so the result is
+// the same whatever the reference - unless a weight overflows: a workgroup whose normalisers end up non-finite, zero or above 2^100
+// raises its flag in a.redo, and a second launch of the two-wavefront kernel (same grid, same block -> rows map) redoes exactly the
+// flagged workgroups with the moving reference (it returns at once everywhere else).  Needs B % 128 == 0 (the drain tile multiplies
+// its row sums by a zero flag; a partly filled tile would need a mask per key), no dropout.
+__global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_fwd1_kernel(AttnArgs a) {
+    constexpr int NB = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int B = a.B, H = a.H, E = H * 16;
+    const size_t ld = (size_t)3 * E;
+    int pair, rt;
+    map_block(blockIdx.x, a.S * H, rlt_cdiv_dev(B, 256), pair, rt);
+    const int s_ = pair / H, h = pair % H;
+    const float* base = a.qkv + (size_t)s_ * B * ld + h * 16;
+    const int row0 = rt * 256 + wv * 64;
+
+    const int ro = l15 * 16 + 8 * (g & 1);
+    const int offW[3] = {(g < 2 ? 1 : 2) * PLT + ro, (g < 2 ? 0 : 1) * PLT + ro, ro};      // row fragments [m|l], [h|m], [h|h]
+    const int offT = (4 * g + (l15 >> 2)) * 16 + 4 * (l15 & 3);
+    bf16x8 sel[2];
+    {
+        uint32_t s0[2] = {0u, 0u};
+        if ((l15 >> 2) == g) s0[(l15 & 3) >> 1] = (l15 & 1) ? 0xBF800000u : 0x0000BF80u;
+        sel[0] = frag4(s0[0], s0[1], 0u, 0u);
+        sel[1] = frag4(0u, 0u, s0[0], s0[1]);
+    }
+    LaneN c;
+    c.l15 = l15; c.g = g;
+
+    bf16x8 amh[NB], alh[NB];                                      // the lane's queries (scaled), stationary B operands of the score products
+    f32x4 seed_s[NB], acc[NB], acc2[NB];
+    float l_run[NB], m_ref[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int r = row0 + 16 * n + l15, rc = min(r, B - 1);
+        own_frags(base + (size_t)rc * ld, c, a.scale * LOG2E, amh[n], alh[n]);
+        acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        l_run[n] = 0.f;
+    }
+    const int nt = B / KTN1;
+    const int npair = a.S * H;
+    const uint8_t* rec0 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)0 * npair + pair) * (size_t)(nt + 1) * RECB;      // K images (block 0 of the forward's buffer)
+    const uint8_t* rec1 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)1 * npair + pair) * (size_t)(nt + 1) * RECB;      // V images
+    auto dma = [&](int j, int tile, uint16_t* ibuf) __attribute__((always_inline)) {
+        const int piece = wv + 4 * (j % 3);
+        const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + piece * 1024 + lane * 16;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + piece * 1024));
+        RLT_DMA_ASM(dst, rec);
+    };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dma(j, 0, img0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the reference of each query: its largest score against the first 32 keys (log2 domain)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            t = mm(*reinterpret_cast<const bf16x8*>(img0 + offW[0] + kb * 256), amh[n], t);
+            t = mm(*reinterpret_cast<const bf16x8*>(img0 + offW[1] + kb * 256), alh[n], t);
+            t = mm(*reinterpret_cast<const bf16x8*>(img0 + offW[2] + kb * 256), amh[n], t);
+            tmax = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), tmax);
+        }
+        m_ref[n] = col_max4(tmax);
+        seed_s[n] = f32x4{-m_ref[n], -m_ref[n], -m_ref[n], -m_ref[n]};
+    }
+
+    f32x4 sc[4][2];
+    uint32_t pln[1][3][4][4];                                   // [P][h, m, l][ring][dword]
+    bf16x8 fr[2][1][2][3];                                      // K row fragments [buffer = 32-row block & 1][.][16-row block][which]
+    v4s trf[2][2][3][2];                                        // V^T fragments [buffer][matrix (1 used)][plane][half]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sc[i][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3 * 4 * 4; ++i) (&pln[0][0][0][0])[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) (&fr[0][0][0][0])[i] = frag4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) (&trf[0][0][0][0])[i] = v4s{0, 0, 0, 0};
+
+    for (int t = 0; t <= nt; ++t) {                             // nt + 1 bodies: the last one drains the pipeline on the empty tile record
+        const int cur = t & 1;
+        const uint16_t* Ic = img0 + cur * 2 * IMGT;
+        uint16_t* In = img0 + (cur ^ 1) * 2 * IMGT;
+        const int t_next = min(t + 1, nt);
+        const float livef = t < nt ? 1.f : 0.f;                  // the items that START in the drain body carry no keys
+        const float prevf = t > 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) asm volatile("" : "+a"(amh[n]), "+a"(alh[n]), "+a"(acc[n]), "+a"(acc2[n]));
+        asm volatile("" : "+a"(sel[0]), "+a"(sel[1]));
+#define GAP_END __builtin_amdgcn_sched_barrier(0)
+        auto mma_aa = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(av), "a"(bv));
+        };
+        auto mma_aa_c = [&](f32x4& d, bf16x8 av, bf16x8 bv, const f32x4& cv) __attribute__((always_inline)) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(av), "a"(bv), "v"(cv));
+        };
+        auto mma_av = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(av), "v"(bv));
+        };
+        auto mma_out = [&](f32x4& d, bf16x8 av, bf16x8 bv) __attribute__((always_inline)) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(av), "v"(bv));
+        };
+        auto m_s = [&](int it, int n, int k, int fb) __attribute__((always_inline)) {
+            const int kb = k / 3, j = k % 3;
+            if (j == 0) mma_aa_c(sc[it][kb], fr[fb][0][kb][0], amh[n], seed_s[n]);
+            else mma_aa(sc[it][kb], fr[fb][0][kb][j], j == 1 ? alh[n] : amh[n]);
+        };
+        auto plane = [&](int which, int lvl, int it) __attribute__((always_inline)) {
+            return frag4(pln[0][lvl][it][0], pln[0][lvl][it][1], pln[0][lvl][it][2], pln[0][lvl][it][3]);
+        };
+        auto m_r = [&](int it, int which, int level, int kb) __attribute__((always_inline)) {
+            mma_av(sc[it][kb], sel[kb], plane(0, level - 1, it));
+        };
+        auto m_o = [&](int it, int n, int which, int k, int fb) __attribute__((always_inline)) {
+            const int ap = k == 0 || k == 3 ? 1 : k == 1 ? 2 : 0, bp = k == 0 || k == 4 ? 1 : k == 2 ? 2 : 0;
+            typedef short v8s __attribute__((ext_vector_type(8)));
+            const v4s x = trf[fb][1][ap][0], y = trf[fb][1][ap][1];
+            const v8s av = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+            mma_out(k < 5 ? acc2[n] : acc[n], __builtin_bit_cast(bf16x8, av), plane(0, bp, it));
+        };
+        auto e_exp = [&](int it, int kb, int r) __attribute__((always_inline)) { sc[it][kb][r] = rlt_exp2(sc[it][kb][r]); };
+        // (chunks of the previous tile's last items: in the first body there is no previous tile - the ring holds zeros - and the weight must be 0, not exp2(0))
+        auto e_exp_p = [&](int it, int kb, int r) __attribute__((always_inline)) { sc[it][kb][r] = rlt_exp2(sc[it][kb][r]) * prevf; };
+        auto e_sum = [&](int it, int n, int kb, int r) __attribute__((always_inline)) { l_run[n] = __builtin_fmaf(sc[it][kb][r], livef, l_run[n]); };
+        auto e_sum_p = [&](int it, int n, int kb, int r) __attribute__((always_inline)) { l_run[n] += sc[it][kb][r]; };
+        auto c_pk = [&](int it, int which, int lvl, int j) __attribute__((always_inline)) {
+            const f32x4& tile = sc[it][j >> 1];
+            pln[0][lvl][it][j] = pk2n(tile[2 * (j & 1)], tile[2 * (j & 1) + 1]);
+        };
+        auto rd_row = [&](int fb, int mat, int kb, int w, int b32) __attribute__((always_inline)) {
+            fr[fb][0][kb][w] = *reinterpret_cast<const bf16x8*>(Ic + offW[w] + (2 * b32 + kb) * 256);
+        };
+        auto rd_tr = [&](int fb, int mat, int pl, int half, int b32) __attribute__((always_inline)) {
+            trf[fb][1][pl][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (v4s __attribute__((address_space(3)))*)(Ic + IMGT + pl * PLT + offT + b32 * 512 + half * 256));
+        };
+        auto st_dma = [&](int j) __attribute__((always_inline)) { dma(j, t_next, In); };
+#include "attention6n_fwd1_body.inc"
+#undef GAP_END
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's LDS-DMA pieces of the next tile have landed
+        __syncthreads();
+    }
+    bool bad = false;
+    float inv[NB], lse[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const float l_tot = col_sum4(l_run[n]);
+        bad |= !(l_tot > 0.f && l_tot <= 1.2676506e30f);         // 2^100: non-finite, vanished or far out of range -> redo with the moving reference
+        inv[n] = 1.f / l_tot;
+        lse[n] = (m_ref[n] + log2f(l_tot)) * LN2;
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0 && a.redo) a.redo[blockIdx.x] = any_bad ? 1u : 0u;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = row0 + 16 * n + l15;
+        const f32x4 o = acc[n] + acc2[n];
+        if (q < B) {
+            *reinterpret_cast<float4*>(a.o + ((size_t)s_ * B + q) * E + h * 16 + 4 * g) =
+                make_float4(o[0] * inv[n], o[1] * inv[n], o[2] * inv[n], o[3] * inv[n]);
+            if (g == 0) a.lse_o[((size_t)s_ * H + h) * B + q] = lse[n];
+        }
+    }
+}
+
 template <bool DROP>
 int launch6n(int which, const AttnArgs& a, hipStream_t st) {
     constexpr int NB = RLT_A6N_NB, NBK = RLT_A6N_NBK;
@@ -953,6 +1135,17 @@ int launch6n(int which, const AttnArgs& a, hipStream_t st) {
     }
     const bool seed = a.B >= 512;
     const dim3 gq(a.S * a.H * rlt_cdiv(a.B, 64 * NB)), gk(a.S * a.H * rlt_cdiv(a.B, 64 * NBK));
+    // forward without dropout, 512 lists and more in whole 128-row tiles, K / V images prepared (a.img) and a flag word per workgroup
+    // (a.redo): the pipelined kernel, then the two-wavefront kernel for the workgroups it flagged (RLT_A6N_F1=0: the latter alone)
+    static const bool fwd1 = [] { const char* e = getenv("RLT_A6N_F1"); return !e || atoi(e) != 0; }();
+    if (!DROP && one && fwd1 && which == 0 && a.B >= 512 && a.B % KTN1 == 0 && a.img && a.redo && NB == 4) {
+        const size_t shm1 = (size_t)4 * IMGT * sizeof(uint16_t);
+        const int rc = rlt_allow_lds(attn6n_fwd1_kernel, shm1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(attn6n_fwd1_kernel, gq, dim3(256), shm1, st, a);
+        hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP, true>), gq, dim3(256), shm, st, a);
+        return RLT_LAUNCH_RESULT();
+    }
     if (which == 0) {
         if (seed) hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP, true>), gq, dim3(256), shm, st, a);
         else hipLaunchKernelGGL((attn6n_fwd_kernel<NB, DROP, false>), gq, dim3(256), shm, st, a);
@@ -980,12 +1173,16 @@ size_t rlt_attn6n_images_bytes(int S, int B, int H) {
     const int npair = S * H, ntile = rlt_cdiv(B, KTN1);
     return 4 * a6n_img_block(npair, ntile) + (size_t)npair * (ntile + 1) * 1024;
 }
-int rlt_attn6n_prepare(int what, const AttnArgs& a, hipStream_t st) {
+// the forward's buffer: K images | V images (two blocks)
+size_t rlt_attn6n_fwd_images_bytes(int S, int B, int H) { return 2 * a6n_img_block(S * H, rlt_cdiv(B, KTN1)); }
+int rlt_attn6n_prepare(int what, const AttnArgs& a, hipStream_t st) { return rlt_attn6n_prepare_at(what, what, a, st); }
+// ... matrix `what` into image block `slot` of a.img
+int rlt_attn6n_prepare_at(int what, int slot, const AttnArgs& a, hipStream_t st) {
     const int npair = a.S * a.H, ntile = rlt_cdiv(a.B, KTN1), E = a.H * 16;
     uint8_t* img = reinterpret_cast<uint8_t*>(const_cast<void*>(a.img));
     const dim3 grid(npair * (ntile + 1));
     if (what < 3)
-        hipLaunchKernelGGL(attn6n_prepare_kernel, grid, dim3(256), 0, st, a.qkv + what * E, (size_t)3 * E, 0, a.S, a.B, a.H, img + what * a6n_img_block(npair, ntile));
+        hipLaunchKernelGGL(attn6n_prepare_kernel, grid, dim3(256), 0, st, a.qkv + what * E, (size_t)3 * E, 0, a.S, a.B, a.H, img + slot * a6n_img_block(npair, ntile));
     else if (what == 3)
         hipLaunchKernelGGL(attn6n_prepare_kernel, grid, dim3(256), 0, st, a.dout, (size_t)E, 0, a.S, a.B, a.H, img + 3 * a6n_img_block(npair, ntile));
     else

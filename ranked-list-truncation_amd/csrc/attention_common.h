@@ -9,6 +9,7 @@ struct AttnArgs {
     int S, B, H;
     float scale;
     float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
+    uint32_t* redo;                           // head dim 16 pipelined forward: one flag word per workgroup (attention6n.hip), or null
 };
 
 // One LDS-DMA piece as inline assembly: M0 carries the LDS destination.  hipcc treats M0 as a reserved register (a
@@ -77,6 +78,9 @@ size_t rlt_attn6_images_bytes(int S, int B, int H, int HD, int nmat);
 // ... at head dim 16 on the 16x16x32 MFMA (no padded head-dim axis, plane pairs in the d contraction, the split of P / dS on the
 // matrix pipe), defined in attention6n.hip: which = 0 forward, 1 dK/dV, 2 dQ
 int rlt_attn6n_run(int which, const AttnArgs& a, hipStream_t st);
+// ... its pipelined forward kernel: K / V images in a two-block buffer (prepare_at: matrix `what` into block `slot` of a.img)
+size_t rlt_attn6n_fwd_images_bytes(int S, int B, int H);
+int rlt_attn6n_prepare_at(int what, int slot, const AttnArgs& a, hipStream_t st);
 // ... its pipelined backward kernels (512 lists and more, no dropout) stage pre-split tile images + row seeds from a.img:
 // rlt_attn6n_images_bytes bytes, written by rlt_attn6n_prepare (what = 0 Q, 1 K, 2 V, 3 dO, 4 seeds)
 size_t rlt_attn6n_images_bytes(int S, int B, int H);

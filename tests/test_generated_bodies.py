@@ -18,6 +18,7 @@ CASES = [
     (["tools/gen_gemm6e_slot.py"], "gemm6e_slot.inc"),
     (["tools/gen_attn6n_body.py", "dq"], "attention6n_dq1_body.inc"),
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
+    (["tools/gen_attn6n_body.py", "fwd"], "attention6n_fwd1_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_seq"], "lstm6w_fwd_seq_body.inc"),
@@ -90,8 +91,8 @@ def test_attention6n_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
     subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["attention6n.hip"] + ["-S", "--cuda-device-only", src, "-o", str(asm)], check=True,
                    capture_output=True)
     text = asm.read_text()
-    for tag, nmf in (("Lb0", 16 * 22), ("Lb1", 16 * 32)):
-        m = re.search(r"^_ZN12_GLOBAL__N_118attn6n_bwd1_kernelI" + tag + r"EEEv8AttnArgs:(.*?)s_endpgm", text, flags=re.S | re.M)
+    for tag, nmf in (("bwd1_kernelILb0EEEv8AttnArgs", 16 * 22), ("bwd1_kernelILb1EEEv8AttnArgs", 16 * 32), ("fwd1_kernelE8AttnArgs", 16 * 16)):
+        m = re.search(r"^_ZN12_GLOBAL__N_118attn6n_" + tag + r":(.*?)s_endpgm", text, flags=re.S | re.M)
         assert m, tag
         blocks = re.split(r"^\.LBB\w+:", m.group(1), flags=re.M)
         loop = max(blocks, key=lambda b: b.count("v_mfma"))
@@ -187,3 +188,19 @@ def test_gemm6s_body_and_loop(tmp_path):
         assert len(loops) == 1, name                                # two blocks per iteration, one basic block
         loop = loops[0]
         assert "v_accvgpr" not in loop and "flat_" not in loop and "vmcnt(0)" not in loop and "s_cbranch_execnz" not in loop, name
+
+
+def test_attention6n_forward_body_covers_every_mfma_and_chunk_once():
+    """The pipelined head-dim-16 forward body: 16 slots of 16 MFMAs (score products, two residual levels, the output products); 128 exponentials
+    and 128 row-sum updates per body - the chunks of a tile's last items that land in the next body under their own names."""
+    import re
+    from collections import Counter
+    text = open(os.path.join(CSRC, "attention6n_fwd1_body.inc")).read()
+    mf = re.findall(r"^(m_[sro])\(([^)]*)\); GAP_END;", text, flags=re.M)
+    assert len(mf) == 16 * 16
+    assert Counter(nm for nm, _a in mf) == {"m_s": 96, "m_r": 64, "m_o": 96}
+    n = lambda name: len(re.findall(r"\b" + name + r"\(", text))
+    assert n("e_exp") + n("e_exp_p") == 128 and n("e_sum") + n("e_sum_p") == 128 and n("e_exp_p") > 0 and n("e_sum_p") > 0
+    assert n("c_pk") == 16 * 12 and n("rd_row") == 4 * 6 and n("rd_tr") == 4 * 6 and n("st_dma") == 6
+    once = Counter(re.findall(r"\b((?:rd_row|rd_tr|st_dma)\([^)]*\))", text))
+    assert set(once.values()) == {1}

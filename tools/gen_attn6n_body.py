@@ -21,6 +21,12 @@ time.  One line of calls per gap; GAP_END (sched_barrier) keeps hipcc from reord
 
     python tools/gen_attn6n_body.py dq  > ranked-list-truncation_amd/csrc/attention6n_dq1_body.inc
     python tools/gen_attn6n_body.py dkv > ranked-list-truncation_amd/csrc/attention6n_dkv1_body.inc
+    python tools/gen_attn6n_body.py fwd > ranked-list-truncation_amd/csrc/attention6n_fwd1_body.inc
+
+fwd (16 MFMAs per slot):  R1(s-2) x2 | O(s-3) x6 | R2(s-2) x2 | S(s) x6 - the forward pass with a FIXED reference per query (seeded
+scores): exp2 of the scores, their sum into the row's normaliser (e_sum; items of the drain tile multiply by a zero flag), the split
+of P on the matrix pipe, O^T += V^T P^T.  Chunks of the last items of a tile that land in the next body are emitted as e_exp_p / e_sum_p:
+the previous tile is always a live one - except in the first body, where there is none and e_exp_p must produce a zero weight.
 """
 import os
 import sys
@@ -39,7 +45,10 @@ CAP = 8                      # vector-issue cycles a gap takes before the schedu
 COST = {"exp": 8, "mul": 4, "sub": 4, "cvt": 5, "rd": 2, "ld": 3, "sp": 16, "st": 8, "tb": 3}
 
 # ---- slot layout: list of (stage, index within stage); stage -> item offset
-if MODE == "dq":
+if MODE == "fwd":
+    LAYOUT = [("R1", k) for k in range(2)] + [("O", k) for k in range(6)] + [("R2", k) for k in range(2)] + [("S", k) for k in range(6)]
+    MATS = ("P",)            # fresh operand that is split: P
+elif MODE == "dq":
     LAYOUT = [("R1", k) for k in range(2)] + [("O", k) for k in range(6)] + [("R2", k) for k in range(2)] + \
              [("S", k) for k in range(6)] + [("D", k) for k in range(6)]
     MATS = ("D",)            # fresh operands that are split: dS
@@ -81,18 +90,21 @@ def add(name, chunks, release, deadline, after=()):
 for i in range(NS):
     it, n, b32 = i % RING, i % NB, i // NB
     s_done = [gap_of("S", 2, i), gap_of("S", 5, i)]
-    d_done = [gap_of("D", 2, i), gap_of("D", 5, i)]
+    d_done = [gap_of("D", 2, i), gap_of("D", 5, i)] if MODE != "fwd" else None
     # element-wise: per register (kb, r)
-    ep, ed = {}, {}
+    ep, ed, es = {}, {}, {}
     for kb in range(2):
         for r in range(4):
             ep[kb, r] = add(f"ep{i}.{kb}{r}", [(f"e_exp({it}, {kb}, {r});", "exp")], s_done[kb] + LAG, None)
-            ed[kb, r] = add(f"ed{i}.{kb}{r}", [(f"e_mul({it}, {kb}, {r});", "mul")], d_done[kb] + LAG, None, [(ep[kb, r], 1)])
+            if MODE == "fwd":      # the weight into the normaliser of own block n (any time before the registers turn into residuals)
+                es[kb, r] = add(f"es{i}.{kb}{r}", [(f"e_sum({it}, {n}, {kb}, {r});", "mul")], 0, gap_of("R1", kb, i) - 1, [(ep[kb, r], 1)])
+            else:
+                ed[kb, r] = add(f"ed{i}.{kb}{r}", [(f"e_mul({it}, {kb}, {r});", "mul")], d_done[kb] + LAG, None, [(ep[kb, r], 1)])
     for m in MATS:
         src = ep if m == "P" else ed
-        r1 = "R1" if MODE == "dq" else f"R{m}1"
-        r2 = "R2" if MODE == "dq" else f"R{m}2"
-        out = ("O" if MODE == "dq" else ("OV" if m == "P" else "OK"))
+        r1 = "R1" if MODE in ("dq", "fwd") else f"R{m}1"
+        r2 = "R2" if MODE in ("dq", "fwd") else f"R{m}2"
+        out = ("O" if MODE in ("dq", "fwd") else ("OV" if m == "P" else "OK"))
         mi = 0 if m == "P" else 1
         c0 = []
         for j in range(4):
@@ -114,6 +126,9 @@ for i in range(NS):
     for kb in range(2):
         for r in range(4):
             j = 2 * kb + (r >> 1)
+            if MODE == "fwd":
+                ep[kb, r].deadline = gap_of("R1", 0, i) - MARGIN - 2
+                continue
             if "P" in MATS:
                 ep[kb, r].deadline = gap_of("RP1", 0, i) - MARGIN - 1
             ed[kb, r].deadline = gap_of("R1" if MODE == "dq" else "RD1", 0, i) - MARGIN - 1
@@ -129,13 +144,13 @@ last_item = lambda b32: b32 * NB + NB - 1
 for b32 in range(NB32):
     fb = b32 & 1
     prev_last = last_item(b32 - 2) if b32 >= 2 else None
-    for mat, stage in (("k" if MODE == "dq" else "q", "S"), ("v" if MODE == "dq" else "d", "D")):
+    for mat, stage in ((("k", "S"),) if MODE == "fwd" else (("k" if MODE == "dq" else "q", "S"), ("v" if MODE == "dq" else "d", "D"))):
         for kb in range(2):
             for w in range(3):
                 use = gap_of(stage, 3 * kb + w, first_item(b32))
                 rel = gap_of(stage, 3 * kb + w, prev_last) + WAR if prev_last is not None else 0
                 add(f"r{mat}{b32}.{kb}{w}", [(f"rd_row({fb}, {0 if stage == 'S' else 1}, {kb}, {w}, {b32});", "rd")], rel, use - RD_AHEAD)
-    outs = (("O", 0),) if MODE == "dq" else (("OV", 1), ("OK", 0))      # dq: K^T; dkv: dO^T for dV, Q^T for dK
+    outs = (("O", 1),) if MODE == "fwd" else (("O", 0),) if MODE == "dq" else (("OV", 1), ("OK", 0))      # fwd: V^T; dq: K^T; dkv: dO^T for dV, Q^T for dK
     for stage, mat in outs:
         # planes in the order the six products take them (A operand): m, l, h, m, h, h -> first uses k = 0 (m), 1 (l), 2 (h);
         # last uses k = 3 (m), 1 (l), 5 (h)
@@ -173,7 +188,8 @@ def place(t, capv):
             if t.deadline is not None and g > t.deadline:
                 return False
         used[g % G] += c
-        sched[g % G].append((call, kind, t.name))
+        # (forward: chunks of a tile's last items that land in the NEXT body get their own names - in the first body they belong to no tile)
+        sched[g % G].append((call.replace("e_sum(", "e_sum_p(").replace("e_exp(", "e_exp_p(") if (MODE == "fwd" and g >= G) else call, kind, t.name))
         t.placed.append(g)
         g += 1
     return t.deadline is None or t.placed[-1] <= t.deadline
@@ -226,10 +242,10 @@ for s in range(NS):
         if stage in ("S", "D"):
             call = f"{CALL[stage]}({it}, {n}, {k}, {fb});"
         elif stage.startswith("R"):
-            which = 1 if stage in ("R1", "R2", "RD1", "RD2") else 0
+            which = 0 if MODE == "fwd" else (1 if stage in ("R1", "R2", "RD1", "RD2") else 0)
             call = f"m_r({it}, {which}, {1 if stage.endswith('1') else 2}, {k});"
         else:
-            which = {"O": 1, "OV": 0, "OK": 1}[stage]
+            which = 0 if MODE == "fwd" else {"O": 1, "OV": 0, "OK": 1}[stage]
             call = f"m_o({it}, {n}, {which}, {k}, {fb});"
         work = " ".join(c for c, _k, _n in sched[s * GS + g0] if c.split("(")[0] not in OMIT)
         out.append(f"{call} GAP_END; {work} GAP_END;".replace("  ", " "))
