@@ -2136,24 +2136,26 @@ def x6_fallbacks():
         report(f"x6_fallbacks ({tag}): checks run in the child (>= {least})", 0.0 if ok2 >= least else 1.0, 0)
         if res2.returncode or failed2:
             print(res2.stdout[-3000:], res2.stderr[-2000:])
-    # (4) the fix-up launch behind the pipelined head-dim-16 forward (csrc/attention6n.hip): a query's reference is its largest score
-    # against the first 32 keys; here the later keys score far above it for HALF of the queries (their weights overflow fp32), so
+    # (4) the fix-up launch behind the pipelined head-dim-16 forward (csrc/attention6n.hip; head dim 64 runs the same inputs through its
+    # running-maximum kernel): a query's reference there is its largest score against the first 32 keys; here the later keys score far above it for HALF of the queries (their weights overflow fp32), so
     # every workgroup raises its flag and the two-wavefront kernel redoes it with the moving reference - against fp64
-    with ops.precision("bf16x6"):
+    for HD4 in (16, 64):
+      with ops.precision("bf16x6"):
         gq = torch.Generator(device=dev).manual_seed(11)
         S4, H4, B4 = 2, 2, 1024
-        E4 = H4 * 16
+        E4 = H4 * HD4
+        amp = 6.0 if HD4 == 16 else 4.0
         q = torch.randn(B4, S4, E4, generator=gq, device=dev)
-        q[::2] = 6.0 + 0.1 * torch.randn(B4 // 2, S4, E4, generator=gq, device=dev)        # every other query: large, one sign
+        q[::2] = amp + 0.1 * torch.randn(B4 // 2, S4, E4, generator=gq, device=dev)        # every other query: large, one sign
         k = torch.randn(B4, S4, E4, generator=gq, device=dev) * 0.05
-        k[64:] += 6.0                                                                         # keys behind the first 64: aligned with those queries
+        k[64:] += amp                                                                         # keys behind the first 64: aligned with those queries
         v = torch.randn(B4, S4, E4, generator=gq, device=dev)
         qkv4 = torch.cat([q, k, v], dim=2)
         ref4 = _attn_ref(qkv4.double(), H4)
         od4 = _unpm(ops.list_attention(_pm(qkv4).to(dev), S4, B4, H4), B4, S4)
-        top = float((qkv4[..., :E4].double().abs().max() * qkv4[..., E4:2 * E4].double().abs().max()) * 16 * 0.25 * 1.4427)
-        report(f"x6_fallbacks: pipelined hd16 forward, overflowing weights (scores up to 2^{top:.0f}): finite", 0.0 if bool(torch.isfinite(od4).all()) else 1.0, 0)
-        report("x6_fallbacks: pipelined hd16 forward, overflowing weights: out vs fp64 (fix-up launch)", rel(od4, ref4), 2e-5)
+        top = float((qkv4[..., :E4].double().abs().max() * qkv4[..., E4:2 * E4].double().abs().max()) * math.sqrt(HD4) * 1.4427)
+        report(f"x6_fallbacks: hd{HD4} forward, weights that overflow against the first keys' maximum (scores up to 2^{top:.0f}): finite", 0.0 if bool(torch.isfinite(od4).all()) else 1.0, 0)
+        report(f"x6_fallbacks: hd{HD4} forward, such weights: out vs fp64" + (" (fix-up launch behind the pipelined kernel)" if HD4 == 16 else " (running maximum)"), rel(od4, ref4), 2e-5)
     g = torch.Generator(device=dev).manual_seed(5)
     S, H, HD = 1, 4, 64
     E = H * HD
