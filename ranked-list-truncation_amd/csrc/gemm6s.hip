@@ -58,12 +58,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_s(const void* p, uint32_t
 // TB: B stored [N][K] (y = x W^T, W row-major) or [K][N].  EPI: 0 plain, 1 C = max(C, 0), 2 the same + the 1-bit mask (C > 0) written,
 // 3 C = mask bit ? C * mask_scale : 0.  A mask word holds the 32 rows of a block for one column: a half block writes its 16 bits as a
 // short (ballot over the 16 lanes that hold a column's rows), reads its bit out of the word every lane of the column loads.
-template <int KS, bool TB, int EPI>
+// NCB: 16-column blocks per wavefront - 4 (a 256-column panel per workgroup) or 2 (128 columns: N = 128, 384 at K = 128; plain epilogues)
+template <int KS, int NCB, bool TB, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
+    static_assert(NCB == 4 || (NCB == 2 && KS == 4 && EPI < 2), "128-column panels: K = 128, plain epilogues");
+    constexpr int PW = 64 * NCB, WC = 16 * NCB;                    // columns per workgroup / per wavefront
     constexpr int GS_PLANE = gs_plane<KS>(), GS_BUF = gs_buf<KS>(), ROWB = gs_rowb<KS>(), CPR = 4 * KS, RPP = 256 / CPR, NI = 32 / RPP;
     extern __shared__ __attribute__((aligned(16))) uint8_t sm6s[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
-    const int npanel = g.N / 256;
+    const int npanel = g.N / PW;
     // (integer division runs on the vector ALU: without the readfirstlane its results - and every buffer resource formed from them - sit
     //  in VGPRs, and hipcc wraps each buffer instruction in a waterfall loop)
     const int panel = __builtin_amdgcn_readfirstlane(blockIdx.x % npanel), stream = __builtin_amdgcn_readfirstlane(blockIdx.x / npanel),
@@ -73,13 +76,13 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     (void)wl_s;
 
     // ---- the stationary panel: column 256 panel + 64 w + 16 cb + n, k = 32 ks + 8 q + j ----
-    bf16x8 wh[4][KS], wm[4][KS], wlv[4][4];
-    f32x4 bv[4];
+    bf16x8 wh[NCB][KS], wm[NCB][KS], wlv[NCB][4];
+    f32x4 bv[NCB];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {             // (second pass: the l fragments kept in VGPRs, when the others are in their AGPRs)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int col = 256 * panel + 64 * w + 16 * cb + n;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int col = PW * panel + WC * w + 16 * cb + n;
             const float* wp = TB ? g.B + (size_t)col * g.ldb + 8 * q : g.B + (size_t)(8 * q) * g.ldb + col;
 #pragma unroll
             for (int ks = 0; ks < (pass ? 4 : KS); ++ks) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
                 }
             }
             if (pass == 0) {                           // the bias of the lane's four columns: the C operand of a chain's first MFMA
-                const int c4 = 256 * panel + 64 * w + 16 * cb + 4 * q;
+                const int c4 = PW * panel + WC * w + 16 * cb + 4 * q;
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + c4); b += f32x4{t.x, t.y, t.z, t.w}; }
                 if (g.bias2) { const float4 t = *reinterpret_cast<const float4*>(g.bias2 + c4); b += f32x4{t.x, t.y, t.z, t.w}; }
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) rdo[j] = n * ROWB + 64u * (j ^ (n >> 2)) + 16u * (q ^ (n & 3));      // + buffer + plane + 16 ROWB half + 256 (ks >> 2)
     const uint8_t* wlrd = sm6s + 2 * GS_BUF + w * (4 * (KS - 4) * 1024) + lane * 16;     // + 1024 ((KS - 4) cb + ks - 4)
-    const uint32_t voff_c = (uint32_t)n * g.ldc * 4u + (64u * w + 4u * q) * 4u;            // + 16 half ldc 4 (soffset) + 64 cb
+    const uint32_t voff_c = (uint32_t)n * g.ldc * 4u + ((uint32_t)WC * w + 4u * q) * 4u;            // + 16 half ldc 4 (soffset) + 64 cb
     // mask words of the block: [column] within the panel's 256; written by lanes 0-15 (column 16 cb + lane), the others out of bounds
-    const uint32_t voff_bo = lane < 16 ? (64u * w + lane) * 4u : 0x7fff0000u;               // + 64 cb + 2 half
-    const uint32_t voff_bi = (64u * w + 4u * q) * 4u;                                       // + 64 cb: the words of the lane's four columns
+    const uint32_t voff_bo = lane < 16 ? ((uint32_t)WC * w + lane) * 4u : 0x7fff0000u;               // + 64 cb + 2 half
+    const uint32_t voff_bi = ((uint32_t)WC * w + 4u * q) * 4u;                                       // + 64 cb: the words of the lane's four columns
     uint32_t bm[5];                       // EPI 2: lane masks - ballot (lane & 3), its low half for (lane >> 2) & 3 < 2 - and the shift
 #pragma unroll
     for (int r = 0; r < 4; ++r) bm[r] = (lane & 3) == r ? 0xffffffffu : 0u;
@@ -146,28 +149,28 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     auto rs_a = [&](int i) { return rsrc_s(g.A + (size_t)(i < 0 ? 0 : blk_of(i)) * 32 * g.lda, (uint32_t)rows_of(i) * g.lda * 4u); };
     auto rs_bits = [&](int i) {
         const uint32_t* base = EPI == 2 ? g.bits_out : g.bits_in;
-        return rsrc_s(base + (size_t)(i < 0 ? 0 : blk_of(i)) * g.N + 256 * panel, rows_of(i) > 0 ? 1024u : 0u);
+        return rsrc_s(base + (size_t)(i < 0 ? 0 : blk_of(i)) * g.N + PW * panel, rows_of(i) > 0 ? (uint32_t)PW * 4u : 0u);
     };
-    auto rs_c = [&](int i) { return rsrc_s(g.C + (size_t)(i < 0 ? 0 : blk_of(i)) * 32 * g.ldc + 256 * panel, (uint32_t)rows_of(i) * g.ldc * 4u); };
+    auto rs_c = [&](int i) { return rsrc_s(g.C + (size_t)(i < 0 ? 0 : blk_of(i)) * 32 * g.ldc + PW * panel, (uint32_t)rows_of(i) * g.ldc * 4u); };
     const int nb = __builtin_amdgcn_readfirstlane(stream < nblk ? (nblk - stream + nstream - 1) / nstream : 0);      // blocks of this workgroup
 
     // ---- state ----
-    f32x4 acc[2][4], xs[2 * NI];
-    u32x4 bw[4];                         // EPI 3: the mask words of the lane's columns, per column block
-    bf16x8 bfr[2][3], lfr[4];
+    f32x4 acc[2][NCB], xs[2 * NI];
+    u32x4 bw[NCB];                         // EPI 3: the mask words of the lane's columns, per column block
+    bf16x8 bfr[2][3], lfr[NCB];
     uint4 sph, spm, spl;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { acc[i >> 2][i & 3] = z4; }
+    for (int i = 0; i < 2 * NCB; ++i) { acc[i / NCB][i % NCB] = z4; }
 #pragma unroll
     for (int i = 0; i < 2 * NI; ++i) xs[i] = z4;
 #pragma unroll
     for (int i = 0; i < 6; ++i) (&bfr[0][0])[i] = frag8s(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lfr[i] = frag8s(0u, 0u, 0u, 0u);
+    for (int i = 0; i < NCB; ++i) lfr[i] = frag8s(0u, 0u, 0u, 0u);
     sph = spm = spl = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bw[cb] = u32x4{0u, 0u, 0u, 0u};
+    for (int cb = 0; cb < NCB; ++cb) bw[cb] = u32x4{0u, 0u, 0u, 0u};
     auto load_x = [&](int i4, int part, __amdgpu_buffer_rsrc_t r) __attribute__((always_inline)) {
         xs[2 * i4 + part] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_a + 16u * part, (uint32_t)(RPP * i4) * g.lda * 4u, 0));
     };
@@ -258,8 +261,10 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
         GAP_END;
         if constexpr (KS == 8) {
 #include "gemm6s_body.inc"
-        } else {
+        } else if constexpr (NCB == 4) {
 #include "gemm6s_k128_body.inc"
+        } else {
+#include "gemm6s_k128n128_body.inc"
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
     // stores nothing (buffer bounds)
     for (int i = 0; i < nb + 1; i += 2) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int k4 = 0; k4 < KS; k4 += 4)
                 asm volatile("" : "+a"(wh[cb][k4]), "+a"(wh[cb][k4 + 1]), "+a"(wh[cb][k4 + 2]), "+a"(wh[cb][k4 + 3]), "+a"(wm[cb][k4]), "+a"(wm[cb][k4 + 1]),
@@ -284,14 +289,15 @@ __global__ __launch_bounds__(256, 1) void gemm6s_kernel(Gemm6sArgs g) {
 
 bool rlt_gemm6s_ok(const Gemm6sArgs& g) {
     static const bool on = [] { const char* e = getenv("RLT_GEMM6S"); return !e || atoi(e) != 0; }();      // RLT_GEMM6S=0: the tiled kernels (A/B runs)
-    return on && (g.K == 256 || g.K == 128) && g.N % 256 == 0 && g.N <= 256 * 256 && g.M >= 32 * 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.ldc % 4 == 0 &&
+    return on && (g.K == 256 || g.K == 128) && (g.N % 256 == 0 || (g.K == 128 && g.N % 128 == 0 && !g.bits_out && !g.bits_in)) && g.N <= 256 * 256 && g.M >= 32 * 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.ldc % 4 == 0 &&
            rlt_aligned16(g.A) && rlt_aligned16(g.B) && rlt_aligned16(g.C) && (!g.bias || rlt_aligned16(g.bias)) &&
            (!g.bias2 || rlt_aligned16(g.bias2)) && (size_t)g.lda * 4 * 32 < (1u << 31) && (size_t)g.ldc * 4 * 32 < (1u << 31) &&
            !(g.bits_out && g.bits_in) && (!g.bits_out || rlt_aligned16(g.bits_out)) && (!g.bits_in || rlt_aligned16(g.bits_in));
 }
 
 int rlt_gemm6s_launch(const Gemm6sArgs& g, bool tb, bool relu, void* stream) {
-    const int npanel = g.N / 256;
+    const bool narrow = g.N % 256 != 0;              // 128-column panels (K = 128)
+    const int npanel = g.N / (narrow ? 128 : 256);
     const int nblk = (g.M + 31) / 32;
     int nstream = 256 / npanel;                      // one workgroup per CU: the panels x as many row streams as fill the chip
     if (nstream < 1) nstream = 1;
@@ -305,8 +311,13 @@ int rlt_gemm6s_launch(const Gemm6sArgs& g, bool tb, bool relu, void* stream) {
     };
     if (g.bits_out && !relu) return -1;
     const int epi = g.bits_in ? 3 : g.bits_out ? 2 : relu ? 1 : 0;
-#define GS_GO(KS_) (tb ? (epi == 3 ? go(gemm6s_kernel<KS_, true, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, true, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, true, 1>) : go(gemm6s_kernel<KS_, true, 0>)) \
-                       : (epi == 3 ? go(gemm6s_kernel<KS_, false, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, false, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, false, 1>) : go(gemm6s_kernel<KS_, false, 0>)))
+    if (narrow) {
+        if (g.K != 128 || epi >= 2) return -1;
+        return tb ? (epi ? go(gemm6s_kernel<4, 2, true, 1>) : go(gemm6s_kernel<4, 2, true, 0>))
+                  : (epi ? go(gemm6s_kernel<4, 2, false, 1>) : go(gemm6s_kernel<4, 2, false, 0>));
+    }
+#define GS_GO(KS_) (tb ? (epi == 3 ? go(gemm6s_kernel<KS_, 4, true, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, 4, true, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, 4, true, 1>) : go(gemm6s_kernel<KS_, 4, true, 0>)) \
+                       : (epi == 3 ? go(gemm6s_kernel<KS_, 4, false, 3>) : epi == 2 ? go(gemm6s_kernel<KS_, 4, false, 2>) : epi == 1 ? go(gemm6s_kernel<KS_, 4, false, 1>) : go(gemm6s_kernel<KS_, 4, false, 0>)))
     return g.K == 256 ? GS_GO(8) : GS_GO(4);
 #undef GS_GO
 }

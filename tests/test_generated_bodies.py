@@ -26,6 +26,7 @@ CASES = [
     (["tools/gen_lstm6w_body.py", "bwd"], "lstm6w_bwd_body.inc"),
     (["tools/gen_gemm6s_body.py"], "gemm6s_body.inc"),
     (["tools/gen_gemm6s_body.py", "k128"], "gemm6s_k128_body.inc"),
+    (["tools/gen_gemm6s_body.py", "k128n128"], "gemm6s_k128n128_body.inc"),
 ]
 
 
@@ -160,11 +161,11 @@ def test_gemm6s_body_and_loop(tmp_path):
     import re
     import shutil
     from collections import Counter
-    for inc, KS in (("gemm6s_body.inc", 8), ("gemm6s_k128_body.inc", 4)):
+    for inc, KS, NCB in (("gemm6s_body.inc", 8, 4), ("gemm6s_k128_body.inc", 4, 4), ("gemm6s_k128n128_body.inc", 4, 2)):
         text = open(os.path.join(CSRC, inc)).read()
         mf = re.findall(r"\bMG\((\d), (\d), (\d), (\d), (\d)\)", text)
-        assert len(mf) == 48 * KS and len(set(m[:4] for m in mf)) == 48 * KS
-        assert sorted((m[0], m[3]) for m in mf if m[4] == "1") == sorted((str(h), str(c)) for h in range(2) for c in range(4))
+        assert len(mf) == 12 * NCB * KS and len(set(m[:4] for m in mf)) == 12 * NCB * KS
+        assert sorted((m[0], m[3]) for m in mf if m[4] == "1") == sorted((str(h), str(c)) for h in range(2) for c in range(NCB))
         seq = {}
         for h, ks, p, cb, _f in mf:
             seq.setdefault((h, ks, cb), []).append(int(p))
@@ -172,7 +173,7 @@ def test_gemm6s_body_and_loop(tmp_path):
         calls = Counter(re.findall(r"\b([A-Z][A-Z]\([^)]*\))", text))
         # (the LDS-resident l fragments of k-steps 4-7 are read once per half: twice per block)
         assert all(v == (2 if c.startswith("RL(") else 1) for c, v in calls.items())
-        assert sum(1 for c in calls if c.startswith("EP(")) == 8 and sum(1 for c in calls if c.startswith("SX(")) == 7 * KS // 2
+        assert sum(1 for c in calls if c.startswith("EP(")) == 2 * NCB and sum(1 for c in calls if c.startswith("SX(")) == 7 * KS // 2
     from rlt_hip import build as B
     if shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC):
         pytest.skip("no hipcc")
@@ -180,11 +181,11 @@ def test_gemm6s_body_and_loop(tmp_path):
     subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["gemm6s.hip"] + ["-S", "--cuda-device-only", os.path.join(CSRC, "gemm6s.hip"), "-o", str(asm)],
                    check=True, capture_output=True)
     kernels = re.findall(r"^(_ZN12_GLOBAL__N_113gemm6s_kernel\w+):(.*?)s_endpgm", asm.read_text(), flags=re.S | re.M)
-    assert len(kernels) == 16                 # K = 256 / 128 x two weight layouts x four epilogues
+    assert len(kernels) == 20                 # K = 256 / 128 x two weight layouts x four epilogues + 128-column panels (K = 128, two epilogues)
     for name, body in kernels:
         assert "scratch_" not in body, name
         blocks = re.split(r"^\.LBB\w+:", body, flags=re.M)
-        loops = [b for b in blocks if b.count("v_mfma_f32_16x16x32_bf16") in (768, 384)]
+        loops = [b for b in blocks if b.count("v_mfma_f32_16x16x32_bf16") in (768, 384, 192)]
         assert len(loops) == 1, name                                # two blocks per iteration, one basic block
         loop = loops[0]
         assert "v_accvgpr" not in loop and "flat_" not in loop and "vmcnt(0)" not in loop and "s_cbranch_execnz" not in loop, name

@@ -97,7 +97,7 @@ def gemm():
         report(f"gemm_ex colsum {M}x{Nn}x{K}", rel(cs, A.double().sum(0)), 1e-5)
     # K = 256 with >= 8192 rows: the weights-stationary streaming kernel of the bf16x6 mode (csrc/gemm6s.hip) - ragged last block, rows
     # behind the end untouched, one / three / four panels, both layouts of the weight, two biases, strided A and C
-    for (M, Nn, K) in [(8209, 256, 256), (8192 + 31, 768, 256), (12000, 1024, 256), (8192 + 7, 512, 128), (20000, 2048, 128)]:
+    for (M, Nn, K) in [(8209, 256, 256), (8192 + 31, 768, 256), (12000, 1024, 256), (8192 + 7, 512, 128), (20000, 2048, 128), (8192 + 19, 384, 128), (9000, 128, 128)]:
         A, W, W2, b1, b2 = torch.randn(M, K + 4), torch.randn(Nn, K) / 16, torch.randn(K, Nn) / 16, torch.randn(Nn), torch.randn(Nn)
         for tb, Bm in ((1, W), (0, W2)):
             C = torch.full((M + 3, Nn + 4), 7.0, device=dev)
