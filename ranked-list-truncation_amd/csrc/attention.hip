@@ -666,12 +666,21 @@ static bool a6n_fwd_images(int HD, int B) {
 }
 static size_t a6n_flags_bytes(int S, int B, int H) { return ((size_t)S * H * rlt_cdiv(B, 256) * sizeof(uint32_t) + 255) / 256 * 256; }
 
+// bf16x6 at head dim 64, 512 lists and more in whole 64-row tiles, no dropout: the pipelined forward kernel of attention6h.hip, same
+// scheme - K / V tile images of the call + a flag word per 256-query workgroup in the forward's `images` buffer, fix-up launch of
+// attention6.hip's ping-pong kernel for the flagged workgroups.  RLT_A6H=0: attention6.hip's kernel alone (A/B runs)
+static bool a6h_fwd_images(int HD, int B) {
+    static const bool on = [] { const char* e = getenv("RLT_A6H"); return !e || atoi(e) != 0; }();
+    return on && HD == 64 && B >= 512 && B % 64 == 0 && attn6_use(HD, 0.f) && !attn6_img(HD);
+}
+
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision) {
     RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
     if (a6n_fwd_images(HD, B)) return rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
+    if (a6h_fwd_images(HD, B)) return rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
     return attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 3) : 0;
 }
 
@@ -700,6 +709,17 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
             if (!rc) rc = rlt_attn6n_prepare_at(2, 1, a, st);
             if (rc) return rc;
             return rlt_attn6n_run(0, a, st);
+        }
+        if (drop_p <= 0.f && a6h_fwd_images(HD, B) && images && rlt_aligned16(images) &&
+            images_bytes >= rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H)) {
+            AttnArgs b = a;
+            b.img = images;
+            b.redo = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(images) + rlt_attn6h_fwd_images_bytes(S, B, H));
+            int rc = rlt_attn6h_prepare2(1, 0, 2, 1, b, st);        // K, V tile images of this call
+            if (!rc) rc = rlt_attn6h_run(0, b, st);
+            if (rc) return rc;
+            b.img = nullptr;                                        // the fix-up launch stages its tiles itself
+            return rlt_attn6_run(0, b, HD, st);
         }
         if (attn6_img(HD) && images) {       // the backward kernels will stage from these images: they must all be written
             if (images_bytes < rlt_attn6_images_bytes(S, B, H, HD, 3)) return RLT_E_WORKSPACE;

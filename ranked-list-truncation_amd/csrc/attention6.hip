@@ -415,6 +415,8 @@ __global__ __launch_bounds__(512, 1) void attn6_fwd_pp_kernel(AttnArgs a) {
     const int q = qt * QT_PP + wv * 32 + l31;
     const bool wave_live = qt * QT_PP + wv * 32 < B;
     const int qc = min(q, B - 1);
+    // second launch behind the pipelined forward kernel of attention6h.hip: only the workgroups it flagged (same grid, same block -> rows map)
+    if (a.redo && a.redo[blockIdx.x] == 0u) return;
 
     Frag3 qf[HD / 16];
     row_frags6<HD>(base + (size_t)qc * ld, hh, a.scale * LOG2E, qf);
@@ -1373,7 +1375,7 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
     int rc;
     static const bool pp = [] { const char* e = getenv("RLT_A6_PP"); return !e || atoi(e) != 0; }();    // RLT_A6_PP=0: the two-workgroup form
     if constexpr (HD == 64) {                 // ping-pong form (instantiated for head dim 64 only): one 512-thread workgroup per CU, 256 queries
-        if (which == 0 && pp) {
+        if (which == 0 && (pp || a.redo)) {          // (a.redo: the fix-up launch behind attention6h.hip's forward is this kernel's grid)
             const size_t shm_pp = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t);
             if ((rc = rlt_allow_lds(attn6_fwd_pp_kernel<HD, DROP, IMG>, shm_pp))) return rc;
             hipLaunchKernelGGL((attn6_fwd_pp_kernel<HD, DROP, IMG>), dim3(a.S * a.H * rlt_cdiv(a.B, QT_PP)), dim3(512), shm_pp, st, a);

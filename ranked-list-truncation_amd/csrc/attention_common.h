@@ -9,7 +9,7 @@ struct AttnArgs {
     int S, B, H;
     float scale;
     float drop_p; uint32_t drop_thr, seed;    // dropout on the attention probabilities (train mode)
-    uint32_t* redo;                           // head dim 16 pipelined forward: one flag word per workgroup (attention6n.hip), or null
+    uint32_t* redo;                           // pipelined forward kernels (attention6n.hip, attention6h.hip): one flag word per workgroup, or null
 };
 
 // One LDS-DMA piece as inline assembly: M0 carries the LDS destination.  hipcc treats M0 as a reserved register (a
@@ -85,6 +85,11 @@ int rlt_attn6n_prepare_at(int what, int slot, const AttnArgs& a, hipStream_t st)
 // rlt_attn6n_images_bytes bytes, written by rlt_attn6n_prepare (what = 0 Q, 1 K, 2 V, 3 dO, 4 seeds)
 size_t rlt_attn6n_images_bytes(int S, int B, int H);
 int rlt_attn6n_prepare(int what, const AttnArgs& a, hipStream_t st);
+// ... at head dim 64 in the same form (attention6h.hip): the pipelined forward stages pre-split K / V tile images (blocks 0 / 1 of
+// a.img, written by rlt_attn6h_prepare2) and leaves a flag word per workgroup (a.redo) for the fix-up launch of attention6.hip
+size_t rlt_attn6h_fwd_images_bytes(int S, int B, int H);
+int rlt_attn6h_prepare2(int what0, int slot0, int what1, int slot1, const AttnArgs& a, hipStream_t st);
+int rlt_attn6h_run(int which, const AttnArgs& a, hipStream_t st);
 // exact fp32 at head dim 16 on the 16x16x4 MFMA (no padded head-dim axis), defined in attention16.hip: same `which`
 int rlt_attn16_run(int which, const AttnArgs& a, hipStream_t st);
 // split-bf16 ("bf16x3") path, defined in attention3.hip

@@ -16,8 +16,10 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # attention6n.hip, -amdgpu-mfma-vgpr-form: its one-wavefront kernels own 512 registers, where hipcc would select the AGPR form of every
 # MFMA and move each score register to a VGPR and back around the element-wise work (828 v_accvgpr moves per tile body of the dQ
 # kernel); with the VGPR form the accumulators the vector ALU touches stay where it can reach them
+# attention6h.hip: the same form at head dim 64, the same flags
 # lstm6w.hip, no SLP packing: the split residuals of values that sit in different registers would be packed by first MOVING them into pairs
 FILE_FLAGS = {"attention6.hip": ["-fno-slp-vectorize"], "attention6n.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+              "attention6h.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
               "lstm6w.hip": ["-fno-slp-vectorize"], "gemm6s.hip": ["-fno-slp-vectorize"]}
 
 

@@ -355,7 +355,10 @@ def attention():
     for (B, S, H, HD) in [(5, 7, 4, 64), (63, 5, 4, 64), (130, 3, 2, 64), (200, 2, 4, 64), (5, 9, 8, 16), (70, 4, 8, 16),
                           (33, 3, 2, 32), (300, 2, 4, 64), (6, 3, 2, 128), (70, 2, 2, 128), (130, 2, 1, 128),
                           # whole 64-key tiles: the one-wavefront forward kernel of head dim 64 (1, 2, 5 tiles; 320 = a partial workgroup)
-                          (64, 3, 4, 64), (128, 2, 2, 64), (320, 2, 4, 64)]:
+                          (64, 3, 4, 64), (128, 2, 2, 64), (320, 2, 4, 64),
+                          # 512 lists and more in whole 64-row tiles: the pipelined forward of attention6h.hip (8 tiles; 9 tiles with a
+                          # partly filled workgroup; 13 tiles, one head)
+                          (512, 2, 4, 64), (576, 1, 2, 64), (832, 1, 1, 64)]:
         E = H * HD
         qkv = torch.randn(B, S, 3 * E)
         dout = torch.randn(B, S, E)
@@ -395,7 +398,7 @@ def attention():
     # the first tile's reference in place while the later weights underflow; a ramp of 6 stays inside the lazy window.  At span 280
     # one fp32 ulp of a score is 3e-5 and the weights of the top keys carry that as a RELATIVE error whatever the kernel does
     # (measured 2.5e-5 .. 6e-5 on the f32 MFMA): that case has the looser bound.
-    for HD, B in ((16, 300), (64, 300), (64, 320)):      # (320: whole tiles - the one-wavefront forward kernel)
+    for HD, B in ((16, 300), (64, 300), (64, 320), (64, 640)):      # (320: whole tiles; 640: the pipelined forward with its FIXED reference - the steep ramps raise its flags and take the fix-up launch)
         for tag, span, ftol in (("rising", 40.0, 2e-5), ("steeply rising", 280.0, 2e-4), ("falling", -280.0, 2e-5),
                                 ("inside the window", 6.0, 2e-5)):
             S, H = 2, 2
@@ -932,10 +935,11 @@ def _chunks(n, step):
 
 
 @section
-def scale_ops():
-    """Kernel families at the shapes of the 4096 x 300 step against fp64 references (every element compared)."""
-    # list-axis attention: 16 / 32 query+key tiles per column
-    for (B, S, H, HD) in [(4096, 2, 4, 64), (8192, 2, 8, 16)]:
+@section
+def scale_attention(shapes=((4096, 2, 4, 64), (8192, 2, 8, 16))):
+    """List-axis attention at the batch sizes of the BASELINE configurations against fp64 (every element compared): 16 / 32 query + key
+    tiles per column."""
+    for (B, S, H, HD) in shapes:
         E = H * HD
         g = torch.Generator(device="cpu").manual_seed(B + HD)
         qkv = torch.randn(B, S, 3 * E, generator=g)
@@ -953,6 +957,12 @@ def scale_ops():
         report(f"attn dv   B{B} S{S} H{H} HD{HD}", rel(gq[..., 2 * E:], qr.grad[..., 2 * E:]), mfma_tol(3e-5))
         del qr, orf, qd, od, gq
         torch.cuda.empty_cache()
+
+
+@section
+def scale_ops():
+    """Kernel families at the shapes of the 4096 x 300 step against fp64 references (every element compared)."""
+    scale_attention()
     # GEMMs with 1,228,800 rows (= 4096 lists x 300 positions): all four layouts
     T = 4096 * 300
     g = torch.Generator(device=dev).manual_seed(5)
