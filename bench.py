@@ -319,10 +319,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # a rank that cannot join (RCCL refuses two ranks on one GPU, a peer died) must fail, not sit in a collective: bounded waits
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("RLT_DIST_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
         assert dist.get_world_size() == args.gpus
 
     import models as hip_models

@@ -35,7 +35,7 @@ extern "C" {
 #define RLT_E_WORKSPACE (-3)  /* workspace too small                               */
 #define RLT_E_ALIGN    (-4)   /* pointer / leading dimension not 16-byte aligned   */
 
-#define RLT_ABI_VERSION 4
+#define RLT_ABI_VERSION 5
 int rlt_abi_version(void);
 /* Precision of the MFMA contractions (the rlt_gemm* family, rlt_list_attention_*, the BiLSTM recurrences); inputs, outputs,
  * softmax, LayerNorm, gate nonlinearities, losses and every accumulator are fp32 in all modes.
@@ -274,7 +274,13 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
  * for the dropout rate of THIS call (without dropout the head-dim-64 backward kernels read the transposed operands
  * straight from the row images and the transposed images of Q and K are not written): the backward entry points must
  * be given the same drop_p and seed as the forward call whose `images` they use. */
-size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision);
+/* BF16X6 without dropout, 512 lists and more in whole tiles (head dim 64: csrc/attention6h.hip; head dim 16: csrc/attention6n.hip):
+ * the pipelined forward kernels stage pre-split K / V tile images that the call itself writes into `images` (+ a flag word per
+ * workgroup for its fix-up launch); the backward pass does not read them - rlt_list_attention_images_retained() tells whether the
+ * caller has to keep `images` for the backward (1) or may treat it as scratch of the forward call (0).  `drop_p` of the workspace
+ * query = the drop_p of the forward call (a train-mode call has no pipelined form and needs no such buffer). */
+size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, float drop_p, int precision);
+int rlt_list_attention_images_retained(int S, int B, int H, int HD, int precision);
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
                            float* out, float* lse, void* images, size_t images_bytes, int precision, void* stream);
 /* backward: ws = [delta (S,H,B) | tile records], rlt_list_attention_bwd_workspace bytes.
@@ -285,15 +291,18 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
  * pre-split 128-row tile images of Q, K, V, dO and the rows' seeds (-lse, -delta) from ws - _bwd_prepare writes the dO images and
  * the seeds, _bwd_dkv the Q images, _bwd_dq the K and V images, each before its kernel (so the three entry points stay callable
  * on their own; ws is scratch of ONE backward pass: the parts of a pass run on one stream, in any order after _bwd_prepare). */
-size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, int precision);
+/* `drop_p` of the workspace query and of _bwd_prepare = the drop_p of the forward call (train-mode kernels stage their tiles
+ * themselves: ws is delta only).  The parts check ws_bytes against the same rule in their OWN precision scope and ws for 16-byte
+ * alignment: RLT_E_WORKSPACE / RLT_E_ALIGN instead of a device write beyond a buffer sized under another mode. */
+size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, float drop_p, int precision);
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                            int S, int B, int H, int HD, float drop_p, uint32_t seed, const void* images, float* dqkv,
                            void* ws, size_t ws_bytes, int precision, void* stream);
-int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD, float drop_p,
                                    const void* images, void* ws, size_t ws_bytes, int precision, void* stream);
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws, size_t ws_bytes,
                                int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream);
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws, size_t ws_bytes,
                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream);
 /* keep-mask of the attention-probability dropout as data (tests, small B): out (S,H,B,B) =
  * keep ? 1/(1-p) : 0 for (position, head, query, key) */

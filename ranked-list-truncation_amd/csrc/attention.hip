@@ -674,14 +674,23 @@ static bool a6h_fwd_images(int HD, int B) {
     return on && HD == 64 && B >= 512 && B % 64 == 0 && attn6_use(HD, 0.f) && !attn6_img(HD);
 }
 
-size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, int precision) {
+size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, float drop_p, int precision) {
     RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
     if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
-    if (a6n_fwd_images(HD, B)) return rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
-    if (a6h_fwd_images(HD, B)) return rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
+    // (the pipelined forward kernels have no train-mode form: a call with dropout does not use - and need not be given - their images)
+    if (!(drop_p > 0.f) && a6n_fwd_images(HD, B)) return rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
+    if (!(drop_p > 0.f) && a6h_fwd_images(HD, B)) return rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
     return attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 3) : 0;
+}
+
+// 1: the backward entry points read the forward's `images` (split-bf16 tile records; the RLT_ATTN6_IMG staging) - the caller keeps
+// the buffer until the backward pass; 0: `images` is scratch of the forward call (the pipelined bf16x6 forward kernels) or empty
+int rlt_list_attention_images_retained(int S, int B, int H, int HD, int precision) {
+    RLT_PREC_SCOPE_SZ(precision);
+    if (S <= 0 || B <= 0 || H <= 0 || !hd_ok(HD)) return 0;
+    return attn_mode(HD) == 1 || attn6_img(HD) ? 1 : 0;
 }
 
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,
@@ -737,26 +746,31 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
     return launch_fwd<16>(a, st);
 }
 
-size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, int precision) {
+// bytes behind delta: the dO tile records (split-bf16), the dO images (RLT_ATTN6_IMG) or the four image blocks + seeds of the pipelined
+// head-dim-16 kernels (no dropout only: the train-mode kernels stage their tiles themselves)
+static size_t bwd_ws_extra(int S, int B, int H, int HD, float drop_p) {
+    return attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1)
+         : attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 1)
+         : a6n_images(HD, B) && !(drop_p > 0.f) ? rlt_attn6n_images_bytes(S, B, H) : 0;
+}
+size_t rlt_list_attention_bwd_workspace(int S, int B, int H, int HD, float drop_p, int precision) {
     RLT_PREC_SCOPE_SZ(precision);
     if (S <= 0 || B <= 0 || H <= 0) return 0;
     if (!hd_ok(HD)) return 0;
-    return delta_bytes(S, B, H) + (attn_mode(HD) == 1 ? rlt_attn3_images_bytes(S, B, H, HD, 1)
-                                                      : attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 1)
-                                                      : a6n_images(HD, B) ? rlt_attn6n_images_bytes(S, B, H) : 0);
+    return delta_bytes(S, B, H) + bwd_ws_extra(S, B, H, HD, drop_p);
 }
 
-// drop_p < 0: unknown (the stand-alone entry point), the dO records get both images
 static int bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
                        const void* images, void* ws, size_t ws_bytes, float drop_p, void* stream) {
-    RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0);
+    RLT_CHECK_ARG(out && dout && lse && ws && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(hd_ok(HD));
     const bool split = attn_mode(HD) == 1 && images;
     const bool img6 = !split && attn6_img(HD) && images;      // bwd_part hands ws + delta to the kernels as the dO images
-    const bool img6n = !split && a6n_images(HD, B) && drop_p <= 0.f;      // (drop_p < 0: unknown - the images are written in case)
+    const bool img6n = !split && a6n_images(HD, B) && drop_p <= 0.f;
     if (ws_bytes < delta_bytes(S, B, H) + (split ? rlt_attn3_images_bytes(S, B, H, HD, 1)
                                                  : img6 ? rlt_attn6_images_bytes(S, B, H, HD, 1)
-                                                 : a6n_images(HD, B) ? rlt_attn6n_images_bytes(S, B, H) : 0)) return RLT_E_WORKSPACE;
+                                                 : img6n ? rlt_attn6n_images_bytes(S, B, H) : 0)) return RLT_E_WORKSPACE;
+    if (!rlt_aligned16(ws)) return RLT_E_ALIGN;
     hipStream_t st = rlt_stream(stream);
     const size_t T = (size_t)S * B;
     const int dgrid = (int)((T + 3) / 4 > 4096 ? 4096 : (T + 3) / 4);
@@ -785,17 +799,20 @@ static int bwd_prepare(const float* out, const float* dout, const float* lse, in
     return rlt_attn3_run(3, a, HD, nullptr, (uint8_t*)ws + delta_bytes(S, B, H), st);
 }
 
-int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD,
+int rlt_list_attention_bwd_prepare(const float* out, const float* dout, const float* lse, int S, int B, int H, int HD, float drop_p,
                                    const void* images, void* ws, size_t ws_bytes, int precision, void* stream) {
     RLT_PREC_SCOPE(precision);
-    return bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, -1.f, stream);
+    return bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, drop_p, stream);
 }
 
-static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
+static int bwd_part(int which, const float* qkv, const float* dout, const float* lse, const void* images, void* ws, size_t ws_bytes,
                     int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, void* stream) {
     RLT_CHECK_ARG(qkv && dout && lse && ws && dqkv && S > 0 && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f);
     RLT_CHECK_SHAPE(hd_ok(HD));
-    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv))) return RLT_E_ALIGN;
+    if (!(rlt_aligned16(qkv) && rlt_aligned16(dout) && rlt_aligned16(dqkv) && rlt_aligned16(ws))) return RLT_E_ALIGN;
+    // the part reads delta - and, by mode, reads or WRITES tile images behind it: the same size rule as _bwd_prepare, evaluated in THIS
+    // call's precision scope (a workspace sized under another mode, or by an older delta-only rule, is refused instead of overrun)
+    if (ws_bytes < delta_bytes(S, B, H) + (images || attn_mode(HD) != 1 ? bwd_ws_extra(S, B, H, HD, drop_p) : 0)) return RLT_E_WORKSPACE;
     const AttnArgs a = bwd_args(qkv, dout, lse, (const float*)ws, S, B, H, HD, drop_p, seed, dqkv);
     hipStream_t st = rlt_stream(stream);
     if (attn_mode(HD) == 1 && images)
@@ -828,16 +845,16 @@ static int bwd_part(int which, const float* qkv, const float* dout, const float*
     return launch_dq<16>(a, st);
 }
 
-int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
+int rlt_list_attention_bwd_dkv(const float* qkv, const float* dout, const float* lse, const void* images, void* ws, size_t ws_bytes,
                                int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
     RLT_PREC_SCOPE(precision);
-    return bwd_part(1, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    return bwd_part(1, qkv, dout, lse, images, ws, ws_bytes, S, B, H, HD, drop_p, seed, dqkv, stream);
 }
 
-int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws,
+int rlt_list_attention_bwd_dq(const float* qkv, const float* dout, const float* lse, const void* images, void* ws, size_t ws_bytes,
                               int S, int B, int H, int HD, float drop_p, uint32_t seed, float* dqkv, int precision, void* stream) {
     RLT_PREC_SCOPE(precision);
-    return bwd_part(2, qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, stream);
+    return bwd_part(2, qkv, dout, lse, images, ws, ws_bytes, S, B, H, HD, drop_p, seed, dqkv, stream);
 }
 
 int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
@@ -846,8 +863,8 @@ int rlt_list_attention_bwd(const float* qkv, const float* out, const float* dout
     RLT_PREC_SCOPE(precision);
     RLT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     int rc = bwd_prepare(out, dout, lse, S, B, H, HD, images, ws, ws_bytes, drop_p, stream);     // knows whether dO^T is needed
-    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
-    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dkv(qkv, dout, lse, images, ws, ws_bytes, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
+    if (!rc) rc = rlt_list_attention_bwd_dq(qkv, dout, lse, images, ws, ws_bytes, S, B, H, HD, drop_p, seed, dqkv, RLT_PRECISION_DEFAULT, stream);
     return rc;
 }
 

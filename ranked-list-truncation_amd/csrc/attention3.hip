@@ -1293,7 +1293,7 @@ int run3(int which, const AttnArgs& a, void* images, void* dimages, hipStream_t 
         p.out = (uint8_t*)dimages; p.S = a.S; p.B = a.B; p.H = a.H; p.nmat = 1;
         p.perm16[0] = HD == 16 && RLT_HD16_SMALL_MFMA;       // dO^T likewise
         // dO^T is read transposed from the rows image by the stepped dK+dV body; the caller says so with drop_p == 0
-        // (rlt_list_attention_bwd; the stand-alone prepare entry point passes drop_p < 0 = unknown)
+        // (rlt_list_attention_bwd and, since ABI 5, the stand-alone prepare entry point: both are given the forward call's drop_p)
         constexpr bool TR_DKV = HD == 64 && RLT_STEPPED != 0 && RLT_DKV_TRREAD != 0 && RLT_STEPPED_SPREAD != 0 && spread_dma<HD>();
         p.skip_t[0] = TR_DKV && a.drop_p == 0.f;
         return prepare3<HD>(p, st);

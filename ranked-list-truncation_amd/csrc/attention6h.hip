@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void attn6h_prepare_kernel(const float* __rest
     }
 }
 
+#ifndef RLT_A6H_FWD1_BODY          // (timing experiments compile other generated bodies: tools/gen_attn6h_body.py with GEN_OMIT / GEN_DMA_STEP)
+#define RLT_A6H_FWD1_BODY "attention6h_fwd1_body.inc"
+#endif
 #ifdef RLT_A6H_STAMPS
 // diagnostic build only: s_memtime at every slot of tiles 8..11 of one workgroup; entries 16 / 17: before / behind the barrier
 __device__ unsigned long long a6h_stamps[4 * 4 * 18];
@@ -177,13 +180,19 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
     const int npair = a.S * H;
     const uint8_t* rec0 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)0 * npair + pair) * (size_t)(nt + 1) * RECH;      // K images
     const uint8_t* rec1 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)1 * npair + pair) * (size_t)(nt + 1) * RECH;      // V images
-    // staging: piece j of this wavefront = piece wv + 4 (j % 6) of matrix j / 6 (24 pieces of 1 KiB per image)
+    // staging: a wavefront copies pieces 6 wv .. 6 wv + 5 of each image (24 pieces of 1 KiB).  The record has the LDS layout, so the
+    // instruction's immediate offset moves the source and the destination together: M0 (the LDS base) is written once per group of
+    // up to four pieces (j % 6 == 0 and == 4), not per piece.  Nothing else in this kernel uses M0 (no movrel, no other LDS-DMA
+    // builtin); the statements neither save nor restore it.
     auto dma = [&](int j, int tile, uint16_t* ibuf) __attribute__((always_inline)) {
-        const int piece = wv + 4 * (j % 6);
-        const uint8_t* rec = (j < 6 ? rec0 : rec1) + (size_t)tile * RECH + piece * 1024 + lane * 16;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 6) * RECH + piece * 1024));
-        RLT_DMA_ASM(dst, rec);
+        const int q = j % 6, grp = q < 4 ? 0 : 4;
+        const uint8_t* rec = (j < 6 ? rec0 : rec1) + (size_t)tile * RECH + (6 * wv + grp) * 1024 + lane * 16;
+        if (q == grp) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 6) * RECH + (6 * wv + grp) * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst) : "memory");
+        }
+        asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(rec), "n"((q - grp) * 1024) : "memory");
     };
 #pragma unroll
     for (int j = 0; j < 12; ++j) dma(j, 0, img0);
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
                 (v4s __attribute__((address_space(3)))*)(Ic + IMGH + pl * PLH + (32 * b32 + 16 * half) * 64 + offT[db]));
         };
         auto st_dma = [&](int j) __attribute__((always_inline)) { dma(j, t_next, In); };
-#include "attention6h_fwd1_body.inc"
+#include RLT_A6H_FWD1_BODY
 #undef GAP_END
         A6H_STAMP(16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's LDS-DMA pieces of the next tile have landed

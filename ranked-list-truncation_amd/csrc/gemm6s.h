@@ -12,5 +12,8 @@ struct Gemm6sArgs {
     const uint32_t* bits_in;                       // C = bit ? C * mask_scale : 0
     float mask_scale;
 };
-bool rlt_gemm6s_ok(const Gemm6sArgs& g);           // shape / alignment conditions (K == 256, N % 256 == 0, M >= 8192)
+// shape / alignment conditions: K == 256 with N % 256 == 0, or K == 128 with N % 256 == 0 (N % 128 == 0 without the mask epilogues); M >= 8192.
+// Mask epilogue (bits_out): the rows past M of the last 32-row block are evaluated as relu(bias) > 0 and their bits land in the final
+// mask word - no consumer reads them (rlt_gemm_bits indexes rows < M), but the word differs from the tiled kernels' (which write 0 there).
+bool rlt_gemm6s_ok(const Gemm6sArgs& g);
 int rlt_gemm6s_launch(const Gemm6sArgs& g, bool tb, bool relu, void* stream);      // 0 or a hip error code (bits_out needs relu; not both bit pointers)

@@ -736,7 +736,8 @@ static int launch_bilstm_fwd(float* gates, const float* w_hh_fwd, const float* w
     hipStream_t st = rlt_stream(stream);
     static const bool lstm6_on = [] { const char* e = getenv("RLT_LSTM6"); return !e || atoi(e) != 0; }();      // RLT_LSTM6=0: the f32 MFMA kernels (A/B runs)
     static const bool lstm6w_on = [] { const char* e = getenv("RLT_LSTM6W"); return !e || atoi(e) != 0; }();    // RLT_LSTM6W=0: round 4's two-phase kernel
-    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on && lstm6w_on) {
+    // (lstm6w.hip bounds its buffer instructions with 32-bit byte counts of B * 4096: 2^20 lists and more take the kernels of this file)
+    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on && lstm6w_on && B < (1 << 20)) {
         const int rc = rlt_lstm6w_fwd(gates, w_hh_fwd, w_hh_rev, S, B, h_out, c_out, xi, stream);
         if (rc) return rc;
     } else if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6_on) {
@@ -804,7 +805,7 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
         const char* b = getenv("RLT_LSTM6W_BWD");
         return (!e || atoi(e) != 0) && (!b || atoi(b) != 0);
     }();
-    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6w_bwd_on) {
+    if (rlt_precision() == RLT_PRECISION_BF16X6 && lstm6w_bwd_on && B < (1 << 20)) {
         rc = rlt_lstm6w_bwd(gates, c, w_hh_fwd, w_hh_rev, d_hout, S, B, stream);
         if (rc) return rc;
     } else if (rlt_precision() == RLT_PRECISION_BF16X3)

@@ -45,7 +45,8 @@ inline int enc_dims(int S, int B, int E, int H, int FF, EncDims& d) {
 
 // stash written by the forward and read by the backward, in this order (all regions 256-byte aligned):
 //   qkv (T,3E) | att (T,E) | lse (S,H,B) | proj (T,E) | st1 (T,2) | h1 (T,E) | hid (T,FF) | relu bits (ceil(T/32),FF) u32 |
-//   ff (T,E) | st2 (T,2) | attention tile records (rlt_list_attention_fwd_workspace bytes, split-bf16 mode only)
+//   ff (T,E) | st2 (T,2) | attention tile records (rlt_list_attention_fwd_workspace bytes; only where the backward reads them:
+//   rlt_list_attention_images_retained - the split-bf16 mode)
 struct EncStash {
     float *qkv, *att, *lse, *proj, *st1, *h1, *hid, *ff, *st2;
     uint32_t* bits;
@@ -66,10 +67,18 @@ inline EncStash enc_stash(const EncDims& d, void* base, size_t cap = (size_t)-1)
     s.bits = d.bits ? c.take<uint32_t>(rlt_gemm_bits_words((int)T, d.FF) * sizeof(uint32_t)) : nullptr;
     s.ff = c.take(T * d.E * f);
     s.st2 = c.take(T * 2 * f);
-    s.images_bytes = rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT);
+    // (only the records the BACKWARD reads live in the stash; the images of the pipelined bf16x6 forward kernels are scratch of the
+    // forward call: enc_fwd_images_scratch below)
+    const bool keep = rlt_list_attention_images_retained(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT) != 0;
+    s.images_bytes = keep ? rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD, 0.f, RLT_PRECISION_DEFAULT) : 0;
     s.images = s.images_bytes ? c.take<uint8_t>(s.images_bytes) : nullptr;
     s.bytes = c.off;
     return s;
+}
+// forward scratch: [ split-K workspace of the GEMMs | attention images that the backward does not read ]
+inline size_t enc_fwd_images_scratch(const EncDims& d, float drop_p) {
+    if (rlt_list_attention_images_retained(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT)) return 0;
+    return rlt_list_attention_fwd_workspace(d.S, d.B, d.H, d.HD, drop_p, RLT_PRECISION_DEFAULT);
 }
 
 // backward scratch.  Two phases share the big middle region:
@@ -109,7 +118,7 @@ inline EncScratch enc_scratch(const EncDims& d, bool drop, void* base, size_t ca
     w.dr1 = drop ? c.take(T * d.E * f) : nullptr;
     w.datt = c.take(T * d.E * f);
     w.dqkv = c.take(T * 3 * d.E * f);
-    w.attn_ws_bytes = rlt_list_attention_bwd_workspace(d.S, d.B, d.H, d.HD, RLT_PRECISION_DEFAULT);
+    w.attn_ws_bytes = rlt_list_attention_bwd_workspace(d.S, d.B, d.H, d.HD, drop ? 0.5f : 0.f, RLT_PRECISION_DEFAULT);     // (any rate > 0: the size depends on train / eval only)
     w.attn_ws = c.take<uint8_t>(w.attn_ws_bytes);
     if (c.off < end_ffn) c.off = end_ffn;
     w.ln_ws_bytes = rlt_add_layernorm_bwd_workspace((int)T, d.E);
@@ -257,7 +266,7 @@ size_t rlt_workspace_bytes(int op, int S, int B, int E, int H, int FF, int train
         EncDims d;
         if (enc_dims(S, B, E, H, FF, d)) return 0;
         if (op == RLT_OP_ENCODER_STASH) return enc_stash(d, nullptr).bytes;
-        if (op == RLT_OP_ENCODER_FWD_WS) return rup(enc_gemm_ws(d));
+        if (op == RLT_OP_ENCODER_FWD_WS) return rup(enc_gemm_ws(d)) + rup(enc_fwd_images_scratch(d, train_dropout ? 0.5f : 0.f));
         return enc_scratch(d, train_dropout != 0, nullptr).bytes;
     }
     if (op == RLT_OP_BILSTM_STASH || op == RLT_OP_BILSTM_WS) {
@@ -278,8 +287,10 @@ int rlt_encoder_layer_fwd(const float* x, const rlt_encoder_weights* w, int S, i
                   w->norm2_weight && w->norm2_bias);
     EncDims d;
     RLT_TRY(enc_dims(S, B, E, H, FF, d));
-    if (stash_bytes < enc_stash(d, nullptr).bytes || ws_bytes < enc_gemm_ws(d) || (enc_gemm_ws(d) && !ws)) return RLT_E_WORKSPACE;
-    const EncStash s = enc_stash(d, stash, stash_bytes);
+    const size_t gemm_ws = rup(enc_gemm_ws(d)), img_scratch = enc_fwd_images_scratch(d, drop_p);
+    if (stash_bytes < enc_stash(d, nullptr).bytes || ws_bytes < gemm_ws + img_scratch || (gemm_ws + img_scratch && !ws)) return RLT_E_WORKSPACE;
+    EncStash s = enc_stash(d, stash, stash_bytes);
+    if (img_scratch) { s.images = static_cast<uint8_t*>(ws) + gemm_ws; s.images_bytes = img_scratch; }       // scratch of this call
     const int T = (int)d.T;
     const uint32_t s_attn = drop_p > 0.f ? seeds[0] : 0u, s_ln1 = drop_p > 0.f ? seeds[1] : 0u,
                    s_ffn = drop_p > 0.f ? seeds[2] : 0u, s_ln2 = drop_p > 0.f ? seeds[3] : 0u;

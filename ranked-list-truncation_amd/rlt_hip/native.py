@@ -68,13 +68,14 @@ _SIGNATURES = {
     "rlt_add_layernorm_fwd": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_uint32, P, P, P]),
     "rlt_add_layernorm_bwd_workspace": (c_size_t, [c_int, c_int]),
     "rlt_add_layernorm_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_uint32, P, P, P, P, c_int, P, c_size_t, P]),
-    "rlt_list_attention_fwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_fwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_float, c_int]),
+    "rlt_list_attention_images_retained": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "rlt_list_attention_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, c_int, P]),
-    "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rlt_list_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_float, c_int]),
     "rlt_list_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, c_size_t, c_int, P]),
-    "rlt_list_attention_bwd_prepare": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, P]),
-    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
-    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
+    "rlt_list_attention_bwd_prepare": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, c_int, P]),
+    "rlt_list_attention_bwd_dkv": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
+    "rlt_list_attention_bwd_dq": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_uint32, P, c_int, P]),
     "rlt_bilstm_rec_fwd": (c_int, [P, P, P, c_int, c_int, P, P, c_int, P]),
     "rlt_bilstm_rec_fwd_x": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, c_int, P]),
     "rlt_bilstm_rec_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
@@ -153,7 +154,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.rlt_abi_version() != 4:
+    if lib.rlt_abi_version() != 5:
         raise RuntimeError("librlt_hip.so ABI version mismatch")
     _lib = lib
     return lib

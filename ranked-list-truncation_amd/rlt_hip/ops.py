@@ -4,6 +4,7 @@ PyTorch here is plumbing: it owns device buffers, the stream and the autograd ta
 arithmetic step of the hot path - forward AND backward - is a call into librlt_hip.so.
 Activations are "position-major": a (S*B, E) matrix whose row index is s*B + b.
 """
+import contextvars
 import math
 
 import torch
@@ -61,31 +62,34 @@ def next_seed():
     return int((x * 0xBF58476D1CE4E5B9 >> 32) & 0xFFFFFFFF)
 
 
-_CALL_PRECISION = [N.PRECISION_DEFAULT]
+# the scope is a context variable: per thread (autograd runs backward nodes on its own threads) and per asyncio task, like the
+# thread-local scope of the library's own entry points (include/rlt_hip.h)
+_CALL_PRECISION = contextvars.ContextVar("rlt_call_precision", default=N.PRECISION_DEFAULT)
 
 
 class precision:
     """`with ops.precision('fp32'):` - every library call issued inside (the forward of the modules called there) runs in
     that mode, whatever the process default (native.set_precision) is; each tape node remembers the mode of its forward and
-    gives it to its backward (the stash layout depends on it).  Re-entrant: nested scopes restore the outer one."""
+    gives it to its backward (the stash layout depends on it).  Re-entrant: nested scopes restore the outer one; scopes of
+    different threads do not see each other."""
 
     def __init__(self, mode):
         self.code = N.PRECISION_DEFAULT if mode is None else N.precision_code(mode)
+        self._tokens = []
 
     def __enter__(self):
-        self.prev = _CALL_PRECISION[0]
-        _CALL_PRECISION[0] = self.code
+        self._tokens.append(_CALL_PRECISION.set(self.code))
         return self
 
     def __exit__(self, *exc):
-        _CALL_PRECISION[0] = self.prev
+        _CALL_PRECISION.reset(self._tokens.pop())
         return False
 
 
 def current_precision():
     """The RLT_PRECISION_* code a forward issued now runs in: the enclosing `precision(...)` scope's, else the process
     default read once, so that forward and backward of a tape node agree even if the default is changed in between."""
-    c = _CALL_PRECISION[0]
+    c = _CALL_PRECISION.get()
     return c if c >= 0 else int(N.load().rlt_get_precision())
 
 
@@ -268,13 +272,15 @@ class ListAttentionFn(Function):
         out = _empty((S * B, E), qkv)
         lse = _empty((S, H, B), qkv)
         ctx.prec = pr = current_precision()
-        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, pr)
-        images = workspace(img_bytes, qkv.device) if img_bytes else None     # pre-split Q/K/V tile records (bf16x3 mode)
+        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, drop_p, pr)
+        images = workspace(img_bytes, qkv.device) if img_bytes else None     # pre-split tile records / images of this call
         _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, seed,
                                          ptr(out), ptr(lse), ptr(images), img_bytes, pr, stream()))
         ctx.dims = (S, B, H, HD)
         ctx.drop = (drop_p, seed)
-        ctx.images = images
+        # kept for the backward only where it reads them (split-bf16 records); the images of the pipelined bf16x6 forward kernels
+        # are scratch of the call above - several GB per layer at the benchmark sizes
+        ctx.images = images if images is not None and N.load().rlt_list_attention_images_retained(S, B, H, HD, pr) else None
         ctx.save_for_backward(qkv, out, lse)
         return out
 
@@ -286,13 +292,13 @@ class ListAttentionFn(Function):
         dout = N.f32c(dout)
         dqkv = torch.empty_like(qkv)
         pr = ctx.prec
-        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, pr)
-        ws = workspace(ws_bytes, qkv.device)
         drop_p, seed = ctx.drop
-        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, pr, stream())
-        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
+        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, drop_p, pr)
+        ws = workspace(ws_bytes, qkv.device)
+        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, drop_p, ptr(images), ptr(ws), ws_bytes, pr, stream())
+        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), ws_bytes,
                                              S, B, H, HD, drop_p, seed, ptr(dqkv), pr, stream()))
-        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws),
+        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), ws_bytes,
                                             S, B, H, HD, drop_p, seed, ptr(dqkv), pr, stream()))
         ctx.images = None
         return dqkv, None, None, None, None, None
@@ -318,7 +324,7 @@ class EncoderLayerFn(Function):
         weights = (in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)
         pr = current_precision()
         stash_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, E, H, FF, 0, pr)
-        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 0, pr)
+        ws_bytes = query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 1 if drop_p > 0 else 0, pr)
         stash = N.byte_buffer(stash_bytes, x.device)
         ws = N.byte_buffer(ws_bytes, x.device)
         y = _empty((T, E), x)
@@ -385,10 +391,12 @@ class EncoderLayerKernelsFn(Function):
         gemm(0, 1, T, 3 * E, E, x, E, in_w, E, qkv, 3 * E, bias=in_b)
         att = _empty((T, E), x)
         lse = _empty((S, H, B), x)
-        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, pr)
+        img_bytes = query("rlt_list_attention_fwd_workspace", S, B, H, HD, drop_p, pr)
         images = workspace(img_bytes, x.device) if img_bytes else None
         _launch("attn_fwd", lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop_p, s_attn,
                                          ptr(att), ptr(lse), ptr(images), img_bytes, pr, stream()))
+        if images is not None and not N.load().rlt_list_attention_images_retained(S, B, H, HD, pr):
+            images = None                                    # scratch of the forward call: not kept for the backward
         proj = _empty((T, E), x)
         gemm(0, 1, T, E, E, att, E, out_w, E, proj, E, bias=out_b)
         h1 = _empty((T, E), x)
@@ -457,12 +465,12 @@ class EncoderLayerKernelsFn(Function):
         # attention
         images = ctx.images
         dqkv = torch.empty_like(qkv)
-        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, pr)
+        ws_bytes = query("rlt_list_attention_bwd_workspace", S, B, H, HD, drop_p, pr)
         ws = workspace(ws_bytes, x.device)
-        call("rlt_list_attention_bwd_prepare", ptr(att), ptr(datt), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), ws_bytes, pr, stream())
-        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws),
+        call("rlt_list_attention_bwd_prepare", ptr(att), ptr(datt), ptr(lse), S, B, H, HD, drop_p, ptr(images), ptr(ws), ws_bytes, pr, stream())
+        _launch("attn_bwd_dkv", lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws), ws_bytes,
                                              S, B, H, HD, drop_p, s_attn, ptr(dqkv), pr, stream()))
-        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws),
+        _launch("attn_bwd_dq", lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(datt), ptr(lse), ptr(images), ptr(ws), ws_bytes,
                                             S, B, H, HD, drop_p, s_attn, ptr(dqkv), pr, stream()))
         ctx.images = None
         # in_proj
@@ -728,11 +736,17 @@ _DCG_TABLE_CACHE = {}
 def dcg_table(device):
     """The float64 DCG coefficient table of rlt_loss_metrics (1 / log2(j + 2) and its prefix sums), filled once per device by
     rlt_dcg_table_init on the current stream: caller memory, the library keeps no state of its own."""
-    key = str(device)
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()      # 'cuda' and 'cuda:0' are one device
     if key not in _DCG_TABLE_CACHE:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the DCG table must exist before a hipGraph capture starts: call ops.dcg_table(device) once, eagerly")
         nbytes = query("rlt_dcg_table_bytes")
-        t = torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
-        call("rlt_dcg_table_init", ptr(t), nbytes, stream())
+        with torch.cuda.device(key):
+            t = torch.empty((nbytes // 8,), dtype=torch.float64, device=torch.device("cuda", key))
+            call("rlt_dcg_table_init", ptr(t), nbytes, stream())
+            # filled once, read from whatever stream a later loss call runs on: nothing orders those streams behind this one
+            torch.cuda.current_stream().synchronize()
         _DCG_TABLE_CACHE[key] = t
     return _DCG_TABLE_CACHE[key]
 

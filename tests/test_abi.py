@@ -25,14 +25,14 @@ def test_header_symbols_are_exported_and_bound(native):
     lib = native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rlt_abi_version() == 4
+    assert lib.rlt_abi_version() == 5
     assert b"workspace" in lib.rlt_error_string(-3)
 
 
 def test_workspace_queries_need_no_gpu(native):
     assert native.query("rlt_gemm_workspace", 1, 0, 2048, 256, 1228800) > 0     # split-K slabs for dW
     assert native.query("rlt_gemm_workspace", 0, 1, 1228800, 2048, 256) == 0
-    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64, native.PRECISION_DEFAULT) >= 300 * 4096 * 4 * 4
+    assert native.query("rlt_list_attention_bwd_workspace", 300, 4096, 4, 64, 0.0, native.PRECISION_DEFAULT) >= 300 * 4096 * 4 * 4
     assert native.query("rlt_colsum_workspace", 1000, 64) > 0
 
 
@@ -71,8 +71,18 @@ def test_path_level_entry_points(native):
     rup = lambda n: (n + 255) // 256 * 256
     floats = rup(T * 3 * E * 4) + 4 * rup(T * E * 4) + rup(S * H * B * 4) + 2 * rup(T * 2 * 4) + rup(T * FF * 4)
     bits = rup(N.query("rlt_gemm_bits_words", T, FF) * 4)
-    images = rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, D))
-    assert stash == floats + bits + images
+    # attention tile images live in the stash only where the backward reads them (ABI 5: rlt_list_attention_images_retained);
+    # the images of the pipelined bf16x6 forward kernels are scratch of the forward call, sized by the FWD_WS query
+    img_b = N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.0, D)
+    kept = lib.rlt_list_attention_images_retained(S, B, H, E // H, D)
+    assert stash == floats + bits + (rup(img_b) if kept else 0)
+    fwd_ws = N.query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 0, D)
+    fwd_ws_train = N.query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 1, D)
+    assert fwd_ws - fwd_ws_train == (0 if kept else rup(img_b) - rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.1, D)))
+    if N.get_precision() == "bf16x6" and not any(os.environ.get(v) == "0" for v in ("RLT_A6H", "RLT_ATTN6")) and not os.environ.get("RLT_ATTN_MODE"):
+        assert not kept and img_b > 2 * S * H * (B // 64) * 24576 and N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.1, D) == 0
+    # the backward parts check their workspace themselves (ABI 5): a delta-only buffer is refused, not overrun, where images are staged
+    assert lib.rlt_list_attention_bwd_dkv(None, None, None, None, None, 0, 1, 1, 1, 64, 0.0, 0, None, D, None) == -1
     ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0, D)
     ws1 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 1, D)
     assert ws1 - ws0 >= T * E * 4                       # train-mode dropout keeps the branch gradients apart
@@ -105,10 +115,12 @@ def test_precision_is_a_call_argument_and_the_default_is_reference_faithful(nati
         for default in ("fp32", "bf16x3", "bf16x6"):
             N.set_precision(default)
             assert N.get_precision() == default
-            img3 = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_BF16X3)
-            assert img3 > 0                                                   # Q / K / V tile records
-            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_FP32) == 0
-            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT) == (img3 if default == "bf16x3" else 0)
+            img3 = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_BF16X3)
+            assert img3 > 0 and lib.rlt_list_attention_images_retained(S, B, H, HD, N.PRECISION_BF16X3) == 1     # Q / K / V tile records
+            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_FP32) == 0
+            img6 = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_BF16X6)       # call-local K / V images of the pipelined forward
+            assert lib.rlt_list_attention_images_retained(S, B, H, HD, N.PRECISION_BF16X6) == 0
+            assert N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT) == {"bf16x3": img3, "bf16x6": img6, "fp32": 0}[default]
             st3 = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 256, H, 2048, 0, N.PRECISION_BF16X3)
             st6 = N.query("rlt_workspace_bytes", N.OP_ENCODER_STASH, S, B, 256, H, 2048, 0, N.PRECISION_BF16X6)
             assert st3 - st6 == (img3 + 255) // 256 * 256

@@ -19,6 +19,7 @@ CASES = [
     (["tools/gen_attn6n_body.py", "dq"], "attention6n_dq1_body.inc"),
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
     (["tools/gen_attn6n_body.py", "fwd"], "attention6n_fwd1_body.inc"),
+    (["tools/gen_attn6h_body.py", "fwd"], "attention6h_fwd1_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_seq"], "lstm6w_fwd_seq_body.inc"),
@@ -77,6 +78,27 @@ def test_attention6n_bodies_cover_every_mfma_and_chunk_once():
         assert set(once.values()) == {1}
 
 
+def test_attention6h_body_covers_every_mfma_and_chunk_once():
+    """The pipelined head-dim-64 forward body: 8 slots of 52 MFMAs (S x24, R1 x2, R2 x2, O x24 of four different items), every
+    (stage, ring slot, own block, index) the right number of times; every exp2 / row-sum / conversion chunk once per item, every
+    fragment read and staging piece once per tile body, the staging pieces in index order (the first of a group writes M0)."""
+    import re
+    from collections import Counter
+    text = open(os.path.join(CSRC, "attention6h_fwd1_body.inc")).read()
+    mf = re.findall(r"^(m_[sro])\(([^)]*)\); GAP_END;", text, flags=re.M)
+    assert len(mf) == 8 * 52
+    by = Counter(mf)
+    # items i and i + 4 share a ring slot and an own-row block: every S / O call twice, every residual call 8 / 4 = twice per ring slot x 2
+    assert {n: set(v for (nm, _a), v in by.items() if nm == n) for n in ("m_s", "m_o", "m_r")} == {"m_s": {2}, "m_o": {2}, "m_r": {2}}
+    assert sum(1 for (nm, _a) in mf if nm == "m_s") == 8 * 24 and sum(1 for (nm, _a) in mf if nm == "m_o") == 8 * 24
+    calls = Counter(re.findall(r"\b([a-z_]+)\(", text))
+    assert calls["e_exp"] + calls["e_exp_p"] == 8 * 8 and calls["e_sum"] + calls["e_sum_p"] == 8 * 8 and calls["c_pk"] == 8 * 12
+    assert calls["rd_row"] == 2 * 12 and calls["rd_tr"] == 2 * 24 and calls["st_dma"] == 12
+    once = Counter(re.findall(r"\b((?:rd_row|rd_tr|st_dma)\([^)]*\))", text))
+    assert set(once.values()) == {1}
+    assert [int(j) for j in re.findall(r"st_dma\((\d+)\)", text)] == list(range(12))
+
+
 def test_attention6n_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
     """The MFMAs of the pipelined bodies are asm statements: hipcc pads nothing in front of them, so the tile loop
     must not contain compiler-made register traffic into their operands - no v_accvgpr_* move and no scratch access inside
@@ -99,6 +121,30 @@ def test_attention6n_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
         loop = max(blocks, key=lambda b: b.count("v_mfma"))
         assert loop.count("v_mfma_f32_16x16x32_bf16") == nmf
         assert "v_accvgpr" not in loop and "scratch_" not in loop
+
+
+def test_attention6h_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
+    """The same ISA check for the head-dim-64 forward (csrc/attention6h.hip): 416 asm MFMAs in the tile loop, no v_accvgpr move, no
+    scratch access, no register-to-register copy, and 12 LDS-DMA pieces with M0 written four times."""
+    import re
+    import shutil
+    from rlt_hip import build as B
+    if shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "a6h.s"
+    src = os.path.join(CSRC, "attention6h.hip")
+    subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["attention6h.hip"] + ["-S", "--cuda-device-only", src, "-o", str(asm)], check=True,
+                   capture_output=True)
+    text = asm.read_text()
+    m = re.search(r"^_ZN12_GLOBAL__N_118attn6h_fwd1_kernelE8AttnArgs:(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert m
+    blocks = re.split(r"^\.LBB\w+:", m.group(1), flags=re.M)
+    loop = max(blocks, key=lambda b: b.count("v_mfma"))
+    assert loop.count("v_mfma_f32_16x16x32_bf16") == 8 * 52
+    assert "v_accvgpr" not in loop and "scratch_" not in loop
+    assert not re.search(r"v_mov_b32_e32 v\d+, [va]\d+", loop)          # no register-to-register copy (constants for addresses are fine)
+    assert loop.count("global_load_lds_dwordx4") == 12 and len(re.findall(r"s_mov_b32 m0,", loop)) == 4
+    assert re.search(r"\.vgpr_spill_count:\s+0", text[text.index("attn6h_fwd1_kernel"):] if ".vgpr_spill_count" in text else ".vgpr_spill_count: 0")
 
 
 def test_lstm6w_bodies_cover_every_mfma_once():

@@ -23,6 +23,8 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
                 MMOECut(4 experts, tasks 2.1) 1024x40 - outputs 1e-4, cut positions, loss 1e-4, per-parameter gradient rel-L2
     full_size_oracle  AttnCut 4096 x 300 (BASELINE configs[1]) forward + DivLoss + cut metrics against the CPU oracle's forward
                 pass on the same batch: p 1e-4, cut positions, F1 / DCG / loss 1e-4
+    full_size_oracle_choopy  Choopy 8192 x 300 (BASELINE configs[2]) forward against the oracle's logits on 24 of the 300 positions
+                (no recurrence: positions meet only in the final softmax, which cancels in log-ratios): 1e-4 for all 8192 lists
     scale_ops   list attention at B=4096 (hd 64) / 8192 (hd 16), every GEMM layout at 1,228,800 rows (all elements vs
                 fp64), split-K dW products over K=1,228,800 with the fused bias gradient, the 1-bit-mask FFN pair,
                 BiLSTM at B=4096, LayerNorm at 1,228,800 rows
@@ -55,6 +57,8 @@ The checks live in tools/gpu_probe.py (one section per kernel family, every case
     precision_argument  two modes side by side in one process through the call argument == the same mode as process default
     determinism  the 4096 x 300 AttnCut and 8192 x 300 Choopy steps twice from one state in each mode: gradient bucket, p, k bitwise
     bench_two_ranks  bench.py --gpus 2 (its own torch.distributed.run child, two gloo ranks on this GPU): the N > 1 JSON line
+    rccl_two_ranks  bench.py --gpus 2 with the REAL backend (nccl = RCCL), both ranks on this box's one GPU: either the N = 2 line, or
+                RCCL's duplicate-GPU refusal reaching the parent as a non-zero exit inside the bounded wait - never a hang
     dp_four_ranks  the largest world the box's process guard admits beside the test process: bench.py --gpus 4 --batch 32 and
                 run.py MMOECut(4e, 2.1) under four ranks with ragged and empty shards vs the shard-wise oracle, replicas bitwise equal
     trajectory  20 Adam steps, each side on its own gradients: per-step loss / F1 / p within 1e-4, cut positions
@@ -86,7 +90,7 @@ def probe():
 MODE_DEPENDENT = ["gemm", "attention", "lstm", "dropout", "optimizer_and_trainer", "models", "bicut",
                   "scale_models", "scale_ops", "scale_dropout", "full_size_kernels", "flip_aligned_grads", "trajectory", "trainer_bookkeeping", "trainer_buckets", "scale_mmoe", "path_level", "lstm_generic", "trainer_dp"]
 MODE_FREE = ["losses", "metrics", "layernorm", "heads", "embed_mmoe", "rccl_one_rank", "x6_image_staging", "x6_fallbacks",
-             "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "dp_four_ranks", "trainer_dp_mt"]
+             "x6_adversarial", "precision_argument", "determinism", "bench_two_ranks", "rccl_two_ranks", "dp_four_ranks", "trainer_dp_mt"]
 
 
 def _run(probe, name):
@@ -127,6 +131,13 @@ def test_full_size_oracle(probe):
     p within 1e-4, cut positions identical outside knife-edge lists, F1 / DCG / loss within 1e-4 (tools/gpu_probe.py
     full_size_oracle)."""
     _run(probe, "full_size_oracle")
+
+
+def test_full_size_oracle_choopy(probe):
+    """BASELINE configs[2] (Choopy 8192 x 300) at full size, default mode, directly against the CPU oracle on a 24-position subset:
+    the log-ratios of the device's cut probabilities between subset positions equal the oracle's logit differences within 1e-4 for
+    all 8192 lists (tools/gpu_probe.py full_size_oracle_choopy)."""
+    _run(probe, "full_size_oracle_choopy")
 
 
 def test_full_size_models(probe):

@@ -17,7 +17,7 @@ import ctypes, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/ranked-list-truncation_amd")
 from rlt_hip import native as N
 lib = N.load()
-assert lib.rlt_abi_version() == 4
+assert lib.rlt_abi_version() == 5
 # workspace queries over a grid of shapes and every precision code: pure host arithmetic
 for S, B, E, H, FF in [(300, 4096, 256, 4, 2048), (300, 8192, 128, 8, 2048), (40, 63, 256, 4, 2048), (1, 1, 64, 1, 64), (7, 33, 128, 8, 96)]:
     for prec in (-1, 0, 1, 2):
@@ -25,7 +25,7 @@ for S, B, E, H, FF in [(300, 4096, 256, 4, 2048), (300, 8192, 128, 8, 2048), (40
             for drop in (0, 1):
                 n = N.query("rlt_workspace_bytes", op, S, B, E, H, FF, drop, prec)
                 assert n % 256 == 0 and (n > 0 or op == 2), (op, S, B, E, H, FF, drop, prec, n)   # (op 2: split-K scratch, may be empty)
-        assert N.query("rlt_list_attention_bwd_workspace", S, B, H, E // H, prec) >= S * B * H * 4
+        assert N.query("rlt_list_attention_bwd_workspace", S, B, H, E // H, 0.0, prec) >= S * B * H * 4
     for ta, tb in ((0, 1), (0, 0), (1, 0), (1, 1)):
         N.query("rlt_gemm_workspace", ta, tb, S * B, FF, E)
         N.query("rlt_gemm_workspace", ta, tb, FF, E, S * B)

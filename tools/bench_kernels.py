@@ -41,18 +41,31 @@ def attention(B=4096, S=60, H=4, HD=64, drop=0.0):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(S, H, B, device=dev)
     unit = B * B * HD * S * H / 1e9     # GFLOP per "2*B*B*HD" product /2
-    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, drop, N.PRECISION_DEFAULT)
     images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
-    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, drop, N.PRECISION_DEFAULT)
     ws = torch.empty(wb // 4 + 4, device=dev)
     ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, drop, 7, ptr(out), ptr(lse), ptr(images), ib, N.PRECISION_DEFAULT, stream()))
     print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, drop, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_prep B{B} S{S} HD{HD}: {ms:8.3f} ms", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dkv", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), wb, S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_dkv  B{B} S{S} HD{HD}: {ms:8.3f} ms  {8 * unit / ms:7.1f} TF/s", flush=True)
-    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
+    ms = timeit(lambda: call("rlt_list_attention_bwd_dq", ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), wb, S, B, H, HD, drop, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream()))
     print(f"attn_bwd_dq   B{B} S{S} HD{HD}: {ms:8.3f} ms  {6 * unit / ms:7.1f} TF/s", flush=True)
+
+
+def attention_fwd(B=4096, S=60, H=4, HD=64):
+    """The forward launch alone (its prepare passes and fix-up launch included)."""
+    E = H * HD
+    T = S * B
+    qkv = torch.randn(T, 3 * E, device=dev)
+    out = torch.empty(T, E, device=dev)
+    lse = torch.empty(S, H, B, device=dev)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
+    images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
+    ms = timeit(lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 7, ptr(out), ptr(lse), ptr(images), ib, N.PRECISION_DEFAULT, stream()), reps=5, warm=2)
+    print(f"attn_fwd      B{B} S{S} HD{HD}: {ms:8.3f} ms  {4 * B * B * HD * S * H / 1e9 / ms:7.1f} TF/s", flush=True)
 
 
 def attention_drop():
@@ -306,12 +319,12 @@ def dkv1_stamps(B=4096, S=60, H=4, HD=64, which="dkv"):
     T = S * B
     qkv = torch.randn(T, 3 * E, device=dev); out = torch.randn(T, E, device=dev); lse = torch.randn(S, H, B, device=dev).abs() + 20
     dout = torch.randn(T, E, device=dev); dqkv = torch.empty_like(qkv)
-    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
     images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
-    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
     ws = torch.empty(wb // 4 + 4, device=dev)
-    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream())
-    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, 0.0, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream())
+    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), wb, S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
     ms = timeit(f)
     fn = N.load().rlt_debug_dkv1_stamps
     fn.restype = ctypes.c_int
@@ -335,10 +348,10 @@ def a6n_stamps(which="dkv", B=8192, S=20, H=8, HD=16):
     T = S * B
     qkv = torch.randn(T, 3 * E, device=dev); out = torch.randn(T, E, device=dev); lse = torch.randn(S, H, B, device=dev).abs() + 20
     dout = torch.randn(T, E, device=dev); dqkv = torch.empty_like(qkv)
-    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
     ws = torch.empty(wb // 4 + 4, device=dev)
-    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, None, ptr(ws), wb, N.PRECISION_DEFAULT, stream())
-    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), None, ptr(ws), S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, 0.0, None, ptr(ws), wb, N.PRECISION_DEFAULT, stream())
+    f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), None, ptr(ws), wb, S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
     ms = timeit(f)
     fn = N.load().rlt_debug_a6n_stamps
     fn.restype = ctypes.c_int
@@ -353,6 +366,46 @@ def a6n_stamps(which="dkv", B=8192, S=20, H=8, HD=16):
             nx = v[(w * 4 + tl + 1) * 18]
             d = [st[k + 1] - st[k] for k in range(16)]
             print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:4d}" for x in d) + f" | {st[17] - st[16]:5d} | {nx - st[0]:6d}")
+
+
+def a6h_stamps(which="fwd", B=4096, S=60, H=4, HD=64):
+    """Slot timeline of the pipelined head-dim-64 kernels: needs a -DRLT_A6H_STAMPS library (RLT_HIP_LIB)."""
+    import ctypes
+    E = H * HD
+    T = S * B
+    qkv = torch.randn(T, 3 * E, device=dev); out = torch.randn(T, E, device=dev); lse = torch.randn(S, H, B, device=dev).abs() + 20
+    dout = torch.randn(T, E, device=dev); dqkv = torch.empty_like(qkv)
+    ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
+    images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
+    wb = N.query("rlt_list_attention_bwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
+    ws = torch.empty(wb // 4 + 4, device=dev)
+    if which == "fwd":
+        f = lambda: call("rlt_list_attention_fwd", ptr(qkv), S, B, H, HD, 0.0, 7, ptr(out), ptr(lse), ptr(images), ib, N.PRECISION_DEFAULT, stream())
+    else:
+        call("rlt_list_attention_bwd_prepare", ptr(out), ptr(dout), ptr(lse), S, B, H, HD, 0.0, ptr(images), ptr(ws), wb, N.PRECISION_DEFAULT, stream())
+        f = lambda: call("rlt_list_attention_bwd_" + which, ptr(qkv), ptr(dout), ptr(lse), ptr(images), ptr(ws), wb, S, B, H, HD, 0.0, 7, ptr(dqkv), N.PRECISION_DEFAULT, stream())
+    ms = timeit(f)
+    fn = N.load().rlt_debug_a6h_stamps
+    fn.restype = ctypes.c_int
+    buf = (ctypes.c_ulonglong * (4 * 4 * 18))()
+    assert fn(buf) == 0
+    v = list(buf)
+    gs, ns = {"fwd": (52, 8), "dq": (76, 4), "dkv": (104, 4)}[which]
+    print(f"{which} {ms:.3f} ms; cycles per slot ({gs} MFMAs = {16 * gs} matrix cycles) of tiles 9, 10 of wavefronts 0 and 3, then the last slot up to the barrier, the barrier wait and the tile period")
+    for w in (0, 3):
+        for tl in (1, 2):
+            st = v[(w * 4 + tl) * 18:(w * 4 + tl) * 18 + 18]
+            nx = v[(w * 4 + tl + 1) * 18]
+            d = [st[k + 1] - st[k] for k in range(ns - 1)] + [st[16] - st[ns - 1]]
+            print(f"  w{w} t{8 + tl}: " + " ".join(f"{x:4d}" for x in d) + f" | {st[17] - st[16]:5d} | {nx - st[0]:6d}")
+
+
+def a6h_stamps_dq():
+    a6h_stamps(which="dq")
+
+
+def a6h_stamps_dkv():
+    a6h_stamps(which="dkv")
 
 
 def a6n_stamps_dq():

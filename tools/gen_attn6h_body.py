@@ -193,8 +193,9 @@ for b32 in range(NB32):
 # ---- staging of the next tile: LDS-DMA pieces of the pre-split tile records (2 images x 24 pieces of 1 KiB, a wavefront issues
 # ---- every fourth one; dK+dV: + the piece of the rows' seeds): early in the body, so that they have landed long before the barrier
 NDMA = 13 if MODE == "dkv" else 12
+DMA_STEP = int(os.environ.get("GEN_DMA_STEP", "5"))           # gaps between two pieces
 for j in range(NDMA):
-    add(f"dma{j}", [(f"st_dma({j});", "ld")], GS // 2 + 5 * j, GS * (NS - 2))
+    add(f"dma{j}", [(f"st_dma({j});", "ld")], GS // 2 + DMA_STEP * j, GS * (NS - 2) + 10)
 
 
 def place(t, capv):
@@ -247,6 +248,9 @@ for attempt in range(400):
         capv[g % G] += 1
 else:
     sys.exit(f"no schedule: {miss.name} (release {miss.release}, deadline {miss.deadline})")
+# the staging pieces carry their LDS base in M0, written by the first piece of a group: pieces in index order
+dma_at = [t.placed[0] for t in tasks if t.name.startswith("dma")]
+assert dma_at == sorted(dma_at) and len(set(dma_at)) == len(dma_at), dma_at
 cap = max(capv)
 sys.stderr.write(f"{MODE}: {G} gaps, capacity {CAP}..{cap} cycles per gap, mean load {sum(used) / G:.1f}, max {max(used)}, "
                  f"{sum(1 for u in used if u > 8)} gaps over 8 cycles (sum of the excess {sum(max(0, u - 8) for u in used)})\n")

@@ -848,8 +848,8 @@ def scale_models():
     BASELINE.json states; observed ~1e-6), identical cut positions except lists whose two best positions are closer
     than 4e-6 in the oracle's own output (reported), loss 1e-4, and per-parameter gradient relative L2 within
     1e-3 (bf16x3) / 2e-4 (exact fp32) of the oracle's - about 10x what is observed - with the oracle's encoder layers
-    following the device's ReLU branch on the (counted) knife-edge units (flip_aligned_grads explains why); the
-    un-aligned figure is printed beside it."""
+    following the device's ReLU branch on the (counted) knife-edge units (flip_aligned_grads explains why); in the default bf16x6
+    mode the un-aligned figure is asserted too (worst 1.2e-3, median 1.5e-4: 10x the observed values)."""
     import models as hm
     from oracle import losses as ol, metrics as omet, models as om
     from oracle.cases import make_criterion
@@ -878,10 +878,10 @@ def scale_models():
         loss_h = make_criterion(hl, cname, case)(out_h, y.to(dev))
         loss_h.backward()
         # un-aligned oracle first: its outputs, loss and cut positions are THE reference; its gradients the printed
-        # diagnostic (bf16x3 and the default bf16x6 mode: the second oracle backward doubles the CPU time of the section, the
-        # exact-fp32 mode goes without)
+        # un-aligned figure, asserted with a bound of its own in the default bf16x6 mode (the second oracle backward doubles the CPU
+        # time of the section: the other two modes go without)
         plain = None
-        if bf or N.get_precision() == "bf16x6":
+        if N.get_precision() == "bf16x6":
             out_r = ref(x)
             loss_r = make_criterion(ol, cname, case)(out_r, y)
             loss_r.backward()
@@ -923,7 +923,12 @@ def scale_models():
         diag = ""
         if plain is not None:
             wp = max(plain, key=plain.get)
-            diag = f"un-aligned worst rel-L2 {plain[wp]:.2e} ({wp}), median {sorted(plain.values())[len(plain) // 2]:.2e}; "
+            pmed = sorted(plain.values())[len(plain) // 2]
+            diag = f"un-aligned worst rel-L2 {plain[wp]:.2e} ({wp}), median {pmed:.2e}; "
+            # against the oracle's OWN ReLU decisions (no alignment): the knife-edge units add their whole gradient to the difference,
+            # so the bound is ~10x what round 5 observed (worst 1.1e-4 - the narrow bias_ih_l0 of the BiLSTM -, median up to 1.5e-5)
+            report(f"{tag} grad rel-L2 worst, un-aligned ({wp})", plain[wp], 1.2e-3)
+            report(f"{tag} grad rel-L2 median, un-aligned", pmed, 1.5e-4)
         print(f"   ({tag}: {counts[0]} of {counts[2]} FFN units aligned; {diag}oracle {t_cpu:.1f}s, total {time.time() - t0:.1f}s)", flush=True)
         del hip, out_h, loss_h, nodes
         torch.cuda.empty_cache()
@@ -1442,6 +1447,66 @@ def full_size_oracle():
           f"F1 {float(f1_h):.6f} / {f1_r:.6f}, DCG {float(dcg_h):.5f} / {dcg_r:.5f}, loss {float(loss_h):.6e} / {float(loss_r):.6e})", flush=True)
     del hip, p_h
     torch.cuda.empty_cache()
+
+
+@section
+def full_size_oracle_choopy():
+    """BASELINE configs[2] AT FULL SIZE against the oracle, directly: Choopy forward on the 8192 x 300 batch (HIP,
+    the process's precision mode) against the CPU oracle on a SUBSET of 24 positions of the same batch.  Choopy has no recurrence: the
+    position-encoded rows of one position pass through the three encoder layers (list-axis attention, FFN, norms) and the decision
+    Linear without meeting another position (reference models/Choopy.py:19-22) - only the final softmax over
+    the 300 positions couples them, and it cancels in log p[:, s] - log p[:, s'] = z_s - z_s'.  So the oracle's logits on 24 positions
+    (2 positions per chunk: two 8192 x 8192 score matrices per head at a time) pin the device's probabilities on those positions for
+    all 8192 lists: | (log p_s - log p_s0) - (z_s - z_s0) | <= 1e-4 for every list and subset position."""
+    import bench
+    import models as hm
+    from oracle import models as om
+    from oracle.weights import fill_state_dict
+    Bq, S = 8192, 300
+    t0 = time.time()
+    xg, _yg = bench.synth_batch(Bq, S, 1, 20241, dev)
+    ref = om.Choopy(seq_len=S, dropout=0.0)
+    fill_state_dict(ref, 56)
+    hip = hm.Choopy(seq_len=S, dropout=0.0)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    hip.train()
+    with torch.no_grad():
+        p_h = hip(xg).squeeze(2).double().cpu()
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    del hip
+    torch.cuda.empty_cache()
+    try:
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    except AttributeError:
+        pass
+    pos = sorted(set([0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 299] + list(range(17, 300, 29))))[:24]
+    x = xg.cpu()
+    ref.train()
+    t0 = time.time()
+    zs = []
+    with torch.no_grad():
+        for i in range(0, len(pos), 2):
+            pp = pos[i:i + 2]
+            h = torch.cat((x[:, pp], ref.position_encoding[pp].expand(Bq, len(pp), 127)), dim=2)
+            h = ref.attention_layer(h)
+            zs.append(ref.decison_layer[0](h).squeeze(2).double())       # the Linear of the softmax head: logits
+    z = torch.cat(zs, dim=1)                                             # (B, 24)
+    t_cpu = time.time() - t0
+    lp = torch.log(p_h[:, pos])
+    live = torch.isfinite(lp).all(dim=1)
+    d = (lp - lp[:, :1]) - (z - z[:, :1])
+    report(f"full_size_oracle_choopy b8192_s300: lists with finite log p on the {len(pos)} positions", float((~live).sum()), 0)
+    report("full_size_oracle_choopy b8192_s300 max | (log p_s - log p_s0) - (z_s - z_s0) | over all lists", float(d[live].abs().max()), 1e-4)
+    # the same on the probabilities renormalised over the subset (what a softmax over these 24 positions alone would give)
+    q_h = p_h[:, pos] / p_h[:, pos].sum(1, keepdim=True)
+    q_r = torch.softmax(z, dim=1)
+    report("full_size_oracle_choopy b8192_s300 max |dq| on the subset-renormalised probabilities", float((q_h - q_r).abs().max()), 1e-4)
+    report("full_size_oracle_choopy b8192_s300 arg max over the subset, lists that differ outside knife edges (gap >= 4e-6)",
+           float(((q_h.argmax(1) != q_r.argmax(1)) & ((torch.topk(q_r, 2, dim=1).values[:, 0] - torch.topk(q_r, 2, dim=1).values[:, 1]) >= 4e-6)).sum()), 0)
+    print(f"   (full_size_oracle_choopy: HIP {t_hip:.1f} s incl. data, oracle {len(pos)} positions {t_cpu:.1f} s on {torch.get_num_threads()} threads; "
+          f"max |d log-ratio| {float(d[live].abs().max()):.2e})", flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -2300,8 +2365,14 @@ def x6_adversarial():
         # worst-split: asserted like the other classes where the kernels keep the small plane products in an accumulator of their
         # own (list attention at head dim 16, csrc/attention6n.hip); bounded at 10x elsewhere (coherent ROUNDING of the small
         # products into one large running sum: see the docstring)
-        if tag != "worst-split" or (name.startswith("attn") and "hd16" in name):
-            report(f"x6 adversarial {name} {tag}: err_x6 <= 1.25 err_f32mfma + min(sqrt(K) 2^-25, 2 err_f32mfma) + 2^-27", e6, 1.25 * e32 + floor)
+        # (the head-dim-64 FORWARD at 512 lists and more is the two-accumulator kernel of csrc/attention6h.hip: its output is held like head dim 16)
+        two_acc = name.startswith("attn") and ("hd16" in name or (name.endswith(" out") and int(name.split()[1][1:]) >= 512))
+        if tag != "worst-split" or two_acc:
+            bound = 1.25 * e32 + floor
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 1.25 err_f32mfma + min(sqrt(K) 2^-25, 2 err_f32mfma) + 2^-27 "
+                   f"(effective multiple {bound / max(e32, 1e-300):.2f})", e6, bound)
+            # ... and without the random-walk allowance: twice the f32 kernel's own error (+ the 2^-27 of the dropped plane products)
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 2 err_f32mfma + 2^-27 (observed multiple {ratio:.2f})", e6, 2.0 * e32 + 2.0 ** -27)
         elif name.startswith("attn"):
             report(f"x6 adversarial {name} {tag}: err_x6 <= 10 err_f32mfma (coherent class, one accumulator)", e6, 10.0 * e32)
         if apriori:
@@ -2533,6 +2604,46 @@ def _bench_ranks(world, batch, tag):
 def bench_two_ranks():
     _bench_ranks(2, 96, "bench --gpus 2")
 bench_two_ranks.__doc__ = _bench_ranks.__doc__
+
+
+@section
+def rccl_two_ranks():
+    """RCCL with MORE than one rank, once, before the driver's 8-GPU run finds out.  This pool leases one GPU per
+    box, so both ranks of `bench.py --gpus 2 --batch 32` are pointed at cuda:0 (RLT_BENCH_DEVICE=0) over the real backend
+    (RLT_DIST_BACKEND=nccl).  Two outcomes are acceptable: (a) RCCL runs two ranks on one device - then the N = 2 JSON line is checked
+    like bench_two_ranks; (b) RCCL refuses the duplicate GPU - then the point of the test is that bench.py FAILS FAST: every rank
+    exits non-zero with RCCL's own message inside the bounded wait (RLT_DIST_TIMEOUT_S), nothing hangs at a barrier (a hung rank
+    is what would burn the driver's 8-GPU lease)."""
+    import json
+    import subprocess
+    bench_py = os.path.join(REPO, "bench.py")
+    env = dict(os.environ, RLT_DIST_BACKEND="nccl", RLT_BENCH_DEVICE="0", RLT_DIST_TIMEOUT_S="60", NCCL_DEBUG="WARN")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    t0 = time.time()
+    try:
+        res = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--batch", "32", "--steps", "3", "--warmup", "1", "--other-steps", "0",
+                              "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240)
+        rc, out, err, hung = res.returncode, res.stdout, res.stderr, False
+    except subprocess.TimeoutExpired as e:
+        rc, out, err, hung = -9, (e.stdout or b"").decode(errors="replace"), (e.stderr or b"").decode(errors="replace"), True
+    dt = time.time() - t0
+    report("rccl_two_ranks: bench.py --gpus 2 over nccl on one device returned (no hang) within 240 s", 1.0 if hung else 0.0, 0)
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    if rc == 0:
+        report("rccl_two_ranks: exactly one JSON line on stdout", abs(len(lines) - 1), 0)
+        d = json.loads(lines[0]) if lines else {}
+        report("rccl_two_ranks: n_gpus == 2", abs(d.get("n_gpus", 0) - 2), 0)
+        report("rccl_two_ranks: collective.ranks == 2 over nccl", 0.0 if d.get("collective", {}).get("ranks") == 2 and d.get("collective", {}).get("backend") == "nccl" else 1.0, 0)
+        report("rccl_two_ranks: value is finite and positive", 0.0 if d.get("value", 0) > 0 else 1.0, 0)
+        print(f"   (rccl_two_ranks: RCCL ran two ranks on one device in {dt:.0f} s: {d.get('value')} lists/s, all-reduce {d.get('collective')})", flush=True)
+    else:
+        refused = any(m in err for m in ("Duplicate GPU", "duplicate GPU", "ncclInvalidUsage", "invalid usage", "ncclUnhandledSystemError", "NCCL error", "ncclSystemError"))
+        report(f"rccl_two_ranks: non-zero exit ({rc}) carries RCCL's own refusal message", 0.0 if refused else 1.0, 0)
+        report("rccl_two_ranks: refusal reached the parent inside the bounded wait (<= 180 s)", 0.0 if dt <= 180 else 1.0, 0)
+        report("rccl_two_ranks: no JSON line was printed by a failed run", float(len(lines)), 0)
+        tail = " | ".join(l for l in err.strip().splitlines() if "NCCL" in l or "Duplicate" in l or "Error" in l)[-400:]
+        print(f"   (rccl_two_ranks: RCCL refused two ranks on one device after {dt:.0f} s, exit {rc}: {tail})", flush=True)
 
 
 @section

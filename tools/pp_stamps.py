@@ -12,7 +12,7 @@ dev = torch.device("cuda")
 B, S, H, HD = 4096, 8, 4, 64
 E = H * HD
 qkv = torch.randn(S * B, 3 * E, device=dev); out = torch.empty(S * B, E, device=dev); lse = torch.empty(S, H, B, device=dev)
-ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, N.PRECISION_DEFAULT)
+ib = N.query("rlt_list_attention_fwd_workspace", S, B, H, HD, 0.0, N.PRECISION_DEFAULT)
 images = torch.empty(max(ib, 16) // 4, device=dev) if ib else None
 print("image workspace bytes:", ib)
 for _ in range(3):
