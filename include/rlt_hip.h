@@ -47,10 +47,13 @@ int rlt_abi_version(void);
  *                        the tests.  Measured against fp64 (tools/gpu_probe.py x6_adversarial, profiles/r05_notes.md): at
  *                        or below the f32 MFMA kernels' error on random operands and on the adversarial classes `ones`
  *                        (low significand bits all ones, one sign) and `cancel` (sums cancelling by 1e4); on operands
- *                        that all share the SAME worst-case low bits (`worst-split`: 0x7F40, one sign) the dropped terms
- *                        add coherently - up to 8x the f32 MFMA kernels' error in attention backward (dQ / dK at 2048
- *                        lists), 17x in a K ~ 10^6 contraction - always inside the a-priori bound K 2^-24 of an fp32
- *                        chain and two orders inside BASELINE.json's 1e-4.  Head dim 128 and shapes off the tile grid
+ *                        that all share the SAME worst-case low bits (`worst-split`: 0x7F40, one sign) the roundings of
+ *                        the small plane products into one running sum add coherently - 17x the f32 MFMA kernels' error
+ *                        in a K ~ 10^6 contraction of the GEMM family, always inside the a-priori bound K 2^-24 of an
+ *                        fp32 chain and two orders inside BASELINE.json's 1e-4; list attention keeps those products in an
+ *                        accumulator of their own (head dim 16: all kernels; head dim 64: the forward at 512 lists and
+ *                        more) and stays at or below the f32 kernels on that class too, its head-dim-64 gradients within
+ *                        2x on every class (asserted; 4-8x until ABI 4).  Head dim 128 and shapes off the tile grid
  *                        run the exact-fp32 kernels in this mode.  THE DEFAULT: the reference computes in fp32 end to
  *                        end (models/AttnCut.py:8-14).
  *   RLT_PRECISION_BF16X3 opt-in fast mode: every operand split into bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi

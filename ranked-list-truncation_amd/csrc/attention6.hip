@@ -5,9 +5,11 @@
 //   a*b ~ m*m' + l*h' + h*l' + m*h' + h*m' + h*h'   (six v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest first);
 // what is dropped is < 2^-23 |a b| in the worst case, 2^-29 typically (tests/test_split6.py): under one fp32 ulp of the
 // product.  (On operands that all share the worst-case low bits the ROUNDINGS of the small plane products into the large running
-// sums add coherently: up to 8x the f32 MFMA kernels' error in dQ / dK at head dim 64, inside the fp32-chain bound; the head-dim-16
-// kernels keep the small products in an accumulator of their own and are below the f32 kernels on every class - attention6n.hip,
-// tools/gpu_probe.py x6_adversarial, profiles/r05_notes.md.)  Six bf16 products cost 6/16 of one f32 MFMA
+// sums add coherently in a one-accumulator kernel: what made dQ / dK at head dim 64 4-8x the f32 MFMA kernels' error through round 5
+// was the coherent error of THIS file's forward in O, amplified through delta = rowsum(dO o O); the head-dim-16 kernels and the
+// head-dim-64 forward at 512 lists and more (attention6n.hip, attention6h.hip) keep the small products in an accumulator of their
+// own, and with them every head-dim-64 gradient is within 2x of the f32 kernels on every class - tools/gpu_probe.py x6_adversarial,
+// profiles/r06_notes.md.)  Six bf16 products cost 6/16 of one f32 MFMA
 // product (2500 / 6 = 417 TFLOP/s of fp32-level peak against 157.3).
 //
 // Head dims 64 (the AttnCut / MMOECut family), 32 and 16 (Choopy / MtChoopy), with and without train-mode dropout; head dim

@@ -2339,8 +2339,11 @@ def x6_adversarial():
     forward) - errors identical to four digits (profiles/r05_notes.md).  What closes it is keeping the five small products of
     the list-contracted outputs (O, dQ, dK, dV) in an accumulator of their own, added to the h h' accumulator once at the end:
     the head-dim-16 kernels (csrc/attention6n.hip) do, and sit at 0.25-1.1 of the f32 kernels' error on EVERY class - held to
-    the 1.25 here, worst-split included.  The head-dim-64 kernels have no registers for a second accumulator set: dQ / dK of
-    worst-split are 4-8x the f32 kernels' there (both at 1e-4 .. 3e-3 of the gradient), bounded at 10x here.
+    the 1.25 here, worst-split included.  Head dim 64: the forward at 512 lists and more is the two-accumulator kernel of
+    csrc/attention6h.hip (O at 0.45-0.6 of the f32 kernels' error on every class); the backward kernels have no registers for a
+    second accumulator set, but what made dQ / dK of worst-split 4-8x the f32 kernels' in rounds 3-5 was the one-accumulator
+    FORWARD's coherent error in O, amplified through delta = rowsum(dO o O) into dS - with the new forward they measure 1.1-1.5x,
+    every head-dim-64 gradient on every class is bounded at 2x here and the 10x exemption is gone.
     The mode is an argument of each call here (ops.precision): the two run side by side in one process."""
     def both(fn):
         outs = {}
@@ -2362,19 +2365,27 @@ def x6_adversarial():
         # term scale for the plane products the mode drops by construction (documented: < 2^-23 worst, 2^-29 typical - it shows
         # where exact pairwise cancellation makes the f32 chain's own error vanish: `cancel` at K = 1,228,800, 1.2e-9 vs 7e-11)
         floor = min(math.sqrt(K) * 2.0 ** -25, 2.0 * e32) + 2.0 ** -27
-        # worst-split: asserted like the other classes where the kernels keep the small plane products in an accumulator of their
-        # own (list attention at head dim 16, csrc/attention6n.hip); bounded at 10x elsewhere (coherent ROUNDING of the small
-        # products into one large running sum: see the docstring)
-        # (the head-dim-64 FORWARD at 512 lists and more is the two-accumulator kernel of csrc/attention6h.hip: its output is held like head dim 16)
+        # Attention at head dim 64: the forward at 512 lists and more is the two-accumulator kernel of csrc/attention6h.hip and is held
+        # like head dim 16; the backward kernels keep ONE accumulator per output, and dQ / dK are DERIVED quantities - dS = P (dP - delta)
+        # with delta = rowsum(dO o O) amplifies whatever error O carries by the cancellation in (dP - delta) (errors of 1e-4 .. 1e-3 of
+        # the gradient in BOTH kernels on these operands) - so which kernel's rounding pattern lands worse is a coin toss per class:
+        # bounded at twice the f32 kernels' error on every class.  (Until round 6 the worst-split class sat at 4-8x here: that was the
+        # one-accumulator FORWARD's coherent error in O arriving through delta, not the backward kernels' own products - with the
+        # two-accumulator forward the same backward kernels measure 1.1-1.5x.)
+        hd64_bwd = name.startswith("attn") and "hd64" in name and not name.endswith(" out")
         two_acc = name.startswith("attn") and ("hd16" in name or (name.endswith(" out") and int(name.split()[1][1:]) >= 512))
-        if tag != "worst-split" or two_acc:
+        if hd64_bwd:
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 2 err_f32mfma + 2^-27 (derived gradient, one accumulator; observed multiple {ratio:.2f})",
+                   e6, 2.0 * e32 + 2.0 ** -27)
+        elif tag != "worst-split" or two_acc:
             bound = 1.25 * e32 + floor
             report(f"x6 adversarial {name} {tag}: err_x6 <= 1.25 err_f32mfma + min(sqrt(K) 2^-25, 2 err_f32mfma) + 2^-27 "
                    f"(effective multiple {bound / max(e32, 1e-300):.2f})", e6, bound)
             # ... and without the random-walk allowance: twice the f32 kernel's own error (+ the 2^-27 of the dropped plane products)
             report(f"x6 adversarial {name} {tag}: err_x6 <= 2 err_f32mfma + 2^-27 (observed multiple {ratio:.2f})", e6, 2.0 * e32 + 2.0 ** -27)
-        elif name.startswith("attn"):
-            report(f"x6 adversarial {name} {tag}: err_x6 <= 10 err_f32mfma (coherent class, one accumulator)", e6, 10.0 * e32)
+        elif name.startswith("attn"):       # worst-split through a one-accumulator forward (head dim 64 below 512 lists)
+            report(f"x6 adversarial {name} {tag}: err_x6 <= 2 err_f32mfma + 2^-27 (coherent class, one accumulator; observed multiple {ratio:.2f})",
+                   e6, 2.0 * e32 + 2.0 ** -27)
         if apriori:
             report(f"x6 adversarial {name} {tag}: bf16x6 within the fp32-chain a-priori bound K 2^-24", e6, K * 2.0 ** -24)
             report(f"x6 adversarial {name} {tag}: f32 MFMA within the fp32-chain a-priori bound K 2^-24", e32, K * 2.0 ** -24)
