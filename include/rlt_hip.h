@@ -277,11 +277,12 @@ int rlt_dropout_mask(uint32_t seed, size_t rows, int cols, float p, float* out, 
  * for the dropout rate of THIS call (without dropout the head-dim-64 backward kernels read the transposed operands
  * straight from the row images and the transposed images of Q and K are not written): the backward entry points must
  * be given the same drop_p and seed as the forward call whose `images` they use. */
-/* BF16X6 without dropout, 512 lists and more in whole tiles (head dim 64: csrc/attention6h.hip; head dim 16: csrc/attention6n.hip):
+/* BF16X6, 512 lists and more in whole tiles (head dim 64, with or without dropout: csrc/attention6h.hip; head dim 16 without dropout:
+ * csrc/attention6n.hip):
  * the pipelined forward kernels stage pre-split K / V tile images that the call itself writes into `images` (+ a flag word per
  * workgroup for its fix-up launch); the backward pass does not read them - rlt_list_attention_images_retained() tells whether the
  * caller has to keep `images` for the backward (1) or may treat it as scratch of the forward call (0).  `drop_p` of the workspace
- * query = the drop_p of the forward call (a train-mode call has no pipelined form and needs no such buffer). */
+ * query = the drop_p of the forward call (at head dim 16 a train-mode call has no pipelined form and needs no such buffer). */
 size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, float drop_p, int precision);
 int rlt_list_attention_images_retained(int S, int B, int H, int HD, int precision);
 int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float drop_p, uint32_t seed,

@@ -666,7 +666,7 @@ static bool a6n_fwd_images(int HD, int B) {
 }
 static size_t a6n_flags_bytes(int S, int B, int H) { return ((size_t)S * H * rlt_cdiv(B, 256) * sizeof(uint32_t) + 255) / 256 * 256; }
 
-// bf16x6 at head dim 64, 512 lists and more in whole 64-row tiles, no dropout: the pipelined forward kernel of attention6h.hip, same
+// bf16x6 at head dim 64, 512 lists and more in whole 64-row tiles, with or without dropout: the pipelined forward kernel of attention6h.hip, same
 // scheme - K / V tile images of the call + a flag word per 256-query workgroup in the forward's `images` buffer, fix-up launch of
 // attention6.hip's ping-pong kernel for the flagged workgroups.  RLT_A6H=0: attention6.hip's kernel alone (A/B runs)
 static bool a6h_fwd_images(int HD, int B) {
@@ -681,7 +681,7 @@ size_t rlt_list_attention_fwd_workspace(int S, int B, int H, int HD, float drop_
     if (attn_mode(HD) == 1) return rlt_attn3_images_bytes(S, B, H, HD, 3);
     // (the pipelined forward kernels have no train-mode form: a call with dropout does not use - and need not be given - their images)
     if (!(drop_p > 0.f) && a6n_fwd_images(HD, B)) return rlt_attn6n_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
-    if (!(drop_p > 0.f) && a6h_fwd_images(HD, B)) return rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);
+    if (a6h_fwd_images(HD, B)) return rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H);       // (train mode included)
     return attn6_img(HD) ? rlt_attn6_images_bytes(S, B, H, HD, 3) : 0;
 }
 
@@ -719,7 +719,7 @@ int rlt_list_attention_fwd(const float* qkv, int S, int B, int H, int HD, float 
             if (rc) return rc;
             return rlt_attn6n_run(0, a, st);
         }
-        if (drop_p <= 0.f && a6h_fwd_images(HD, B) && images && rlt_aligned16(images) &&
+        if (a6h_fwd_images(HD, B) && images && rlt_aligned16(images) &&
             images_bytes >= rlt_attn6h_fwd_images_bytes(S, B, H) + a6n_flags_bytes(S, B, H)) {
             AttnArgs b = a;
             b.img = images;

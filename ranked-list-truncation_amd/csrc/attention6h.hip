@@ -5,7 +5,7 @@
 // pipeline over 512-score items across tile boundaries, tile images pre-split once per call and staged by LDS-DMA, and the five small
 // plane products of every list-contracted output in an accumulator of their OWN (what keeps the `worst-split` class at the f32
 // kernels' error: profiles/r05_notes.md).  Same interface, same algorithm (flash-style, deterministic, no atomics), same fp32
-// softmax arithmetic as attention6.hip, which stays the path for train-mode dropout, ragged batches and fewer than 512 lists.
+// softmax arithmetic as attention6.hip, which stays the path for ragged batches, fewer than 512 lists and the backward pass.
 //
 // What head dim 64 changes against attention6n.hip: a d-contracted product (S = Q K^T, dP = dO V^T) is two k-steps of each of the
 // six plane products (12 MFMAs per 16 x 16 tile - no plane pairing), a d-indexed output (P V, dQ, dK, dV) four 16-row blocks; a slot
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void attn6h_prepare_kernel(const float* __rest
 
 #ifndef RLT_A6H_FWD1_BODY          // (timing experiments compile other generated bodies: tools/gen_attn6h_body.py with GEN_OMIT / GEN_DMA_STEP)
 #define RLT_A6H_FWD1_BODY "attention6h_fwd1_body.inc"
+#define RLT_A6H_FWD1_BODY_DROP "attention6h_fwd1_body_drop.inc"
 #endif
 #ifdef RLT_A6H_STAMPS
 // diagnostic build only: s_memtime at every slot of tiles 8..11 of one workgroup; entries 16 / 17: before / behind the barrier
@@ -124,11 +125,17 @@ __device__ __forceinline__ constexpr int prod_b(int p) { return p == 0 ? 1 : p =
 // keys.  fp32 and the exact split are scale-free, so the result is the same whatever the reference - unless a weight leaves the fp32
 // range: a workgroup whose normalisers end up non-finite, zero or above 2^100 raises its flag in a.redo, and a second launch (the
 // ping-pong kernel of attention6.hip, same grid, same block -> rows map) redoes exactly the flagged workgroups with a moving
-// reference.  Needs B % 64 == 0 (a partly filled tile would need a mask per key), no dropout.
+// reference.  Needs B % 64 == 0 (a partly filled tile would need a mask per key).
+// DROP: train-mode dropout of the attention probabilities, the same counter-based masks as every other kernel family (keep(pair seed,
+// query, key) = row_hash(query) * col_hash(key) >= threshold): the lane's four query hashes in registers, the 64 column hashes of
+// the NEXT tile computed once per body into a double-buffered LDS table, a block's eight per lane read with its fragments; the mask
+// is applied to the weight after it went into the normaliser (e_drop: one integer multiply, a compare, a multiply, a select).
+template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
     constexpr int NB = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);           // [2 buffers][K image | V image]
+    uint32_t* htab = reinterpret_cast<uint32_t*>(img0 + 4 * IMGH);   // DROP: [2 buffers][64] column hashes of the tile's keys
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int B = a.B, H = a.H, E = H * 64;
@@ -161,10 +168,14 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
     bf16x8 qf[NB][3][2];
     f32x4 seed_s[NB], acc[NB][4], acc2[NB][4];
     float l_run[NB], m_ref[NB];
+    uint32_t hq[NB];
+    const uint32_t ps = DROP ? pair_seed(a.seed, pair) : 0u;
+    const float inv_keep = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
     const float qmul = a.scale * LOG2E;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int r = row0 + 16 * n + l15, rc = min(r, B - 1);
+        hq[n] = DROP ? rlt_row_hash(ps, (uint32_t)r) : 0u;
         const float* qp = base + (size_t)rc * ld;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
     };
 #pragma unroll
     for (int j = 0; j < 12; ++j) dma(j, 0, img0);
+    if (DROP) htab[lane] = rlt_col_hash(ps, (uint32_t)lane);      // tile 0 (every wavefront writes the same 64 words)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the reference of each query: its largest score against the first 32 keys (log2 domain)
@@ -221,6 +233,8 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
     uint32_t pln[3][4][4];                                      // [h, m, l][ring][dword]
     bf16x8 kf[2][3][2];                                         // K row fragments [16-row block][plane][k-step]
     v4s vt[3][4][2];                                            // V^T fragments [plane][d block][half]
+    uint4 hcv[2][2];                                            // DROP: column hashes of the block's keys [block parity][16-row block]
+    hcv[0][0] = hcv[0][1] = hcv[1][0] = hcv[1][1] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -297,7 +311,23 @@ __global__ __launch_bounds__(256, 1) void attn6h_fwd1_kernel(AttnArgs a) {
                 (v4s __attribute__((address_space(3)))*)(Ic + IMGH + pl * PLH + (32 * b32 + 16 * half) * 64 + offT[db]));
         };
         auto st_dma = [&](int j) __attribute__((always_inline)) { dma(j, t_next, In); };
+        const uint32_t* Hc = htab + cur * KTH;
+        auto rd_hc = [&](int fb, int kb, int b32) __attribute__((always_inline)) {
+            hcv[fb][kb] = *reinterpret_cast<const uint4*>(Hc + 32 * b32 + 16 * kb + 4 * g);
+        };
+        auto st_hcol = [&]() __attribute__((always_inline)) {
+            htab[(cur ^ 1) * KTH + lane] = rlt_col_hash(ps, (uint32_t)(t_next * KTH + lane));
+        };
+        auto e_drop = [&](int it, int n, int kb, int r, int fb) __attribute__((always_inline)) {
+            const uint4& h4 = hcv[fb][kb];
+            const uint32_t hc = r == 0 ? h4.x : r == 1 ? h4.y : r == 2 ? h4.z : h4.w;
+            sc[it][kb][r] = rlt_keep_rc(hq[n], hc, a.drop_thr) ? sc[it][kb][r] * inv_keep : 0.f;
+        };
+        if constexpr (DROP) {
+#include RLT_A6H_FWD1_BODY_DROP
+        } else {
 #include RLT_A6H_FWD1_BODY
+        }
 #undef GAP_END
         A6H_STAMP(16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's LDS-DMA pieces of the next tile have landed
@@ -357,10 +387,16 @@ int rlt_attn6h_prepare2(int what0, int slot0, int what1, int slot1, const AttnAr
 // which = 0: the pipelined forward (K / V images in blocks 0 / 1 of a.img, one flag word per workgroup in a.redo); the caller
 // follows it with the fix-up launch of attention6.hip's kernel
 int rlt_attn6h_run(int which, const AttnArgs& a, hipStream_t st) {
-    RLT_CHECK_ARG(which == 0 && a.img && a.redo && a.B % KTH == 0 && a.drop_p <= 0.f);
-    const size_t shm = (size_t)4 * IMGH * sizeof(uint16_t);
-    const int rc = rlt_allow_lds(attn6h_fwd1_kernel, shm);
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn6h_fwd1_kernel, dim3(a.S * a.H * rlt_cdiv(a.B, 256)), dim3(256), shm, st, a);
+    RLT_CHECK_ARG(which == 0 && a.img && a.redo && a.B % KTH == 0);
+    const size_t shm = (size_t)4 * IMGH * sizeof(uint16_t) + 2 * KTH * sizeof(uint32_t);
+    const dim3 grid(a.S * a.H * rlt_cdiv(a.B, 256));
+    int rc;
+    if (a.drop_p > 0.f) {            // (a template parameter: hipcc if-converts a run-time test and executes the hashes regardless)
+        if ((rc = rlt_allow_lds(attn6h_fwd1_kernel<true>, shm))) return rc;
+        hipLaunchKernelGGL(attn6h_fwd1_kernel<true>, grid, dim3(256), shm, st, a);
+    } else {
+        if ((rc = rlt_allow_lds(attn6h_fwd1_kernel<false>, shm))) return rc;
+        hipLaunchKernelGGL(attn6h_fwd1_kernel<false>, grid, dim3(256), shm, st, a);
+    }
     return RLT_LAUNCH_RESULT();
 }

@@ -80,7 +80,9 @@ def test_path_level_entry_points(native):
     fwd_ws_train = N.query("rlt_workspace_bytes", N.OP_ENCODER_FWD_WS, S, B, E, H, FF, 1, D)
     assert fwd_ws - fwd_ws_train == (0 if kept else rup(img_b) - rup(N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.1, D)))
     if N.get_precision() == "bf16x6" and not any(os.environ.get(v) == "0" for v in ("RLT_A6H", "RLT_ATTN6")) and not os.environ.get("RLT_ATTN_MODE"):
-        assert not kept and img_b > 2 * S * H * (B // 64) * 24576 and N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.1, D) == 0
+        assert not kept and img_b > 2 * S * H * (B // 64) * 24576 and N.query("rlt_list_attention_fwd_workspace", S, B, H, E // H, 0.1, D) == img_b
+        img16 = N.query("rlt_list_attention_fwd_workspace", S, 8192, 8, 16, 0.0, D)          # head dim 16: the pipelined forward has no train-mode form
+        assert img16 > 0 and N.query("rlt_list_attention_fwd_workspace", S, 8192, 8, 16, 0.1, D) == 0
     # the backward parts check their workspace themselves (ABI 5): a delta-only buffer is refused, not overrun, where images are staged
     assert lib.rlt_list_attention_bwd_dkv(None, None, None, None, None, 0, 1, 1, 1, 64, 0.0, 0, None, D, None) == -1
     ws0 = N.query("rlt_workspace_bytes", N.OP_ENCODER_BWD_WS, S, B, E, H, FF, 0, D)

@@ -20,6 +20,7 @@ CASES = [
     (["tools/gen_attn6n_body.py", "dkv"], "attention6n_dkv1_body.inc"),
     (["tools/gen_attn6n_body.py", "fwd"], "attention6n_fwd1_body.inc"),
     (["tools/gen_attn6h_body.py", "fwd"], "attention6h_fwd1_body.inc"),
+    (["tools/gen_attn6h_body.py", "fwd", "drop"], "attention6h_fwd1_body_drop.inc"),
     (["tools/gen_lstm6w_body.py", "fwd"], "lstm6w_fwd_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_xin"], "lstm6w_fwd_xin_body.inc"),
     (["tools/gen_lstm6w_body.py", "fwd_seq"], "lstm6w_fwd_seq_body.inc"),
@@ -136,14 +137,15 @@ def test_attention6h_pipelined_loop_has_no_unpadded_register_moves(tmp_path):
     subprocess.run([B.HIPCC] + B.FLAGS + B.FILE_FLAGS["attention6h.hip"] + ["-S", "--cuda-device-only", src, "-o", str(asm)], check=True,
                    capture_output=True)
     text = asm.read_text()
-    m = re.search(r"^_ZN12_GLOBAL__N_118attn6h_fwd1_kernelE8AttnArgs:(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert m
-    blocks = re.split(r"^\.LBB\w+:", m.group(1), flags=re.M)
-    loop = max(blocks, key=lambda b: b.count("v_mfma"))
-    assert loop.count("v_mfma_f32_16x16x32_bf16") == 8 * 52
-    assert "v_accvgpr" not in loop and "scratch_" not in loop
-    assert not re.search(r"v_mov_b32_e32 v\d+, [va]\d+", loop)          # no register-to-register copy (constants for addresses are fine)
-    assert loop.count("global_load_lds_dwordx4") == 12 and len(re.findall(r"s_mov_b32 m0,", loop)) == 4
+    for tag in ("ILb0EEEv8AttnArgs", "ILb1EEEv8AttnArgs"):             # without / with dropout
+        m = re.search(r"^_ZN12_GLOBAL__N_118attn6h_fwd1_kernel" + tag + r":(.*?)s_endpgm", text, flags=re.S | re.M)
+        assert m, tag
+        blocks = re.split(r"^\.LBB\w+:", m.group(1), flags=re.M)
+        loop = max(blocks, key=lambda b: b.count("v_mfma"))
+        assert loop.count("v_mfma_f32_16x16x32_bf16") == 8 * 52
+        assert "v_accvgpr" not in loop and "scratch_" not in loop
+        assert not re.search(r"v_mov_b32_e32 v\d+, [va]\d+", loop)          # no register-to-register copy (constants for addresses are fine)
+        assert loop.count("global_load_lds_dwordx4") == 12 and len(re.findall(r"s_mov_b32 m0,", loop)) == 4
     assert re.search(r"\.vgpr_spill_count:\s+0", text[text.index("attn6h_fwd1_kernel"):] if ".vgpr_spill_count" in text else ".vgpr_spill_count: 0")
 
 

@@ -45,7 +45,7 @@ MARGIN = 2                   # a chunk that writes an MFMA operand sits at least
 WAR = 2                      # a fragment register is rewritten at the earliest this many gaps behind the last MFMA that reads it
 RD_AHEAD = 10                # an LDS read is issued at least this many gaps (~160 cycles) ahead of the MFMA that takes its data
 CAP = 8                      # vector-issue cycles a gap takes before the scheduler looks for another one
-COST = {"exp": 8, "mul": 4, "sub": 4, "cvt": 5, "rd": 2, "ld": 3, "tb": 3, "imul": 8, "sel": 4}
+COST = {"exp": 8, "mul": 4, "sub": 4, "cvt": 5, "rd": 2, "ld": 3, "tb": 3, "drop": 16, "hc": 48}
 
 # the six plane products, smallest first: (plane of the A operand, plane of the B operand); 0 = h, 1 = m, 2 = l
 PROD = [(1, 1), (2, 0), (0, 2), (1, 0), (0, 1), (0, 0)]
@@ -106,16 +106,19 @@ for i in range(NS):
     it, n, b32 = i % RING, i % NB, i // NB
     s_done = [gap_of("S", 11, i), gap_of("S", 23, i)]
     d_done = [gap_of("D", 11, i), gap_of("D", 23, i)] if MODE != "fwd" else None
-    ep, ed, es = {}, {}, {}
+    ep, ed, es, ek = {}, {}, {}, {}
     for kb in range(2):
         for r in range(4):
             ep[kb, r] = add(f"ep{i}.{kb}{r}", [(f"e_exp({it}, {kb}, {r});", "exp")], s_done[kb] + LAG, None)
             if MODE == "fwd":      # the weight into the normaliser of own block n (any time before the registers turn into residuals)
                 es[kb, r] = add(f"es{i}.{kb}{r}", [(f"e_sum({it}, {n}, {kb}, {r});", "mul")], 0, gap_of("R1", kb, i) - 1, [(ep[kb, r], 1)])
+                if DROP:           # train mode: the dropout mask acts on the weight AFTER it went into the normaliser
+                    ek[kb, r] = add(f"ek{i}.{kb}{r}", [(f"e_drop({it}, {n}, {kb}, {r}, {b32 & 1});", "drop")], 0, gap_of("R1", 0, i) - MARGIN - 1,
+                                    [(es[kb, r], 1)])
             else:
                 ed[kb, r] = add(f"ed{i}.{kb}{r}", [(f"e_mul({it}, {kb}, {r});", "mul")], d_done[kb] + LAG, None, [(ep[kb, r], 1)])
     for m in MATS:
-        src = ep if m == "P" else ed
+        src = (ek if DROP and MODE == "fwd" else ep) if m == "P" else ed
         r1, r2, out = r_stage(m, 1), r_stage(m, 2), o_stage(m)
         mi = 0 if m == "P" else 1
         for j in range(4):
@@ -136,7 +139,7 @@ for i in range(NS):
     for kb in range(2):
         for r in range(4):
             if MODE == "fwd":
-                ep[kb, r].deadline = gap_of("R1", 0, i) - MARGIN - 2
+                ep[kb, r].deadline = gap_of("R1", 0, i) - MARGIN - (4 if DROP else 2)
                 continue
             if "P" in MATS:
                 ep[kb, r].deadline = gap_of("RP1", 0, i) - MARGIN - 1
@@ -189,6 +192,19 @@ for b32 in range(NB32):
                 use = gap_of(stg, 12 * kb, first_item(b32))
                 rel = gap_of(stg, 12 * kb, last_item(b32 - 1)) + WAR if b32 >= 1 else 0
                 add(f"tb{b32}.{kb}{which}", [(f"rd_tab({which}, {kb}, {b32});", "tb")], rel, use - RD_AHEAD)
+
+if DROP and MODE == "fwd":
+    # column hashes of the block's 32 keys (one uint4 per 16-row block, double-buffered by block parity: the masks of a block's last
+    # item are evaluated a slot after the next block's first score product) and the hash table of the NEXT tile's 64 keys
+    item_tasks = {t.name: t for t in tasks}
+    for b32 in range(NB32):
+        for kb in range(2):
+            rel = GS if b32 == NB32 - 1 else 0        # (buffer 1's previous tenant: the previous tile's last block, masked up to slot 0)
+            rd = add(f"hc{b32}.{kb}", [(f"rd_hc({b32 & 1}, {kb}, {b32});", "tb")], rel, None)
+            for n_ in range(NB):
+                for r in range(4):
+                    item_tasks[f"ek{first_item(b32) + n_}.{kb}{r}"].after.append((rd, RD_AHEAD))
+    add("hcol", [("st_hcol();", "hc")], 2 * GS, GS * (NS - 1))
 
 # ---- staging of the next tile: LDS-DMA pieces of the pre-split tile records (2 images x 24 pieces of 1 KiB, a wavefront issues
 # ---- every fourth one; dK+dV: + the piece of the rows' seeds): early in the body, so that they have landed long before the barrier
@@ -250,14 +266,16 @@ else:
     sys.exit(f"no schedule: {miss.name} (release {miss.release}, deadline {miss.deadline})")
 # the staging pieces carry their LDS base in M0, written by the first piece of a group: pieces in index order
 dma_at = [t.placed[0] for t in tasks if t.name.startswith("dma")]
-assert dma_at == sorted(dma_at) and len(set(dma_at)) == len(dma_at), dma_at
+assert dma_at == sorted(dma_at), dma_at
+emitted = [c for gap in sched for c, _k, _n in gap if c.startswith("st_dma(")]
+assert emitted == [f"st_dma({j});" for j in range(NDMA)], emitted
 cap = max(capv)
 sys.stderr.write(f"{MODE}: {G} gaps, capacity {CAP}..{cap} cycles per gap, mean load {sum(used) / G:.1f}, max {max(used)}, "
                  f"{sum(1 for u in used if u > 8)} gaps over 8 cycles (sum of the excess {sum(max(0, u - 8) for u in used)})\n")
 
 # ---- emit
 CALL = {"S": "m_s", "D": "m_d", "O": "m_o", "OV": "m_o", "OK": "m_o"}
-out = [f"// generated by tools/gen_attn6h_body.py {MODE} - do not edit"]
+out = [f"// generated by tools/gen_attn6h_body.py {MODE}{' drop' if DROP else ''} - do not edit"]
 for s in range(NS):
     out.append(f"// slot {s}")
     out.append(f"A6H_STAMP({s});")
