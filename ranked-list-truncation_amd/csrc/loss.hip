@@ -293,41 +293,45 @@ __global__ __launch_bounds__(256) void reward_loss_kernel(RewardArgs a) {
     }
 }
 
-// ---- the same pass, two lists per wavefront (the form the training step runs) ----------------------------------
-// A half-wavefront (32 lanes) owns a list and every lane keeps the 16-byte pieces it loaded: in round r lane l holds
-// positions 128 r + 4 l .. + 3, so loads and stores are whole coalesced rows and nothing is turned through LDS.  The
-// prefix sums run round by round (3 serial adds, a 32-lane DPP scan - the row_shr steps plus one row_bcast:15 - and the
-// running total of the rounds before); the reductions are the same scan read at the last lane of the half.  Per-position
-// constants (position numbers, the float64 DCG coefficients) are fetched once per wavefront, outside the list loop.
-// Requires S % 4 == 0, S <= 128 R <= 384, 16-byte aligned rows, p and dp present (the general kernel above takes the rest).
-template <typename T, typename Op>
+// ---- the same pass, two or FOUR lists per wavefront (the form the training step runs) ---------------------------
+// A group of LL = 32 (16) lanes owns a list and every lane keeps the 16-byte pieces it loaded: in round r lane l of the group holds
+// positions 4 LL r + 4 l .. + 3, so loads and stores are whole coalesced rows and nothing is turned through LDS.  The
+// prefix sums run round by round (3 serial adds, a DPP scan over the group - the row_shr steps, for 32 lanes plus one
+// row_bcast:15 - and the running total of the rounds before); the reductions are the same scan read at the last lane of the group.
+// Per-position constants (position numbers, the float64 DCG coefficients) are fetched once per wavefront, outside the list loop.
+// Requires S % 4 == 0, S <= 4 LL R, 16-byte aligned rows, p and dp present (the general kernel above takes the rest).
+// LL = 16 (four lists per wavefront, rounds of 64 positions) where it wastes fewer lane slots: the pass is bound by vector issue, and
+// S = 300 fills 300 of 384 slots in three rounds of 128 but 300 of 320 in five rounds of 64 - a sixth less vector work per list, and
+// the 16-lane scans and "last lane of the group" reads are one DPP step shorter / a single row broadcast.
+template <int LL, typename T, typename Op>
 __device__ __forceinline__ T half_scan_op(T v, T id, Op op) {
     v = op(v, rlt_dpp<0x111, 0xf>(id, v));
     v = op(v, rlt_dpp<0x112, 0xf>(id, v));
     v = op(v, rlt_dpp<0x114, 0xf>(id, v));
     v = op(v, rlt_dpp<0x118, 0xf>(id, v));
-    v = op(v, rlt_dpp<0x142, 0xa>(id, v));      // row 0 -> row 1, row 2 -> row 3: inclusive inside each half
+    if (LL == 32) v = op(v, rlt_dpp<0x142, 0xa>(id, v));      // row 0 -> row 1, row 2 -> row 3: inclusive inside each half
     return v;
 }
-template <typename T>
-__device__ __forceinline__ T half_last(T v, bool upper) {     // the value of the last lane of the caller's half
+template <int LL, typename T>
+__device__ __forceinline__ T half_last(T v, bool upper) {     // the value of the last lane of the caller's group
+    if (LL == 16) return rlt_dpp<0x15F, 0xf>(v, v);          // row_newbcast:15: lane 15 of the row to every lane of the row
     const T lo = rlt_readlane(v, 31), hi = rlt_readlane(v, 63);
     return upper ? hi : lo;
 }
-template <typename T>
+template <int LL, typename T>
 __device__ __forceinline__ T half_sum(T v, bool upper) {
-    return half_last(half_scan_op(v, T(0), [](T x, T y) { return x + y; }), upper);
+    return half_last<LL>(half_scan_op<LL>(v, T(0), [](T x, T y) { return x + y; }), upper);
 }
 
-template <int R, bool METRICS, bool F1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F1 ? 4 : 3)))   // <= 128 (168) registers, no spills
+template <int R, bool METRICS, bool F1, int LL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F1 && R <= 3 ? 4 : 3)))   // <= 128 (168) registers, no spills
 void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
-    constexpr int N = 4 * R;
+    constexpr int N = 4 * R, PR = 4 * LL, LPW = 64 / LL;      // positions per lane, per round; lists per wavefront
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool upper = lane >= 32;
-    const int hl = lane & 31;
+    const int hl = lane & (LL - 1), grp = lane / LL;
     const int S = a.S, B = a.B;
-    const bool last_ok = (R - 1) * 128 + 4 * hl < S;          // rounds before the last lie inside the list by construction
+    const bool last_ok = (R - 1) * PR + 4 * hl < S;           // rounds before the last lie inside the list by construction
     auto ok = [&](int r) { return r < R - 1 || last_ok; };
     // ---- per-position constants of this lane -------------------------------------------------------------------
     float icf[F1 ? 1 : N];                                    // DCG reward: 1 / log2(j + 2), 0 beyond the list
@@ -335,7 +339,7 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) icf[4 * r + i] = ok(r) ? fast_rcp(a.coef[r * 128 + 4 * hl + i]) : 0.f;
+            for (int i = 0; i < 4; ++i) icf[4 * r + i] = ok(r) ? fast_rcp(a.coef[r * PR + 4 * hl + i]) : 0.f;
     }
     const float c_exp = (1.f / a.tau) * 1.4426950408889634f;
     // F1 reward 2c / (k + N): k + N <= 2 S <= 768 is a small integer, so 2 / (k + N) comes from a table in LDS (filled with the same
@@ -349,14 +353,14 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
     }
     double part_loss = 0.0, part_f1 = 0.0, part_dcg = 0.0;
     const int nwaves = gridDim.x * 4;
-    for (int pb = 2 * (blockIdx.x * 4 + wv); pb < B; pb += 2 * nwaves) {
-        const bool live = pb + (upper ? 1 : 0) < B;           // B odd: the idle half shadows its partner, stores masked
-        const int b = live ? pb + (upper ? 1 : 0) : pb;
+    for (int pb = LPW * (blockIdx.x * 4 + wv); pb < B; pb += LPW * nwaves) {
+        const bool live = pb + grp < B;                       // lists beyond B: the idle group shadows the first one, stores masked
+        const int b = live ? pb + grp : pb;
         const size_t base = (size_t)b * S;
         float y[N], p[N];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const size_t at = base + (ok(r) ? r * 128 + 4 * hl : 0);
+            const size_t at = base + (ok(r) ? r * PR + 4 * hl : 0);
             float4 vy = *reinterpret_cast<const float4*>(a.y + at);
             float4 vp = *reinterpret_cast<const float4*>(a.p + at);
             if (r == R - 1 && !last_ok) { vy = make_float4(0.f, 0.f, 0.f, 0.f); vp = make_float4(1.f, 1.f, 1.f, 1.f); }
@@ -371,17 +375,17 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float s0 = y[4 * r], s1 = s0 + y[4 * r + 1], s2 = s1 + y[4 * r + 2], s3 = s2 + y[4 * r + 3];
-                const float incl = half_scan_op(s3, 0.f, [](float x, float z) { return x + z; });
+                const float incl = half_scan_op<LL>(s3, 0.f, [](float x, float z) { return x + z; });
                 const float ex = (incl - s3) + off;
                 rv[4 * r] = ex + s0; rv[4 * r + 1] = ex + s1; rv[4 * r + 2] = ex + s2; rv[4 * r + 3] = ex + s3;
-                off += half_last(incl, upper);
+                off += half_last<LL>(incl, upper);
             }
             n_rel = off;
             const float* rt = rtab + (4 * hl + 1 + (int)n_rel);       // 2 / (k + N), k = position + 1
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rv[4 * r + i] *= rt[r * 128 + i];              // c = 0 gives 0 (k + N >= 1)
+                for (int i = 0; i < 4; ++i) rv[4 * r + i] *= rt[r * PR + i];              // c = 0 gives 0 (k + N >= 1)
             }
         } else {                                              // utils/metrics.py:93-101: prefix of (+1 | penalty) / log2(j+2)
             float off = 0.f;
@@ -391,16 +395,16 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[i] = (y[4 * r + i] == 1.f) ? icf[4 * r + i] : icf[4 * r + i] * a.penalty;
                 const float s0 = g[0], s1 = s0 + g[1], s2 = s1 + g[2], s3 = s2 + g[3];
-                const float incl = half_scan_op(s3, 0.f, [](float x, float z) { return x + z; });
+                const float incl = half_scan_op<LL>(s3, 0.f, [](float x, float z) { return x + z; });
                 const float ex = (incl - s3) + off;
                 rv[4 * r] = ex + s0; rv[4 * r + 1] = ex + s1; rv[4 * r + 2] = ex + s2; rv[4 * r + 3] = ex + s3;
-                off += half_last(incl, upper);
+                off += half_last<LL>(incl, upper);
             }
             if (METRICS) {
                 float cnt = 0.f;
 #pragma unroll
                 for (int n = 0; n < N; ++n) cnt += y[n];
-                n_rel = half_sum(cnt, upper);
+                n_rel = half_sum<LL>(cnt, upper);
             }
         }
         // ---- q = exp(r / tau) / sum (utils/losses.py:226-228; no maximum subtracted, like the reference) ----------
@@ -414,7 +418,7 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
                 if (n >= N - 4 && !last_ok) q[n] = 0.f;
                 zs += q[n];
             }
-            const float zsum = half_sum(zs, upper);
+            const float zsum = half_sum<LL>(zs, upper);
             const float iz = fast_rcp(zsum);
             l2z = __builtin_amdgcn_logf(zsum);                // log2 q_n = r_n c_exp - log2 Z: no v_log_f32 per position for q
 #pragma unroll
@@ -484,13 +488,13 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             if (!last_ok) part -= 4.f;                        // the 4 positions beyond the list carry p = 1, q = 0: s = 1 each
             part *= 0.5f * 0.6931471805599453f;
         }
-        const float tot = half_sum(part, upper);
+        const float tot = half_sum<LL>(part, upper);
         if (hl == 0 && live && a.loss_per_list) a.loss_per_list[b] = tot;
         if (live) part_loss += (double)tot;
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (live && ok(r))
-                *reinterpret_cast<float4*>(a.dp + base + r * 128 + 4 * hl) =
+                *reinterpret_cast<float4*>(a.dp + base + r * PR + 4 * hl) =
                     make_float4(dpv[4 * r], dpv[4 * r + 1], dpv[4 * r + 2], dpv[4 * r + 3]);
         // ---- cut metrics of the same lists (run.py:141-145 -> utils/metrics.py:15-38) ----------------------------
         if (METRICS) {
@@ -500,12 +504,12 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int j = r * 128 + 4 * hl + i;
+                    const int j = r * PR + 4 * hl + i;
                     if (ok(r) && p[4 * r + i] > best) { best = p[4 * r + i]; bi = j; }
                 }
-            const float m = half_last(half_scan_op(best, -INFINITY, [](float x, float z) { return fmaxf(x, z); }), upper);
+            const float m = half_last<LL>(half_scan_op<LL>(best, -INFINITY, [](float x, float z) { return fmaxf(x, z); }), upper);
             const int cand = (best == m) ? bi : 0x7fffffff;
-            const int kmin = half_last(half_scan_op(cand, 0x7fffffff, [](int x, int z) { return x < z ? x : z; }), upper);
+            const int kmin = half_last<LL>(half_scan_op<LL>(cand, 0x7fffffff, [](int x, int z) { return x < z ? x : z; }), upper);
             const int k = (kmin == 0x7fffffff ? 0 : kmin) + 1;
             // DCG@k = sum_{j<k} (y_j == 1 ? 1 : pen) / log2(j + 2) = pen * T[k] + (1 - pen) * sum_{j<k, y_j == 1} 1 / log2(j + 2),
             // T[k] = sum_{j<k} 1 / log2(j + 2) from the per-device table (float64; 1e-16 relative apart from the serial sum)
@@ -513,25 +517,27 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             double rel = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (r * 128 >= __builtin_amdgcn_readfirstlane(max(rlt_readlane(k, 0), rlt_readlane(k, 32)))) break;   // both cuts lie before this round
+                int kmax = max(rlt_readlane(k, 0), rlt_readlane(k, 32));
+                if (LL == 16) kmax = max(kmax, max(rlt_readlane(k, 16), rlt_readlane(k, 48)));
+                if (r * PR >= __builtin_amdgcn_readfirstlane(kmax)) break;   // every group's cut lies before this round
                 // 1 / log2(j + 2) in float64 (utils/metrics.py:7): the same 32 bytes per lane for every list, served by the cache
                 double ic[4];
                 {
-                    const double* src = icoef_tab + (ok(r) ? r * 128 + 4 * hl : 0);
+                    const double* src = icoef_tab + (ok(r) ? r * PR + 4 * hl : 0);
                     asm volatile("" : "+v"(src));             // keep the loads here: hoisted out of the list loop they cost 8 R registers
                     const double2 lo = *reinterpret_cast<const double2*>(src), hi = *reinterpret_cast<const double2*>(src + 2);
                     ic[0] = lo.x; ic[1] = lo.y; ic[2] = hi.x; ic[3] = hi.y;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int j = r * 128 + 4 * hl + i;
+                    const int j = r * PR + 4 * hl + i;
                     const bool in = j < k && ok(r);
                     hits += in ? y[4 * r + i] : 0.f;
                     rel += (in && y[4 * r + i] == 1.f) ? ic[i] : 0.0;
                 }
             }
-            hits = half_sum(hits, upper);
-            rel = half_sum(rel, upper);
+            hits = half_sum<LL>(hits, upper);
+            rel = half_sum<LL>(rel, upper);
             const double dcg = a.mpenalty * icoef_tab[1024 + k] + (1.0 - a.mpenalty) * rel;
             // F1 = 2pr / (p + r) = 2c / (k + N) (0 when c = 0, which covers N = 0): small integers, reciprocal by two
             // Newton steps from v_rcp_f64 (~1e-16 relative; the parity bound on the mean is 1e-12)
@@ -548,10 +554,15 @@ void reward_loss_h_kernel(RewardArgs a, const double* __restrict__ icoef_tab) {
             if (live) { part_f1 += f1; part_dcg += dcg; }
         }
     }
-    if (METRICS) {                                            // one record per wavefront: lower half + upper half
-        const double l = rlt_readlane(part_loss, 0) + rlt_readlane(part_loss, 32);
-        const double f = rlt_readlane(part_f1, 0) + rlt_readlane(part_f1, 32);
-        const double d = rlt_readlane(part_dcg, 0) + rlt_readlane(part_dcg, 32);
+    if (METRICS) {                                            // one record per wavefront: its groups in lane order
+        auto groups = [&](double v) {
+            double t = rlt_readlane(v, 0);
+            if (LL == 16) t += rlt_readlane(v, 16);
+            t += rlt_readlane(v, 32);
+            if (LL == 16) t += rlt_readlane(v, 48);
+            return t;
+        };
+        const double l = groups(part_loss), f = groups(part_f1), d = groups(part_dcg);
         if (lane == 0) {
             double* rec = a.partials + 3 * ((size_t)blockIdx.x * 4 + wv);
             rec[0] = l; rec[1] = f; rec[2] = d;
@@ -625,19 +636,20 @@ __global__ __launch_bounds__(1024) void dcg_table_kernel(double* __restrict__ ta
     }
 }
 
-// two lists per wavefront: one workgroup per 8 lists up to the same number of workgroups
-int reward_h_grid(int B) {
-    const int groups = rlt_cdiv(B, 2 * LISTS_PER_WG);
+// two (four) lists per wavefront: one workgroup per 8 (16) lists up to the same number of workgroups
+int reward_h_grid(int B, int lpw = 2) {
+    const int groups = rlt_cdiv(B, lpw * LISTS_PER_WG);
     return groups < REWARD_MAX_GRID ? groups : REWARD_MAX_GRID;
 }
-template <int R, bool METRICS>
+template <int R, bool METRICS, int LL = 32>
 int launch_reward_h(const RewardArgs& a, hipStream_t st) {
     const double* tab = a.icoef_tab;
     if (METRICS && !tab) return RLT_E_ARG;
+    const dim3 grid(reward_h_grid(a.B, 64 / LL));
     if (a.metric == RLT_METRIC_F1)
-        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, true>), dim3(reward_h_grid(a.B)), dim3(256), 0, st, a, tab);
+        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, true, LL>), grid, dim3(256), 0, st, a, tab);
     else
-        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, false>), dim3(reward_h_grid(a.B)), dim3(256), 0, st, a, tab);
+        hipLaunchKernelGGL((reward_loss_h_kernel<R, METRICS, false, LL>), grid, dim3(256), 0, st, a, tab);
     return RLT_LAUNCH_RESULT();
 }
 
@@ -648,6 +660,17 @@ int dispatch_reward_m(const RewardArgs& a, hipStream_t st, int* records = nullpt
     const bool halves = a.p && a.dp && !a.r_out && !a.q_out && (a.S & 3) == 0 && a.S <= 384 && rlt_aligned16(a.dp) &&
                         rlt_aligned16(a.p) && rlt_aligned16(a.y) && !general_only;
     if (halves) {
+        // four lists per wavefront where rounds of 64 positions waste fewer lane slots than rounds of 128 (an odd number of them:
+        // S in 1..64, 129..192, 257..320 - the reference's 300); RLT_LOSS_QUARTERS=0: two lists per wavefront everywhere (A/B runs)
+        static const bool quarters = [] { const char* e = getenv("RLT_LOSS_QUARTERS"); return !e || atoi(e) != 0; }();
+        const int r16 = rlt_cdiv(a.S, 64);
+        // (the DCG reward keeps a coefficient per position in registers: its five-round form would spill)
+        if (quarters && (r16 & 1) && r16 <= (a.metric == RLT_METRIC_F1 ? 5 : 3)) {
+            if (records) *records = reward_h_grid(a.B, 4) * LISTS_PER_WG;
+            if (r16 == 1) return launch_reward_h<1, METRICS, 16>(a, st);
+            if (r16 == 3) return launch_reward_h<3, METRICS, 16>(a, st);
+            return launch_reward_h<5, METRICS, 16>(a, st);
+        }
         if (records) *records = reward_h_grid(a.B) * LISTS_PER_WG;
         const int r = rlt_cdiv(a.S, 128);
         if (r <= 1) return launch_reward_h<1, METRICS>(a, st);
