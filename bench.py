@@ -16,7 +16,10 @@ library's DEFAULT mode, `bf16x6`: f32 operands, accumulation and storage; every 
 family, the list attention and the BiLSTM recurrences from an EXACT three-way bf16 split of both
 operands, six bf16 MFMA products per fp32 product, per-product error < 2^-23 (the reference computes
 in fp32 end to end - models/AttnCut.py:8-14; VERDICT r03 accepted this mode as the reference's
-precision: all 24 operand bits enter, errors against fp64 at or below the f32 MFMA kernels').  Two
+precision: all 24 operand bits enter; errors against fp64 at or below the f32 MFMA kernels' on random operands and on
+two of three adversarial operand classes - on operands that all share the worst-case low significand bits the GEMM family
+reaches 17x the f32 kernels' error at K ~ 10^6, inside the fp32-chain bound, and list attention stays within 2x on every
+class: include/rlt_hip.h, tools/gpu_probe.py x6_adversarial).  Two
 sibling blocks time the same step in the same run, each with its own roofline: `f32_mfma_mode` (exact
 fp32 products on `v_mfma_f32_32x32x2_f32`, peak 157.3 TFLOP/s) and `fast_mode` (bf16x3: 16 operand
 bits, inside the 1e-4 parity bound, narrower than the reference - opt-in).  `--precision` moves another
@@ -44,7 +47,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 PEAK_HBM_BPS = 8.0e12
 # HBM traffic per launch / per step is NOT measured by this script: it comes from separate rocprofv3 --pmc passes of
 # this same command (tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) committed here:
-PMC_TRAFFIC_FILES = {m: tuple(os.path.join("profiles", f"{r}_pmc_traffic_{m}.json") for r in ("r05", "r04", "r03"))
+PMC_TRAFFIC_FILES = {m: tuple(os.path.join("profiles", f"{r}_pmc_traffic_{m}.json") for r in ("r06", "r05", "r04", "r03"))
                      for m in ("bf16x6", "fp32", "bf16x3")}
 
 

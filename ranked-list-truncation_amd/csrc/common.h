@@ -141,7 +141,7 @@ __host__ __device__ __forceinline__ uint32_t rlt_col_hash(uint32_t seed, uint32_
     return rlt_mix32((seed ^ 0x85EBCA6BU) + rlt_mix32(col + 0x7F4A7C15U)) | 1u;
 }
 __host__ __device__ __forceinline__ bool rlt_keep_rc(uint32_t row_hash, uint32_t col_hash, uint32_t thr) {
-    return row_hash * col_hash >= thr;
+    return row_hash * col_hash >= thr;       // (a 24-bit multiply - v_mul_u32_u24 - in its place measured no different: profiles/r06_notes.md)
 }
 // threshold for "drop": drop iff number < thr, thr = p * 2^32
 __host__ __device__ __forceinline__ uint32_t rlt_drop_threshold(float p) {

@@ -17,8 +17,9 @@ import json
 import re
 import sys
 
-KERNEL_RE = re.compile(r"(attn(?:3|6n|6|16)?_\w+|gemm6[bce]?_kernel<[^>]*>|gemm3?b?_kernel<[^>]*>|bilstm[36]?_\w+|splitk_reduce_kernel|add_ln_\w+|heads_\w+|narrow_dw_\w+|"
-                       r"reward_loss_kernel|reward_loss_h_kernel|adam_kernel|rlt_rows_reduce_kernel|colsum_\w+|cut_metrics_kernel)")
+KERNEL_RE = re.compile(r"(attn(?:3|6n|6h|6|16)?_\w+|gemm6[bces]?_kernel<[^>]*>|gemm3?b?_kernel<[^>]*>|bilstm(?:3|6w|6)?_\w+|splitk_reduce_kernel|add_ln_\w+|heads_\w+|"
+                       r"narrow_dw_\w+|reward_loss_kernel|reward_loss_h_kernel|loss_metrics_final_kernel|adam_kernel|rlt_rows_reduce_kernel|colsum_\w+|"
+                       r"cut_metrics_kernel|embed_\w+|mmoe_\w+|pair_softmax_\w+|mt_\w+_kernel|dropout_mask_kernel)")
 
 
 def per_kernel(path, counter):
