@@ -775,22 +775,27 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_bwd1_kernel(AttnArgs
 
     const int nt = rlt_cdiv_dev(B, KTN1);
     // staging: LDS-DMA of the pre-split tile records (attn6n_prepare_kernel): 12 pieces of 1 KiB per image, the two images of a
-    // tile adjacent in LDS; dK+dV: + the piece of the tile's seeds.  Piece j of this wavefront = piece wv + 4 j of the tile.
+    // tile adjacent in LDS; dK+dV: + the piece of the tile's seeds.
     const int npair = a.S * H;
     const uint8_t* rec0 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)(DKV ? 0 : 1) * npair + pair) * (size_t)(nt + 1) * RECB;
     const uint8_t* rec1 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)(DKV ? 3 : 2) * npair + pair) * (size_t)(nt + 1) * RECB;
     const uint8_t* recs = reinterpret_cast<const uint8_t*>(a.img) + 4 * a6n_img_block(npair, nt) + (size_t)pair * (nt + 1) * 1024;
+    // (a wavefront copies pieces 3 wv .. 3 wv + 2 of each image: the record has the LDS layout, so the instruction's immediate offset
+    // moves source and destination together and M0 - the LDS base - is written once per image, not per piece (attention6h.hip: 2 % of
+    // the launch there).  Nothing else in this kernel uses M0; the statements neither save nor restore it.)
     auto dma = [&](int j, int tile, uint16_t* ibuf, float* tbuf) __attribute__((always_inline)) {
-        if (j < 6) {                                            // pieces wv + 4 (j % 3) of matrix j / 3 (no branch: j is a constant)
-            const int piece = wv + 4 * (j % 3);
-            const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + piece * 1024 + lane * 16;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(
-                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + piece * 1024));
-            RLT_DMA_ASM(dst, rec);
+        if (j < 6) {                                            // pieces 3 wv + (j % 3) of matrix j / 3 (no branch: j is a constant)
+            const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + 3 * wv * 1024 + lane * 16;
+            if (j % 3 == 0) {
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + 3 * wv * 1024));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst) : "memory");
+            }
+            asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(rec), "n"((j % 3) * 1024) : "memory");
         } else if (DKV) {                                       // the seeds: every wavefront copies the same KiB (no branch on the wavefront)
             const uint8_t* rec = recs + (size_t)tile * 1024 + lane * 16;
             const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(tbuf)));
-            RLT_DMA_ASM(dst, rec);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(rec) : "memory");
         }
     };
     // prologue: tile 0 -> buffer 0
@@ -986,12 +991,14 @@ __global__ __launch_bounds__(256, RLT_A6N_OCC1) void attn6n_fwd1_kernel(AttnArgs
     const int npair = a.S * H;
     const uint8_t* rec0 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)0 * npair + pair) * (size_t)(nt + 1) * RECB;      // K images (block 0 of the forward's buffer)
     const uint8_t* rec1 = reinterpret_cast<const uint8_t*>(a.img) + ((size_t)1 * npair + pair) * (size_t)(nt + 1) * RECB;      // V images
-    auto dma = [&](int j, int tile, uint16_t* ibuf) __attribute__((always_inline)) {
-        const int piece = wv + 4 * (j % 3);
-        const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + piece * 1024 + lane * 16;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + piece * 1024));
-        RLT_DMA_ASM(dst, rec);
+    auto dma = [&](int j, int tile, uint16_t* ibuf) __attribute__((always_inline)) {       // (as in attn6n_bwd1_kernel: M0 once per image)
+        const uint8_t* rec = (j < 3 ? rec0 : rec1) + (size_t)tile * RECB + 3 * wv * 1024 + lane * 16;
+        if (j % 3 == 0) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(ibuf) + (j / 3) * (IMGT * 2) + 3 * wv * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst) : "memory");
+        }
+        asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(rec), "n"((j % 3) * 1024) : "memory");
     };
 #pragma unroll
     for (int j = 0; j < 6; ++j) dma(j, 0, img0);

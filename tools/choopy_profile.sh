@@ -2,7 +2,7 @@
 # Runs on the GPU box: BASELINE configs[2] (Choopy, 8192 lists x 300, head dim 16) in the DEFAULT bf16x6 mode - rocprofv3 kernel
 # stats + per-call table, the SQ counter pass and the two PMC traffic passes -> gpurun_out/TAG_choopy_bf16x6_* 
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 ARGS="--precision bf16x6 --model choopy --batch 8192 --steps 2 --warmup 1 --no-cpu-baseline --other-steps 0"

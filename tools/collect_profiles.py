@@ -36,7 +36,7 @@ def main():
         fetch = one(f"{tag}_pmc_fetch_{mode}/**/p_counter_collection.csv")
         write = one(f"{tag}_pmc_write_{mode}/**/p_counter_collection.csv")
         if fetch and write:
-            dom = {"fp32": "attn_bwd_dkv_kernel", "bf16x3": "attn3_bwd_dkv_kernel", "bf16x6": "attn6_bwd_dkv"}[mode]
+            dom = {"fp32": "attn_bwd_dkv_kernel", "bf16x3": "attn3_bwd_dkv_kernel", "bf16x6": "attn6_bwd_dkv"}[mode]      # (prefix: attn6_bwd_dkv1_kernel)
             with open(os.path.join(P, f"{tag}_pmc_traffic_{mode}.json"), "w") as f:
                 # steps in the profiled command: 1 warm-up + 2 timed + 3 kernel-timing steps
                 subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), fetch, write, dom,
@@ -48,6 +48,13 @@ def main():
     if trace:
         with open(os.path.join(P, f"{tag}_bench_choopy_b8192_per_call.txt"), "w") as f:
             subprocess.run([sys.executable, os.path.join(REPO, "tools", "trace_calls.py"), trace], stdout=f, check=True)
+    # the default-mode Choopy profile (tools/choopy_profile.sh), the SQ counter reports and the side configurations
+    for name in (f"{tag}_choopy_bf16x6_per_call.txt", f"{tag}_choopy_bf16x6_kernel_stats.csv", f"{tag}_pmc_sq_choopy_bf16x6.txt",
+                 f"{tag}_pmc_traffic_choopy_bf16x6.json", f"{tag}_pmc_sq_bf16x6.txt", f"{tag}_pmc_sq_fp32.txt", f"{tag}_pmc_sq_bf16x3.txt",
+                 f"{tag}_side_configs.txt"):
+        src = os.path.join(O, name)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(P, name))
     for f in sorted(os.listdir(P)):
         if f.startswith(tag):
             print(f)
