@@ -758,6 +758,39 @@ __global__ __launch_bounds__(256, 2) void attn6_bwd_dkv_kernel(AttnArgs a) {
 //   X(b): S (4 steps) and dP (4 steps) of block b into ONE score / dP accumulator pair;  Y(b): dV, dK of block b (8 steps)
 constexpr int QT1 = 256;
 struct Frag2 { bf16x8 h, m; };
+// LDS tile image of the two one-wavefront kernels below (they stage and split their tiles themselves, so the layout is theirs alone):
+// [plane][64 rows][64 d] bf16 with 128-byte rows, the 16-byte unit c of row r at c ^ swz1(r).  The padded 144-byte rows of the other kernels
+// of this file cost these two 21-27 % of their LDS cycles in bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r06_notes.md:
+// the transposed reads of four rows x 64 bytes wrap onto each other at a 36-bank stride); this one is conflict-free for the row fragments
+// (`ds_read_b128`: 16-lane groups of rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} at one unit), the transposed fragments
+// (`ds_read_b64_tr_b16`: 4 rows x 4 units per 32 lanes) and the staging stores (a row per 16 lanes) - tests/test_a6h_layout.py enumerates it.
+// RLT_A6_SWZ=0 (build switch): the padded layout (A/B runs).
+#ifndef RLT_A6_SWZ
+#define RLT_A6_SWZ 1
+#endif
+constexpr int LDR1 = RLT_A6_SWZ ? 64 : ldr6<64>(), PL1 = KT * LDR1, IMG1 = 3 * PL1;
+__host__ __device__ constexpr int swz1(int row) { return (((row >> 1) & 1) << 2) | ((row >> 3) & 3); }
+// element offset of bf16 element `col` (a multiple of 4) of row `row` in a plane
+__device__ __forceinline__ int img1_off(int row, int col) {
+#if RLT_A6_SWZ
+    return row * 64 + ((((col >> 3) ^ swz1(row)) << 3) | (col & 7));
+#else
+    return row * LDR1 + col;
+#endif
+}
+// prologue staging of a whole tile into that layout (the tile body stages through its generated chunks)
+__device__ __forceinline__ void stage1_store(uint16_t* __restrict__ img, int tid, const Stage6<64>& st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        uint2 h, m, l;
+        split4x3_6(st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w, h, m, l);
+        const int off = img1_off(idx / 16, 4 * (idx % 16));
+        *reinterpret_cast<uint2*>(img + off) = h;
+        *reinterpret_cast<uint2*>(img + PL1 + off) = m;
+        *reinterpret_cast<uint2*>(img + 2 * PL1 + off) = l;
+    }
+}
 #ifndef RLT_A6_MLAST
 #define RLT_A6_MLAST 0     // 1: the plane of the first product is read LAST so that one wait covers a step - measured 1 % slower
 #endif
@@ -779,7 +812,7 @@ __device__ unsigned long long dkv1_stamps[4 * 4 * 66];
 #endif
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
-    constexpr int HD = 64, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
+    constexpr int HD = 64, IMG6 = IMG1, PL = PL1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);              // [2 buffers][Q image | dO image]
     float* tab0 = reinterpret_cast<float*>(img0 + 4 * IMG6);         // [2 buffers][lse * log2e | delta | row hashes][KT]
@@ -852,8 +885,8 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         stage6_load<HD>(base, ld, 0, B, tid, rs);
         stage6_load<HD>(dobase, (size_t)E, 0, B, tid, r0);
         load_small(0);
-        stage6_store<HD>(img0, tid, rs, 1.f);
-        stage6_store<HD>(img0 + IMG6, tid, r0, 1.f);
+        stage1_store(img0, tid, rs);
+        stage1_store(img0 + IMG6, tid, r0);
         store_small(tab0, 0);
         const int r1 = min(1, nt - 1) * KT;
         stage6_load<HD>(base, ld, r1, B, tid, rs);
@@ -907,7 +940,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, kh = b & 1;
             const uint16_t* img = j < 4 ? Qc : Dc;
-            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
+            const int off = img1_off(sub * 32 + l31, 8 * hh + 16 * (j & 3));
             // issue order: the plane the FIRST product takes (m) LAST - LDS reads complete in order, so the one wait in front of
             // that product covers the whole step (issued m, l, h: a wait before each of the first three products)
             const int kk = RLT_A6_MLAST ? (j < 4 ? k : k + 1) : (k < 3 ? 3 - k : 0);
@@ -919,10 +952,10 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
         auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, s = j >> 2, which = (j >> 1) & 1, dt = j & 1;
             const uint16_t* img = which ? Qc : Dc;
-            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
-            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2) + 8 * (k & 1);
+            const int off = img1_off(row, 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
             const int pl = RLT_A6_MLAST ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 1 : k < 4 ? 2 : 0);     // h, l, m: the plane of the first product last
-            trv[u][pl][k & 1] = tr_read6(img + pl * PL + off + (k & 1) * 8 * LDR);
+            trv[u][pl][k & 1] = tr_read6(img + pl * PL + off);
         };
         auto tl = [&](int b, int c) __attribute__((always_inline)) {
             lvr[c & 1] = *reinterpret_cast<const float4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
@@ -1010,7 +1043,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
             if (part == 5) {
                 uint16_t* img = which ? Dn : Qn;
                 const int idx = tid + 256 * i;
-                const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
+                const int off = img1_off(idx / (HD / 4), 4 * (idx % (HD / 4)));
                 *reinterpret_cast<uint2*>(img + off) = sg[i].hi;
                 *reinterpret_cast<uint2*>(img + PL + off) = sg[i].mid;
                 *reinterpret_cast<uint2*>(img + 2 * PL + off) = sg[i].lo;
@@ -1053,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dkv1_kernel(AttnArgs a) {
 // zeros, so whatever dS they get multiplies a zero column of K^T - no mask on the scores.
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
-    constexpr int HD = 64, IMG6 = img6<HD>(), LDR = ldr6<HD>(), PL = plane6<HD>();
+    constexpr int HD = 64, IMG6 = IMG1, PL = PL1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* img0 = reinterpret_cast<uint16_t*>(smem);              // [2 buffers][K image | V image]
     uint32_t* tab0 = reinterpret_cast<uint32_t*>(img0 + 4 * IMG6);   // [2 buffers][KT] column hashes of the tile's keys (DROP)
@@ -1109,8 +1142,8 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         Stage6<HD> r0;
         stage6_load<HD>(base + E, ld, 0, B, tid, rs);               // (zero rows beyond B)
         stage6_load<HD>(base + 2 * E, ld, 0, B, tid, r0);
-        stage6_store<HD>(img0, tid, rs, 1.f);
-        stage6_store<HD>(img0 + IMG6, tid, r0, 1.f);
+        stage1_store(img0, tid, rs);
+        stage1_store(img0 + IMG6, tid, r0);
         if (DROP) tab0[trow] = rlt_col_hash(ps, (uint32_t)trow);
         const int r1 = min(1, nt - 1) * KT;
 #pragma unroll
@@ -1156,7 +1189,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         auto rx = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, qh = b & 1;
             const uint16_t* img = j < 4 ? Kc : Vc;
-            const int off = (sub * 32 + l31) * LDR + 8 * hh + 16 * (j & 3);
+            const int off = img1_off(sub * 32 + l31, 8 * hh + 16 * (j & 3));
             const int kk = RLT_A6_MLAST ? (j < 4 ? k : k + 1) : (k < 3 ? 3 - k : 0);     // (m last: see attn6_bwd_dkv1_kernel)
             if (kk == 0) qlr[u] = qlr_base[(qh * 4 + j) * 64];
             else if (kk == 1) afr[u].h = *reinterpret_cast<const bf16x8*>(img + off);
@@ -1165,10 +1198,10 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
         };
         auto ry = [&](int u, int k, int b, int j) __attribute__((always_inline)) {
             const int sub = b >> 1, s = j >> 1, dt = j & 1;
-            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2);
-            const int off = row * LDR + 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int row = sub * 32 + 16 * s + 4 * hh + ((lane & 15) >> 2) + 8 * (k & 1);
+            const int off = img1_off(row, 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
             const int pl = RLT_A6_MLAST ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 1 : k < 4 ? 2 : 0);
-            trv[u][pl][k & 1] = tr_read6(Kc + pl * PL + off + (k & 1) * 8 * LDR);
+            trv[u][pl][k & 1] = tr_read6(Kc + pl * PL + off);
         };
         auto te = [&](int b, int c) __attribute__((always_inline)) {
             if (DROP) hvr[c & 1] = *reinterpret_cast<const uint4*>(Tc + (b >> 1) * 32 + 8 * c + 4 * hh);
@@ -1240,7 +1273,7 @@ __global__ __launch_bounds__(256, 1) void attn6_bwd_dq1_kernel(AttnArgs a) {
             split6_part(sg[i], rs.v[i].x, rs.v[i].y, rs.v[i].z, rs.v[i].w, part);
             if (part == 5) {
                 uint16_t* img = which ? Vn : Kn;
-                const int off = (idx / (HD / 4)) * LDR + 4 * (idx % (HD / 4));
+                const int off = img1_off(idx / (HD / 4), 4 * (idx % (HD / 4)));
                 *reinterpret_cast<uint2*>(img + off) = sg[i].hi;
                 *reinterpret_cast<uint2*>(img + PL + off) = sg[i].mid;
                 *reinterpret_cast<uint2*>(img + 2 * PL + off) = sg[i].lo;
@@ -1389,13 +1422,13 @@ static int attn6_launch(int which, const AttnArgs& a, hipStream_t st) {
         static const bool dq1 = [] { const char* e = getenv("RLT_A6_DQ1"); return !e || atoi(e) != 0; }();
         const bool small24 = (long long)a.B * 3 * a.H * HD < (1ll << 24);     // their loaders form B * ld in 24-bit multiplies
         if (which == 2 && dq1 && small24) {
-            const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
+            const size_t shm1 = (size_t)4 * IMG1 * sizeof(uint16_t) + 2 * KT * sizeof(uint32_t) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
             if ((rc = rlt_allow_lds(attn6_bwd_dq1_kernel<DROP>, shm1))) return rc;
             hipLaunchKernelGGL((attn6_bwd_dq1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
             return RLT_LAUNCH_RESULT();
         }
         if (which == 1 && dkv1 && small24) {
-            const size_t shm1 = (size_t)4 * img6<HD>() * sizeof(uint16_t) + 2 * 3 * KT * sizeof(float) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
+            const size_t shm1 = (size_t)4 * IMG1 * sizeof(uint16_t) + 2 * 3 * KT * sizeof(float) + (size_t)4 * 2 * 4 * 64 * sizeof(uint4);
             if ((rc = rlt_allow_lds(attn6_bwd_dkv1_kernel<DROP>, shm1))) return rc;
             hipLaunchKernelGGL((attn6_bwd_dkv1_kernel<DROP>), dim3(a.S * a.H * rlt_cdiv(a.B, QT1)), dim3(256), shm1, st, a);
             return RLT_LAUNCH_RESULT();
