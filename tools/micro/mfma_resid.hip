@@ -132,23 +132,27 @@ __global__ void check32(const float* __restrict__ x, uint32_t* __restrict__ out,
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, d, 0, 0, 0);
     for (int i = 0; i < 8; ++i) lp[i] = pk2(d[2 * i], d[2 * i + 1]);
     int nbad = 0;
+    // (round 6: `__builtin_bit_cast(uint32_t, c[i])` on an ELEMENT of an ext-vector compiles to a read of element 0 - hipcc 7.2 -, which is what
+    // made this check report "register 0 identical, registers 1..15 not" for two rounds; the elements are copied to scalars first)
+    float cs[16], ds_[16];
+    for (int i = 0; i < 16; ++i) { cs[i] = c[i]; ds_[i] = d[i]; }
     for (int i = 0; i < 16; ++i) {
-        if (__builtin_bit_cast(uint32_t, c[i]) != __builtin_bit_cast(uint32_t, ref1[i])) {
+        if (__builtin_bit_cast(uint32_t, cs[i]) != __builtin_bit_cast(uint32_t, ref1[i])) {
             ++nbad;
-            if (atomicAdd(bad + 1, 1ull) == 0) { out[8] = __builtin_bit_cast(uint32_t, v[i]); out[9] = __builtin_bit_cast(uint32_t, c[i]); out[10] = __builtin_bit_cast(uint32_t, ref1[i]); out[11] = lane * 16 + i; }
+            if (atomicAdd(bad + 1, 1ull) == 0) { out[8] = __builtin_bit_cast(uint32_t, v[i]); out[9] = __builtin_bit_cast(uint32_t, cs[i]); out[10] = __builtin_bit_cast(uint32_t, ref1[i]); out[11] = lane * 16 + i; }
             atomicOr(out + 6, 1u << i);
             if (lane < 32) atomicOr(out + 7, 1u << lane);
         }
-        if (__builtin_bit_cast(uint32_t, d[i]) != __builtin_bit_cast(uint32_t, ref2[i])) {
+        if (__builtin_bit_cast(uint32_t, ds_[i]) != __builtin_bit_cast(uint32_t, ref2[i])) {
             ++nbad;
-            if (atomicAdd(bad + 2, 1ull) == 0) { out[12] = __builtin_bit_cast(uint32_t, ref1[i]); out[13] = __builtin_bit_cast(uint32_t, d[i]); out[14] = __builtin_bit_cast(uint32_t, ref2[i]); out[15] = lane * 16 + i; }
+            if (atomicAdd(bad + 2, 1ull) == 0) { out[12] = __builtin_bit_cast(uint32_t, ref1[i]); out[13] = __builtin_bit_cast(uint32_t, ds_[i]); out[14] = __builtin_bit_cast(uint32_t, ref2[i]); out[15] = lane * 16 + i; }
         }
     }
     for (int i = 0; i < 8; ++i) { nbad += mp[i] != mpr[i]; nbad += lp[i] != lpr[i]; }
     if (nbad) {
         if (atomicAdd(bad, (unsigned long long)nbad) == 0) {
-            out[0] = __builtin_bit_cast(uint32_t, v[0]); out[1] = __builtin_bit_cast(uint32_t, c[0]); out[2] = __builtin_bit_cast(uint32_t, ref1[0]);
-            out[3] = __builtin_bit_cast(uint32_t, d[0]); out[4] = __builtin_bit_cast(uint32_t, ref2[0]); out[5] = (uint32_t)lane;
+            out[0] = __builtin_bit_cast(uint32_t, v[0]); out[1] = __builtin_bit_cast(uint32_t, cs[0]); out[2] = __builtin_bit_cast(uint32_t, ref1[0]);
+            out[3] = __builtin_bit_cast(uint32_t, ds_[0]); out[4] = __builtin_bit_cast(uint32_t, ref2[0]); out[5] = (uint32_t)lane;
         }
     }
 }
