@@ -352,8 +352,10 @@ int rlt_bilstm_rec_bwd(float* gates, const float* c, const float* w_hh_fwd, cons
  * rlt_workspace_bytes(op, S, B, E, H, FF, train_dropout) reports their sizes; all regions are 256-byte aligned, pass
  * 256-byte aligned buffers.  For the RLT_OP_BILSTM_* queries E = the input feature count of layer 0, H and FF unused.
  */
-#define RLT_OP_ENCODER_STASH   1   /* stash of rlt_encoder_layer_fwd/bwd                                        */
-#define RLT_OP_ENCODER_FWD_WS  2   /* ws of rlt_encoder_layer_fwd                                               */
+#define RLT_OP_ENCODER_STASH   1   /* stash of rlt_encoder_layer_fwd/bwd (attention tile records only where the backward reads
+                                    * them: rlt_list_attention_images_retained; independent of train_dropout)  */
+#define RLT_OP_ENCODER_FWD_WS  2   /* ws of rlt_encoder_layer_fwd: split-K scratch + the attention images that are scratch of the
+                                    * forward call (the pipelined bf16x6 forward kernels; train_dropout = the call's drop_p > 0) */
 #define RLT_OP_ENCODER_BWD_WS  3   /* ws of rlt_encoder_layer_bwd (train_dropout != 0: + two (T,E) dropout grads) */
 #define RLT_OP_BILSTM_STASH    4   /* stash of rlt_bilstm_fwd/bwd                                               */
 #define RLT_OP_BILSTM_WS       5   /* ws of rlt_bilstm_fwd and rlt_bilstm_bwd                                   */
